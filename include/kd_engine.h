@@ -1,0 +1,190 @@
+/*
+ * kd_engine.h — C ABI of libkd_engine.so, the MI355X (gfx950) denoising engine that sits
+ * under the drop-in `imagen_pytorch` package of this repo.
+ *
+ * The reference (jameshball/kidney-diffusion) has no FFI: its hot path is the Python API of
+ * the third-party `imagen-pytorch==1.18.5` (reference requirements.txt:37).  Each entry point
+ * below names the reference-side call it replaces (file:line in /root/reference) and, for the
+ * arithmetic, the SURVEY.md Appendix A item it implements.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (HBM), borrowed, never freed by the library;
+ *   - `stream` is a hipStream_t passed as void*; all calls are stream-ordered, no hidden syncs
+ *     (kd_unet_create / kd_sampler_create allocate and synchronise; nothing else does);
+ *   - every function returns 0 on success, non-zero on failure; kd_last_error() gives the text;
+ *   - images are fp32 NCHW exactly as the reference passes them (sample_ultra_res.py:183-195);
+ *     feature maps inside the engine are fp32 NHWC (DESIGN.md "Data layout").
+ */
+#ifndef KD_ENGINE_H
+#define KD_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KD_MAX_LEVELS 8
+
+const char* kd_last_error(void);
+int kd_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * UNet.  Replaces `Unet(...)` construction + `Unet.forward` of imagen-pytorch as configured at
+ * train_ultra_res.py:29-60, train.py:30-65, train_uncond.py:30-61.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct kd_unet_config {
+  int dim;
+  int num_levels;
+  int dim_mults[KD_MAX_LEVELS];
+  int num_resnet_blocks[KD_MAX_LEVELS];
+  int layer_attns[KD_MAX_LEVELS];
+  int layer_cross_attns[KD_MAX_LEVELS];
+  int cond_dim;               /* already defaulted to dim by the host */
+  int channels;               /* 3 */
+  int cond_images_channels;   /* 0 / 3 / 4 / 6 */
+  int lowres_cond;            /* set by Imagen for unets after the first */
+  int memory_efficient;
+  int init_conv_to_final_conv_residual;
+  int cond_on_text;
+  int text_tokens;            /* number of pooled text tokens handed to forward (0 if none) */
+  int attn_heads;             /* 8 */
+  int attn_dim_head;          /* 64 */
+  int ff_mult_x2;             /* 2*ff_mult, integer (4 for ff_mult=2) */
+  int num_time_tokens;        /* 2 */
+  int sinu_dim;               /* learned_sinu_pos_emb_dim, 16 */
+  int resnet_groups;          /* 8 */
+  int attend_at_middle;       /* 1 */
+  int use_gca;                /* use_global_context_attn, 1 */
+  /* static shape of the plan */
+  int batch;
+  int image_size;             /* S: x is [batch, channels, S, S] */
+} kd_unet_config_t;
+
+/* One named parameter tensor of the UNet's state_dict (key WITHOUT the `unets.N.` prefix,
+ * e.g. "downs.0.1.block1.project.weight"), fp32, contiguous, torch layout, on the device. */
+typedef struct kd_param {
+  const char* name;
+  const float* d_data;
+  int64_t numel;
+} kd_param_t;
+
+typedef struct kd_unet kd_unet_t;
+
+/* Builds the execution plan, re-packs the weights into the engine's layouts (copies; the
+ * caller may free its tensors afterwards) and allocates the activation workspace. */
+int kd_unet_create(const kd_unet_config_t* cfg, const kd_param_t* params, int n_params,
+                   kd_unet_t** out);
+void kd_unet_destroy(kd_unet_t* u);
+/* bytes of HBM held (weights + workspace) and algorithmic MACs of one forward (whole batch) */
+int64_t kd_unet_hbm_bytes(const kd_unet_t* u);
+int64_t kd_unet_macs(const kd_unet_t* u);
+int kd_unet_num_launches(const kd_unet_t* u);
+
+/* Replaces `unet.forward_with_cond_scale(x, log_snr(t), lowres_cond_img=..,
+ * lowres_noise_times=.., cond_images=.., text_embeds=..)` at cond_scale == 1.
+ *   d_x            [B,3,S,S]
+ *   d_lowres       [B,3,S,S] or NULL (required iff cfg.lowres_cond)
+ *   d_cond_images  [B,Cc,S,S] already nearest-resized to S, or NULL (required iff Cc > 0)
+ *   d_log_snr      [B] log-SNR of the current time; d_lowres_log_snr [B] or NULL
+ *   d_text_tokens  [B,text_tokens,cond_dim] pooled text tokens (pre norm_cond) or NULL
+ *   d_text_hiddens [B,time_cond_dim] or NULL
+ *   d_out          [B,3,S,S] */
+int kd_unet_forward(kd_unet_t* u, const float* d_x, const float* d_lowres,
+                    const float* d_cond_images, const float* d_log_snr,
+                    const float* d_lowres_log_snr, const float* d_text_tokens,
+                    const float* d_text_hiddens, float* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sampler.  Replaces `Imagen.p_sample_loop` / `p_sample` / `p_mean_variance` (SURVEY §3.2,
+ * A.2) as entered from sample_ultra_res.py:183-195, outpainting.py:146-157,
+ * sample_cond.py:40-48, sample_uncond.py:49-55.
+ * ---------------------------------------------------------------------------------------- */
+enum { KD_OBJ_NOISE = 0, KD_OBJ_V = 1, KD_OBJ_X_START = 2 };
+
+/* Per-(timestep) scalars precomputed by the host in fp32 exactly as the library's torch ops
+ * produce them.  All arrays have T entries. */
+typedef struct kd_schedule {
+  int T;
+  const float* log_snr;       /* log_snr(t_k)            -> UNet time input               */
+  const float* alpha;         /* sqrt(sigmoid(log_snr))                                    */
+  const float* sigma;         /* sqrt(sigmoid(-log_snr))                                   */
+  const float* alpha_next;    /* alpha at t_{k+1}                                          */
+  const float* sigma_next;    /* sigma at t_{k+1}                                          */
+  const float* c;             /* -expm1(log_snr - log_snr_next)                            */
+  const float* noise_scale;   /* [t_next != 0] * exp(0.5*log(max(sigma_next^2*c,1e-20)))   */
+  /* inpainting re-noise t_next -> t:  x*rn_a + noise*rn_b ; 0-length use allowed if unused */
+  const float* rn_a;          /* alpha_t/alpha_next                                         */
+  const float* rn_b;          /* (sigma_t*alpha_next - sigma_next*alpha_t)/alpha_next       */
+} kd_schedule_t;
+
+typedef struct kd_sample_args {
+  int objective;              /* KD_OBJ_*  (train_ultra_res.py:87, train.py:90) */
+  int dynamic_threshold;      /* 1: s = max(1, quantile_0.95 |x0|) per sample   */
+  float percentile;           /* 0.95 */
+  int resample_times;         /* inpaint_resample_times if inpainting else 1 (sample_ultra_res.py:192) */
+  /* conditioning, constant over the loop */
+  const float* d_lowres;          /* [B,3,S,S] noised low-res conditioning or NULL */
+  const float* d_lowres_log_snr;  /* [B] or NULL */
+  const float* d_cond_images;     /* [B,Cc,S,S] or NULL */
+  const float* d_text_tokens;     /* or NULL */
+  const float* d_text_hiddens;    /* or NULL */
+  /* inpainting (both NULL or both set): image already normalised to [-1,1] and resized,
+   * mask [B,1,S,S] as 0/1 floats (sample_ultra_res.py:149-174) */
+  const float* d_inpaint_images;
+  const float* d_inpaint_masks;
+  /* noise: explicit tensors (parity tests) or on-device Philox (seed) when the pointer is NULL.
+   * d_noise_step    [T*R,B,3,S,S]   index (k*R + (R-1-r))
+   * d_noise_inpaint [T*R,B,3,S,S]   same indexing (only read when inpainting)
+   * d_noise_renoise [T*R,B,3,S,S]   same indexing (only read when inpainting and r != 0) */
+  const float* d_noise_step;
+  const float* d_noise_inpaint;
+  const float* d_noise_renoise;
+  uint64_t seed;
+  int use_graph;              /* 1: capture one step into a hipGraph and replay it */
+} kd_sample_args_t;
+
+/* In: d_img = x_T [B,3,S,S].  Out: d_img = unnormalised sample in [0,1] (clamp, final inpaint
+ * paste and (x+1)/2 included).  Runs all T*R denoising iterations on `stream`. */
+int kd_sample_loop(kd_unet_t* u, const kd_schedule_t* sched, const kd_sample_args_t* args,
+                   float* d_img, void* stream);
+/* Runs iterations [k_begin, k_end) only, without the final clamp/unnormalise (used by bench.py
+ * to time exactly K steps, and by tests to compare intermediate states). */
+int kd_sample_steps(kd_unet_t* u, const kd_schedule_t* sched, const kd_sample_args_t* args,
+                    float* d_img, int k_begin, int k_end, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Individual kernels, exported so that tests/ can check each one against the oracle through
+ * the same ABI the plan uses internally.
+ * ---------------------------------------------------------------------------------------- */
+
+/* 2-D convolution as implicit GEMM on fp32 MFMA.  x: NHWC [B,Hi,Wi,Cin]; w: torch OIHW
+ * [Cout,Cin,KH,KW] (re-packed internally on each call of this test entry); y: NHWC.
+ * act: 0 none, 1 SiLU, 2 GELU(erf). */
+int kd_conv2d_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias, float* d_y,
+                   int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                   int act, void* stream);
+/* GroupNorm(G) + optional FiLM (scale+1, shift: [B,2C] = [scale | shift]) + SiLU, NHWC. */
+int kd_groupnorm_silu_nhwc(const float* d_x, const float* d_gamma, const float* d_beta,
+                           const float* d_scale_shift, float* d_y, int B, int HW, int C, int G,
+                           float eps, void* stream);
+/* LayerNorm over the last dim of [rows, C]; beta may be NULL (gain-only). */
+int kd_layernorm(const float* d_x, const float* d_g, const float* d_beta, float* d_y,
+                 int rows, int C, float eps, void* stream);
+/* Attention with fp32 softmax.  q [B,Nq,H,D] (already scaled), k/v [B,Nk,Hkv,D] with
+ * Hkv in {1,H}; out [B,Nq,H,D].  D must be 64. */
+int kd_attention(const float* d_q, const float* d_k, const float* d_v, float* d_out,
+                 int B, int Nq, int Nk, int H, int Hkv, int D, void* stream);
+/* Per-sample linear-interpolated quantile of |x| over n values (torch.quantile semantics). */
+int kd_quantile_abs(const float* d_x, float* d_out, int B, int64_t n, float q, void* d_workspace,
+                    size_t workspace_bytes, void* stream);
+size_t kd_quantile_workspace_bytes(int B);
+/* Standard-normal Philox4x32-10 fill (the generator kd_sample_loop uses when no noise tensors
+ * are given): element i of stream `stream_id` under `seed`. */
+int kd_philox_normal(float* d_out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KD_ENGINE_H */

@@ -1,0 +1,135 @@
+// Internal declarations shared by the engine's translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+namespace kd {
+
+void set_error(const std::string& msg);
+
+#define KD_HIP_CHECK(expr)                                                               \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      ::kd::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " at " + \
+                      __FILE__ + ":" + std::to_string(__LINE__));                        \
+      return 1;                                                                          \
+    }                                                                                    \
+  } while (0)
+
+#define KD_REQUIRE(cond, msg)                                                             \
+  do {                                                                                    \
+    if (!(cond)) {                                                                        \
+      ::kd::set_error(std::string("requirement failed: ") + #cond + " — " + (msg) + " at " + \
+                      __FILE__ + ":" + std::to_string(__LINE__));                         \
+      return 1;                                                                           \
+    }                                                                                     \
+  } while (0)
+
+enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_SIGMOID = 3 };
+enum OutMode { OUT_NHWC = 0, OUT_PIXSHUF = 1, OUT_NCHW = 2 };
+
+// Implicit-GEMM convolution / token GEMM.  y[m][n] = sum_{tap,c} x[pix(m,tap)][c] * w[tap][n][c]
+struct ConvParams {
+  const float* x;   // NHWC, channel stride ldx (>= Cin), 16-B aligned rows
+  const float* w;   // packed [KH*KW][Cout][Cin]
+  const float* bias;
+  float* y;
+  int B, Hi, Wi, Cin, ldx;
+  int Ho, Wo, Cout;
+  int KH, KW, stride, pad;
+  int act;
+  const float* res;       // y += res[m][n]   (row stride ldres)
+  int ldres;
+  const float* gate_src;  // y += gate_src[m][n] * gate[b][n]   (resblock tail: h*gca + res_conv(x))
+  const float* gate;      // [B][Cout]
+  int ldgs;
+  int out_mode;
+  int ldy, yoff;          // OUT_NHWC: y[m*ldy + yoff + n]
+};
+
+int launch_conv_igemm(const ConvParams& p, hipStream_t s);
+int64_t conv_macs(const ConvParams& p);
+
+// weight re-packing (device→device)
+// OIHW -> [tap][O][Ipad] (zero for i >= I)
+int launch_pack_oihw(const float* w_oihw, float* w_packed, int O, int I, int Ipad, int KH, int KW, hipStream_t s);
+// Downsample conv1x1 over pixel-unshuffled input ([O][4C], k = c*4+s1*2+s2) -> [tap=s1*2+s2][O][C]
+int launch_pack_unshuffle(const float* w, float* w_packed, int O, int C, hipStream_t s);
+// PixelShuffle conv1x1 ([4Co][I], n = c*4+i*2+j) -> rows n' = (i*2+j)*Co + c ; same for bias
+int launch_pack_shuffle(const float* w, const float* b, float* w_packed, float* b_packed, int Co, int I,
+                        hipStream_t s);
+
+// ---- norms / elementwise (kernels_norm.hip)
+int launch_gn_stats(const float* x, int ldx, float* stats /*[B][G][2] mean,rstd*/, double* partial,
+                    int B, int HW, int C, int G, float eps, hipStream_t s);
+size_t gn_partial_bytes(int B, int HW, int C, int G);
+int launch_gn_apply_silu(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
+                         const float* scale_shift /*row b: [scale(C) | shift(C)], row stride ld_ss; or null*/,
+                         int ld_ss, float* y, int B, int HW, int C, int G, hipStream_t s);
+// y = LN(x)*g (+beta) (+res)
+int launch_layernorm(const float* x, const float* g, const float* beta, const float* res, float* y, int rows,
+                     int C, float eps, hipStream_t s);
+int launch_concat2(const float* a, int Ca, const float* b, int Cb, float scale_b, float* y, int64_t rows,
+                   hipStream_t s);
+// y = a*gate[b][c] + r   (NHWC, rows = B*HW)
+int launch_gate_add(const float* a, const float* gate, const float* r, float* y, int B, int HW, int C,
+                    hipStream_t s);
+int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s);
+int launch_act(const float* a, float* y, int64_t n, int act, hipStream_t s);
+// init image assembly: NCHW planes -> NHWC [B][H][W][Cpad] with channel order cond | x | lowres, zero pad
+int launch_pack_init(const float* cond, int Cc, const float* x, const float* lowres, int Cl, float* y, int Cpad,
+                     int B, int HW, hipStream_t s);
+// y[b][r][:] rows copy helper for building key/value buffers: dst[b][row_off + r][c] = src[b][r][c]
+int launch_copy_rows(const float* src, int64_t src_bstride, int ld_src, float* dst, int64_t dst_bstride,
+                     int ld_dst, int rows, int C, int B, hipStream_t s);
+// dst[b][row][c] = src[c] (broadcast one row to every batch)
+int launch_bcast_row(const float* src, float* dst, int64_t dst_bstride, int C, int B, hipStream_t s);
+
+// ---- attention / gca / skinny linear (kernels_attn.hip)
+// q [B][Nq][H*D] with row stride ldq; out [B][Nq][H*D].  Keys = optional shared null key/value
+// (64 floats each, same for every head and batch) followed by up to two segments
+// k,v [B][n][Hkv*D] with row strides ld.
+struct KVSeg {
+  const float* k;
+  const float* v;
+  int ld;
+  int n;
+};
+int launch_attention(const float* q, int ldq, const float* null_k, const float* null_v, KVSeg s0, KVSeg s1,
+                     float* out, int ldo, int B, int Nq, int H, int Hkv, float scale, hipStream_t s);
+// y[m][n] = act( sum_k f(x[m][k]) * w[n][k] + bias[n] ) for small M (<= 64); in_act applied to x
+int launch_linear_skinny(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int M,
+                         int K, int N, int in_act, int act, hipStream_t s);
+// GlobalContext: logits[b][p] = x[b][p][:]·wk + bk ; pooled[b][c] = sum_p softmax_p(logits) x[b][p][c]
+int launch_gca_pool(const float* x, const float* wk, const float* bk, float* logits, float* pooled,
+                    float* scratch, int B, int HW, int C, hipStream_t s);
+size_t gca_scratch_floats(int B, int HW, int C);
+// time embedding: out[b][0]=t, [1..h]=sin(t*w*2pi), [h+1..2h]=cos
+int launch_sinu_emb(const float* t, const float* w, float* out, int B, int half, hipStream_t s);
+
+// ---- sampler (kernels_sampler.hip)
+struct StepTables {  // device arrays of T floats
+  const float *log_snr, *alpha, *sigma, *alpha_next, *sigma_next, *c, *noise_scale, *rn_a, *rn_b;
+};
+int launch_fill_time(const float* table, const int* d_iter, int R, float* out, int B, hipStream_t s);
+int launch_x0(const float* x, const float* pred, float* x0, const StepTables& tb, const int* d_iter, int R,
+              int objective, int64_t n, hipStream_t s);
+int launch_quantile_abs(const float* x, float* out, int B, int64_t n, float q, void* ws, hipStream_t s);
+size_t quantile_ws_bytes(int B);
+int launch_ddpm_update(float* x, const float* x0, const float* s_thresh, const float* noise, int64_t noise_stride,
+                       uint64_t seed, const StepTables& tb, const int* d_iter, int R, int dynamic_threshold,
+                       int B, int64_t per, hipStream_t s);
+int launch_inpaint_mix(float* x, const float* inp, const float* mask, const float* noise, int64_t noise_stride,
+                       uint64_t seed, const StepTables& tb, const int* d_iter, int R, int B, int C, int64_t hw,
+                       hipStream_t s);
+int launch_renoise(float* x, const float* noise, int64_t noise_stride, uint64_t seed, const StepTables& tb,
+                   const int* d_iter, int R, int T, int B, int64_t per, hipStream_t s);
+int launch_iter_set(int* d_iter, int value, hipStream_t s);
+int launch_finalize(float* x, const float* inp, const float* mask, int B, int C, int64_t hw, hipStream_t s);
+int launch_iter_inc(int* d_iter, hipStream_t s);
+int launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, hipStream_t s);
+
+}  // namespace kd

@@ -1,0 +1,619 @@
+// libkd_engine: UNet execution plan, sampler loop and the C ABI of include/kd_engine.h.
+//
+// The plan builder walks the same module tree the host-side `Unet` class declares
+//  and emits a flat list of kernel launches with static shapes and
+// static workspace offsets, so one denoising iteration can be captured into a hipGraph and
+// replayed.  Feature maps are NHWC fp32; token tensors [B,N,C] are the same memory.
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/kd_engine.h"
+#include "common.h"
+
+namespace kd {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+#define KD_THROW_IF(expr)                                          \
+  do {                                                             \
+    if ((expr) != 0) throw std::runtime_error(::kd::g_err);        \
+  } while (0)
+#define KD_HIP_THROW(expr)                                                                       \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess)                                                                        \
+      throw std::runtime_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));        \
+  } while (0)
+
+// ------------------------------------------------------------------------------ memory helpers
+struct WeightPool {  // engine-owned HBM for weights, bump-allocated from 256 MiB slabs
+  std::vector<void*> slabs;
+  char* cur = nullptr;
+  size_t left = 0, total = 0;
+  float* alloc(size_t n_floats) {
+    size_t bytes = (n_floats * sizeof(float) + 255) & ~size_t(255);
+    if (bytes > left) {
+      size_t slab = std::max(bytes, size_t(256) << 20);
+      void* p = nullptr;
+      KD_HIP_THROW(hipMalloc(&p, slab));
+      slabs.push_back(p);
+      cur = (char*)p;
+      left = slab;
+      total += slab;
+    }
+    float* r = (float*)cur;
+    cur += bytes;
+    left -= bytes;
+    return r;
+  }
+  ~WeightPool() {
+    for (void* p : slabs) (void)hipFree(p);
+  }
+};
+
+struct Arena {  // plan-time activation allocator with reuse (single in-order stream => safe)
+  struct Blk {
+    size_t off, size;
+    bool free;
+  };
+  std::vector<Blk> blks;
+  size_t end = 0, peak = 0;
+  size_t alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~size_t(255);
+    if (bytes == 0) bytes = 256;
+    for (size_t i = 0; i < blks.size(); ++i) {
+      if (blks[i].free && blks[i].size >= bytes) {
+        if (blks[i].size > bytes) {
+          Blk rest{blks[i].off + bytes, blks[i].size - bytes, true};
+          blks[i].size = bytes;
+          blks.insert(blks.begin() + i + 1, rest);
+        }
+        blks[i].free = false;
+        return blks[i].off;
+      }
+    }
+    if (!blks.empty() && blks.back().free) {  // grow the trailing free block
+      blks.back().size = bytes;
+      blks.back().free = false;
+      end = blks.back().off + bytes;
+      peak = std::max(peak, end);
+      return blks.back().off;
+    }
+    blks.push_back(Blk{end, bytes, false});
+    end += bytes;
+    peak = std::max(peak, end);
+    return blks.back().off;
+  }
+  void release(size_t off) {
+    for (size_t i = 0; i < blks.size(); ++i) {
+      if (blks[i].off == off && !blks[i].free) {
+        blks[i].free = true;
+        if (i + 1 < blks.size() && blks[i + 1].free) {
+          blks[i].size += blks[i + 1].size;
+          blks.erase(blks.begin() + i + 1);
+        }
+        if (i > 0 && blks[i - 1].free) {
+          blks[i - 1].size += blks[i].size;
+          blks.erase(blks.begin() + i);
+        }
+        return;
+      }
+    }
+    throw std::runtime_error("arena: release of unknown offset");
+  }
+};
+
+struct T {  // NHWC tensor in the workspace
+  size_t off = 0;
+  int B = 0, H = 0, W = 0, C = 0;
+  int64_t rows() const { return (int64_t)B * H * W; }
+  int HW() const { return H * W; }
+};
+
+}  // namespace kd
+
+using namespace kd;
+
+// ------------------------------------------------------------------------------ the UNet object
+struct kd_unet {
+  kd_unet_config_t cfg;
+  std::vector<std::function<int(hipStream_t)>> ops;
+  WeightPool wpool;
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  int64_t macs = 0;
+  int time_cond_dim = 0;
+  // per-call I/O (read by the ops at run time)
+  const float *in_x = nullptr, *in_lowres = nullptr, *in_cond = nullptr, *in_log_snr = nullptr,
+              *in_lowres_log_snr = nullptr, *in_text_tokens = nullptr, *in_text_hiddens = nullptr;
+  float* out = nullptr;
+  // sampler scratch (allocated on first use)
+  float *s_pred = nullptr, *s_x0 = nullptr, *s_thresh = nullptr, *s_time = nullptr, *s_tables = nullptr;
+  int* s_iter = nullptr;
+  void* s_qws = nullptr;
+  int s_tables_cap = 0;
+  // cached graph of one iteration
+  hipGraphExec_t graph_exec = nullptr;
+  std::vector<uint64_t> graph_key;
+
+  float* P(size_t off) const { return (float*)(ws + off); }
+  ~kd_unet() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    void* frees[] = {ws, s_pred, s_x0, s_thresh, s_time, s_tables, s_iter, s_qws};
+    for (void* p : frees)
+      if (p) (void)hipFree(p);
+  }
+};
+
+namespace kd {
+
+// ------------------------------------------------------------------------------ plan builder
+struct Builder {
+  kd_unet* u;
+  Arena arena;
+  std::unordered_map<std::string, std::pair<const float*, int64_t>> params;
+  std::unordered_map<std::string, const float*> owned;  // engine-owned copies of raw params
+  const kd_unet_config_t& cfg;
+  int B;
+  // batched time-MLP: every ResnetBlock's Linear(time_cond_dim, 2*dim_out) in one skinny GEMM
+  std::vector<std::string> tmlp_prefixes;
+  std::unordered_map<std::string, int> tmlp_off;
+  int tmlp_total = 0;
+  float *tmlp_w = nullptr, *tmlp_b = nullptr;
+  T t_ss;  // [B, tmlp_total] scale|shift rows for all blocks
+  // shared scratch
+  T gn_stats_t, gn_partial_t;
+  size_t gn_partial_max = 0;
+
+  Builder(kd_unet* u_) : u(u_), cfg(u_->cfg), B(u_->cfg.batch) {}
+
+  // ---- parameters
+  bool has(const std::string& n) const { return params.count(n) != 0; }
+  int64_t numel(const std::string& n) const {
+    auto it = params.find(n);
+    if (it == params.end()) throw std::runtime_error("missing parameter '" + n + "'");
+    return it->second.second;
+  }
+  const float* raw(const std::string& n, int64_t expect = -1) {
+    auto it = params.find(n);
+    if (it == params.end()) throw std::runtime_error("missing parameter '" + n + "'");
+    if (expect >= 0 && it->second.second != expect)
+      throw std::runtime_error("parameter '" + n + "' has " + std::to_string(it->second.second) +
+                               " elements, plan expects " + std::to_string(expect));
+    return it->second.first;
+  }
+  const float* P(const std::string& n, int64_t expect = -1) {  // engine-owned copy, torch layout
+    auto it = owned.find(n);
+    if (it != owned.end()) return it->second;
+    const float* src = raw(n, expect);
+    int64_t ne = numel(n);
+    float* dst = u->wpool.alloc((size_t)ne);
+    KD_HIP_THROW(hipMemcpyAsync(dst, src, (size_t)ne * sizeof(float), hipMemcpyDeviceToDevice, 0));
+    owned[n] = dst;
+    return dst;
+  }
+  const float* pack_conv(const std::string& n, int O, int I, int Ipad, int K) {
+    const float* src = raw(n, (int64_t)O * I * K * K);
+    float* dst = u->wpool.alloc((size_t)O * Ipad * K * K);
+    KD_THROW_IF(launch_pack_oihw(src, dst, O, I, Ipad, K, K, 0));
+    return dst;
+  }
+
+  // ---- activations
+  T alloc(int b, int h, int w, int c) {
+    T t;
+    t.B = b; t.H = h; t.W = w; t.C = c;
+    t.off = arena.alloc((size_t)b * h * w * c * sizeof(float));
+    refs[t.off] = 1;
+    return t;
+  }
+  T alloc_bytes(size_t bytes) {
+    T t;
+    t.B = 1; t.H = 1; t.W = 1; t.C = (int)((bytes + 3) / 4);
+    t.off = arena.alloc(bytes);
+    refs[t.off] = 1;
+    return t;
+  }
+  // every builder function returns a tensor owned by the caller (refcount 1) and never releases
+  // its inputs; skip connections take an extra reference with retain().
+  std::unordered_map<size_t, int> refs;
+  void retain(const T& t) { refs[t.off] += 1; }
+  void free(const T& t) {
+    auto it = refs.find(t.off);
+    if (it == refs.end() || it->second <= 0) throw std::runtime_error("plan: release of a dead tensor");
+    if (--it->second == 0) {
+      refs.erase(it);
+      arena.release(t.off);
+    }
+  }
+  void emit(std::function<int(hipStream_t)> f) { u->ops.push_back(std::move(f)); }
+
+  // ---- conv / GEMM emission
+  struct ConvOpt {
+    int act = ACT_NONE;
+    const T* res = nullptr;       // y += res
+    const T* gate_src = nullptr;  // y += gate_src * gate
+    const T* gate = nullptr;
+    int out_mode = OUT_NHWC;
+    const T* dst = nullptr;  // write into channel slice [yoff, yoff+Cout) of dst
+    int yoff = 0;
+    int cin_logical = -1;
+    bool out_external = false;  // OUT_NCHW into u->out
+  };
+  T conv(const T& x, const float* w, const float* bias, int Cout, int K, int stride, int pad, const ConvOpt& o) {
+    int Ho = (x.H + 2 * pad - K) / stride + 1, Wo = (x.W + 2 * pad - K) / stride + 1;
+    T y;
+    if (o.dst) {
+      y = *o.dst;
+    } else if (o.out_mode == OUT_PIXSHUF) {
+      y = alloc(x.B, 2 * Ho, 2 * Wo, Cout / 4);
+    } else if (o.out_external) {
+      y = T();
+      y.B = x.B; y.H = Ho; y.W = Wo; y.C = Cout;
+    } else {
+      y = alloc(x.B, Ho, Wo, Cout);
+    }
+    ConvParams p{};
+    p.w = w; p.bias = bias;
+    p.B = x.B; p.Hi = x.H; p.Wi = x.W; p.Cin = x.C; p.ldx = x.C;
+    p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
+    p.KH = K; p.KW = K; p.stride = stride; p.pad = pad;
+    p.act = o.act; p.out_mode = o.out_mode;
+    p.ldy = (o.out_mode == OUT_NHWC || o.out_mode == OUT_PIXSHUF) ? y.C : 0;
+    p.yoff = o.yoff;
+    p.ldres = o.res ? o.res->C : 0;
+    p.ldgs = o.gate_src ? o.gate_src->C : 0;
+    size_t xo = x.off, yo = y.off;
+    bool has_res = o.res != nullptr, has_gs = o.gate_src != nullptr, ext = o.out_external;
+    size_t ro = has_res ? o.res->off : 0, gso = has_gs ? o.gate_src->off : 0, go = has_gs ? o.gate->off : 0;
+    kd_unet* uu = u;
+    emit([=](hipStream_t s) {
+      ConvParams q = p;
+      q.x = uu->P(xo);
+      q.y = ext ? uu->out : uu->P(yo);
+      q.res = has_res ? uu->P(ro) : nullptr;
+      q.gate_src = has_gs ? uu->P(gso) : nullptr;
+      q.gate = has_gs ? uu->P(go) : nullptr;
+      return launch_conv_igemm(q, s);
+    });
+    int cin = o.cin_logical > 0 ? o.cin_logical : x.C;
+    u->macs += (int64_t)x.B * Ho * Wo * Cout * cin * K * K;
+    return y;
+  }
+  // token GEMM y[M,N] = x[M,K] @ w[N,K]^T
+  T linear(const T& x, const float* w, const float* bias, int N, int act = ACT_NONE, const T* res = nullptr) {
+    T xf = x;
+    xf.B = 1; xf.H = 1; xf.W = (int)x.rows();
+    ConvOpt o;
+    o.act = act;
+    T rf;
+    if (res) {
+      rf = *res;
+      rf.B = 1; rf.H = 1; rf.W = (int)res->rows();
+      o.res = &rf;
+    }
+    T y = conv(xf, w, bias, N, 1, 1, 0, o);
+    y.B = x.B; y.H = x.H; y.W = x.W;
+    return y;
+  }
+  // small-M linear on [M,K] rows living at workspace offset (row stride ldx) -> [M,N] (row stride ldy)
+  void skinny(size_t x_off, int ldx, const float* w, const float* bias, size_t y_off, int ldy, int M, int K, int N,
+              int in_act, int act) {
+    kd_unet* uu = u;
+    emit([=](hipStream_t s) {
+      return launch_linear_skinny(uu->P(x_off), ldx, w, bias, uu->P(y_off), ldy, M, K, N, in_act, act, s);
+    });
+    u->macs += (int64_t)M * K * N;
+  }
+
+  T layernorm(const T& x, const float* g, const float* beta, const T* res = nullptr) {
+    T y = alloc(x.B, x.H, x.W, x.C);
+    size_t xo = x.off, yo = y.off, ro = res ? res->off : 0;
+    bool hr = res != nullptr;
+    int rows = (int)x.rows(), C = x.C;
+    kd_unet* uu = u;
+    emit([=](hipStream_t s) {
+      return launch_layernorm(uu->P(xo), g, beta, hr ? uu->P(ro) : nullptr, uu->P(yo), rows, C, 1e-5f, s);
+    });
+    return y;
+  }
+
+  T gn_silu(const T& x, const std::string& prefix, const float* ss, int ld_ss) {
+    const float* gamma = P(prefix + ".weight", x.C);
+    const float* beta = P(prefix + ".bias", x.C);
+    int G = cfg.resnet_groups;
+    T y = alloc(x.B, x.H, x.W, x.C);
+    size_t pb = gn_partial_bytes(x.B, x.HW(), x.C, G);
+    if (pb > gn_partial_max) throw std::runtime_error("gn partial scratch too small");
+    size_t xo = x.off, yo = y.off, so = gn_stats_t.off, po = gn_partial_t.off;
+    int Bx = x.B, HW = x.HW(), C = x.C;
+    kd_unet* uu = u;
+    emit([=](hipStream_t s) {
+      if (launch_gn_stats(uu->P(xo), C, uu->P(so), (double*)uu->P(po), Bx, HW, C, G, 1e-5f, s)) return 1;
+      return launch_gn_apply_silu(uu->P(xo), C, uu->P(so), gamma, beta, ss, ld_ss, uu->P(yo), Bx, HW, C, G, s);
+    });
+    return y;
+  }
+
+  // ---- modules
+  // cross attention of feature tokens to the conditioning tokens c [B,Nc,cond_dim]; returns attn(x)+x
+  T cross_attn(const T& x, const std::string& pre, const T& c) {
+    int H = cfg.attn_heads, D = cfg.attn_dim_head, inner = H * D, dim = x.C;
+    T xn = layernorm(x, P(pre + ".norm.g", dim), nullptr);
+    T q = linear(xn, P(pre + ".to_q.weight", (int64_t)inner * dim), nullptr, inner);
+    free(xn);
+    T kv = linear(c, P(pre + ".to_kv.weight", (int64_t)2 * inner * c.C), nullptr, 2 * inner);
+    const float* nkv = P(pre + ".null_kv", 2 * D);
+    T o = alloc(x.B, x.H, x.W, inner);
+    {
+      size_t qo = q.off, kvo = kv.off, oo = o.off;
+      int Bx = x.B, Nq = x.HW(), Nc = c.HW();
+      float scale = 1.0f / sqrtf((float)D);
+      kd_unet* uu = u;
+      emit([=](hipStream_t s) {
+        KVSeg s0{uu->P(kvo), uu->P(kvo) + inner, 2 * inner, Nc};
+        KVSeg s1{nullptr, nullptr, 0, 0};
+        return launch_attention(uu->P(qo), inner, nkv, nkv + D, s0, s1, uu->P(oo), inner, Bx, Nq, H, H, scale, s);
+      });
+      u->macs += (int64_t)Bx * H * Nq * (Nc + 1) * D * 2;
+    }
+    free(q);
+    free(kv);
+    T proj = linear(o, P(pre + ".to_out.0.weight", (int64_t)dim * inner), nullptr, dim);
+    free(o);
+    T y = layernorm(proj, P(pre + ".to_out.1.g", dim), nullptr, &x);
+    free(proj);
+    return y;
+  }
+
+  // TransformerBlock (depth 1): x = attn(x, ctx) + x ; x = ff(x) + x.
+  T transformer(const T& x, const std::string& pre, const T* ctx) {
+    int H = cfg.attn_heads, D = cfg.attn_dim_head, inner = H * D, dim = x.C;
+    std::string a = pre + ".layers.0.0", f = pre + ".layers.0.1";
+    T xn = layernorm(x, P(a + ".norm.g", dim), nullptr);
+    T q = linear(xn, P(a + ".to_q.weight", (int64_t)inner * dim), nullptr, inner);
+    T kv = linear(xn, P(a + ".to_kv.weight", (int64_t)2 * D * dim), nullptr, 2 * D);
+    free(xn);
+    T ckv;
+    bool has_ctx = ctx != nullptr;
+    if (has_ctx) {
+      T cn = layernorm(*ctx, P(a + ".to_context.0.weight", ctx->C), P(a + ".to_context.0.bias", ctx->C));
+      ckv = linear(cn, P(a + ".to_context.1.weight", (int64_t)2 * D * ctx->C), P(a + ".to_context.1.bias", 2 * D),
+                   2 * D);
+      free(cn);
+    }
+    const float* nkv = P(a + ".null_kv", 2 * D);
+    T o = alloc(x.B, x.H, x.W, inner);
+    {
+      size_t qo = q.off, kvo = kv.off, oo = o.off, co = has_ctx ? ckv.off : 0;
+      int Bx = x.B, N = x.HW(), Nc = has_ctx ? ctx->HW() : 0;
+      float scale = 1.0f / sqrtf((float)D);
+      kd_unet* uu = u;
+      emit([=](hipStream_t s) {
+        KVSeg s0{nullptr, nullptr, 0, 0};
+        if (has_ctx) s0 = KVSeg{uu->P(co), uu->P(co) + D, 2 * D, Nc};
+        KVSeg s1{uu->P(kvo), uu->P(kvo) + D, 2 * D, N};
+        return launch_attention(uu->P(qo), inner, nkv, nkv + D, s0, s1, uu->P(oo), inner, Bx, N, H, 1, scale, s);
+      });
+      u->macs += (int64_t)Bx * H * N * (N + Nc + 1) * D * 2;
+    }
+    free(q);
+    free(kv);
+    if (has_ctx) free(ckv);
+    T proj = linear(o, P(a + ".to_out.0.weight", (int64_t)dim * inner), nullptr, dim);
+    free(o);
+    T x1 = layernorm(proj, P(a + ".to_out.1.g", dim), nullptr, &x);
+    free(proj);
+    // feed forward
+    int hidden = dim * cfg.ff_mult_x2 / 2;
+    T h0 = layernorm(x1, P(f + ".0.g", dim), nullptr);
+    T h1 = linear(h0, P(f + ".1.weight", (int64_t)hidden * dim), nullptr, hidden, ACT_GELU);
+    free(h0);
+    T h2 = layernorm(h1, P(f + ".3.g", hidden), nullptr);
+    free(h1);
+    T y = linear(h2, P(f + ".4.weight", (int64_t)dim * hidden), nullptr, dim, ACT_NONE, &x1);
+    free(h2);
+    free(x1);
+    return y;
+  }
+
+  // GlobalContext gate [B,1,1,C]
+  T gca(const T& h, const std::string& pre) {
+    int C = h.C, hid = std::max(3, C / 2);
+    const float* wk = P(pre + ".to_k.weight", C);
+    const float* bk = P(pre + ".to_k.bias", 1);
+    const float* w0 = P(pre + ".net.0.weight", (int64_t)hid * C);
+    const float* b0 = P(pre + ".net.0.bias", hid);
+    const float* w2 = P(pre + ".net.2.weight", (int64_t)C * hid);
+    const float* b2 = P(pre + ".net.2.bias", C);
+    T logits = alloc(h.B, h.H, h.W, 1);
+    T pooled = alloc(h.B, 1, 1, C);
+    T scratch = alloc_bytes(gca_scratch_floats(h.B, h.HW(), C) * sizeof(float));
+    size_t ho = h.off, lo = logits.off, po = pooled.off, so = scratch.off;
+    int Bx = h.B, HW = h.HW();
+    kd_unet* uu = u;
+    emit([=](hipStream_t s) {
+      return launch_gca_pool(uu->P(ho), wk, bk, uu->P(lo), uu->P(po), uu->P(so), Bx, HW, C, s);
+    });
+    u->macs += (int64_t)Bx * HW * C * 2;
+    free(logits);
+    free(scratch);
+    T hidden = alloc(h.B, 1, 1, hid);
+    skinny(pooled.off, C, w0, b0, hidden.off, hid, h.B, C, hid, ACT_NONE, ACT_SILU);
+    free(pooled);
+    T gate = alloc(h.B, 1, 1, C);
+    skinny(hidden.off, hid, w2, b2, gate.off, C, h.B, hid, C, ACT_NONE, ACT_SIGMOID);
+    free(hidden);
+    return gate;
+  }
+
+  // ResnetBlock.  Does NOT free x.
+  T resnet(const T& x, const std::string& pre, int dim_out, const T* ctx, bool use_gca) {
+    bool has_cross = has(pre + ".cross_attn.to_q.weight");
+    if (has_cross && !ctx) throw std::runtime_error("cross-attention block without conditioning tokens: " + pre);
+    int dim_in = x.C;
+    T y1 = gn_silu(x, pre + ".block1.groupnorm", nullptr, 0);
+    T h = conv(y1, pack_conv(pre + ".block1.project.weight", dim_out, dim_in, dim_in, 3),
+               P(pre + ".block1.project.bias", dim_out), dim_out, 3, 1, 1, ConvOpt());
+    free(y1);
+    if (has_cross) {
+      T h2 = cross_attn(h, pre + ".cross_attn", *ctx);
+      free(h);
+      h = h2;
+    }
+    auto it = tmlp_off.find(pre);
+    int ss_col = it != tmlp_off.end() ? it->second : -1;
+    T y2;
+    {
+      // scale/shift rows live in t_ss at column ss_col (row stride tmlp_total)
+      const float* gamma = P(pre + ".block2.groupnorm.weight", dim_out);
+      const float* beta = P(pre + ".block2.groupnorm.bias", dim_out);
+      int G = cfg.resnet_groups;
+      y2 = alloc(h.B, h.H, h.W, dim_out);
+      size_t xo = h.off, yo = y2.off, so = gn_stats_t.off, po = gn_partial_t.off, sso = t_ss.off;
+      int Bx = h.B, HW = h.HW(), C = dim_out, ld = tmlp_total;
+      kd_unet* uu = u;
+      emit([=](hipStream_t s) {
+        if (launch_gn_stats(uu->P(xo), C, uu->P(so), (double*)uu->P(po), Bx, HW, C, G, 1e-5f, s)) return 1;
+        const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
+        return launch_gn_apply_silu(uu->P(xo), C, uu->P(so), gamma, beta, ssp, ld, uu->P(yo), Bx, HW, C, G, s);
+      });
+    }
+    bool has_res_conv = has(pre + ".res_conv.weight");
+    ConvOpt o2;
+    if (!use_gca && !has_res_conv) o2.res = &x;  // h2 + x folded into the conv epilogue
+    free(h);
+    T h2 = conv(y2, pack_conv(pre + ".block2.project.weight", dim_out, dim_out, dim_out, 3),
+                P(pre + ".block2.project.bias", dim_out), dim_out, 3, 1, 1, o2);
+    free(y2);
+    if (!use_gca && !has_res_conv) return h2;
+    T out;
+    if (use_gca) {
+      T gate = gca(h2, pre + ".gca");
+      if (has_res_conv) {
+        ConvOpt o;
+        o.gate_src = &h2;
+        o.gate = &gate;
+        out = conv(x, P(pre + ".res_conv.weight", (int64_t)dim_out * dim_in), P(pre + ".res_conv.bias", dim_out),
+                   dim_out, 1, 1, 0, o);
+      } else {
+        out = alloc(x.B, x.H, x.W, dim_out);
+        size_t ao = h2.off, go = gate.off, ro = x.off, yo = out.off;
+        int Bx = x.B, HW = x.HW();
+        kd_unet* uu = u;
+        emit([=](hipStream_t s) {
+          return launch_gate_add(uu->P(ao), uu->P(go), uu->P(ro), uu->P(yo), Bx, HW, dim_out, s);
+        });
+      }
+      free(gate);
+    } else {  // res_conv without gca: out = conv1x1(x) + h2
+      ConvOpt o;
+      o.res = &h2;
+      out = conv(x, P(pre + ".res_conv.weight", (int64_t)dim_out * dim_in), P(pre + ".res_conv.bias", dim_out),
+                 dim_out, 1, 1, 0, o);
+    }
+    free(h2);
+    return out;
+  }
+
+  T downsample(const T& x, const std::string& pre, int dim_out) {  // pixel-unshuffle + conv1x1 == 2x2/s2 conv
+    const float* src = raw(pre + ".1.weight", (int64_t)dim_out * 4 * x.C);
+    float* w = u->wpool.alloc((size_t)dim_out * 4 * x.C);
+    KD_THROW_IF(launch_pack_unshuffle(src, w, dim_out, x.C, 0));
+    return conv(x, w, P(pre + ".1.bias", dim_out), dim_out, 2, 2, 0, ConvOpt());
+  }
+  T upsample(const T& x, const std::string& pre, int dim_out) {  // conv1x1 -> SiLU -> PixelShuffle(2)
+    const float* wsrc = raw(pre + ".net.0.weight", (int64_t)4 * dim_out * x.C);
+    const float* bsrc = raw(pre + ".net.0.bias", 4 * dim_out);
+    float* w = u->wpool.alloc((size_t)4 * dim_out * x.C);
+    float* b = u->wpool.alloc((size_t)4 * dim_out);
+    KD_THROW_IF(launch_pack_shuffle(wsrc, bsrc, w, b, dim_out, x.C, 0));
+    ConvOpt o;
+    o.act = ACT_SILU;
+    o.out_mode = OUT_PIXSHUF;
+    return conv(x, w, b, 4 * dim_out, 1, 1, 0, o);
+  }
+  T concat_skip(const T& x, const T& skip, float scale) {
+    T y = alloc(x.B, x.H, x.W, x.C + skip.C);
+    size_t ao = x.off, bo = skip.off, yo = y.off;
+    int Ca = x.C, Cb = skip.C;
+    int64_t rows = x.rows();
+    kd_unet* uu = u;
+    emit([=](hipStream_t s) { return launch_concat2(uu->P(ao), Ca, uu->P(bo), Cb, scale, uu->P(yo), rows, s); });
+    return y;
+  }
+
+  void collect_time_mlps() {
+    std::vector<std::string> names;
+    const std::string suffix = ".time_mlp.1.weight";
+    for (auto& kv : params) {
+      const std::string& n = kv.first;
+      if (n.size() > suffix.size() && n.compare(n.size() - suffix.size(), suffix.size(), suffix) == 0)
+        names.push_back(n.substr(0, n.size() - suffix.size()));
+    }
+    std::sort(names.begin(), names.end());
+    int tcd = u->time_cond_dim;
+    int total = 0;
+    for (auto& pre : names) {
+      int64_t ne = numel(pre + suffix);
+      if (ne % tcd) throw std::runtime_error("time_mlp weight of unexpected shape: " + pre);
+      tmlp_off[pre] = total;
+      total += (int)(ne / tcd);
+    }
+    tmlp_total = total;
+    tmlp_prefixes = names;
+    if (total == 0) return;
+    tmlp_w = u->wpool.alloc((size_t)total * tcd);
+    tmlp_b = u->wpool.alloc((size_t)total);
+    for (auto& pre : names) {
+      int off = tmlp_off[pre];
+      int64_t ne = numel(pre + suffix);
+      KD_HIP_THROW(hipMemcpyAsync(tmlp_w + (size_t)off * tcd, raw(pre + suffix), (size_t)ne * 4,
+                                  hipMemcpyDeviceToDevice, 0));
+      KD_HIP_THROW(hipMemcpyAsync(tmlp_b + off, raw(pre + ".time_mlp.1.bias", ne / tcd), (size_t)(ne / tcd) * 4,
+                                  hipMemcpyDeviceToDevice, 0));
+    }
+  }
+
+  // one time-conditioning trio: log_snr[B] -> (t [B,tcd] written/accumulated, tokens into c rows)
+  void time_trio(const std::string& hid, const std::string& cond, const std::string& tok, bool lowres,
+                 const T& t_out, const T& c_tok, int tok_row, const T& emb, const T& hidden) {
+    int tcd = u->time_cond_dim, half = cfg.sinu_dim / 2, sw = cfg.sinu_dim + 1;
+    int cd = cfg.cond_dim, ntt = cfg.num_time_tokens, ntok = c_tok.H * c_tok.W;
+    const float* sw_w = P(hid + ".0.weights", half);
+    kd_unet* uu = u;
+    size_t eo = emb.off;
+    int Bx = B;
+    emit([=](hipStream_t s) {
+      const float* t = lowres ? uu->in_lowres_log_snr : uu->in_log_snr;
+      if (!t) {
+        set_error(lowres ? "lowres_log_snr is required by this UNet" : "log_snr is required");
+        return 1;
+      }
+      return launch_sinu_emb(t, sw_w, uu->P(eo), Bx, half, s);
+    });
+    skinny(emb.off, sw, P(hid + ".1.weight", (int64_t)tcd * sw), P(hid + ".1.bias", tcd), hidden.off, tcd, B, sw,
+           tcd, ACT_NONE, ACT_SILU);
+    // tokens: [B, ntt*cd] written at row tok_row of c (row stride ntok*cd per batch)
+    skinny(hidden.off, tcd, P(tok + ".0.weight", (int64_t)cd * ntt * tcd), P(tok + ".0.bias", cd * ntt),
+           c_tok.off + (size_t)tok_row * cd * sizeof(float), ntok * cd, B, tcd, cd * ntt, ACT_NONE, ACT_NONE);
+    skinny(hidden.off, tcd, P(cond + ".0.weight", (int64_t)tcd * tcd), P(cond + ".0.bias", tcd), t_out.off, tcd, B,
+           tcd, tcd, ACT_NONE, ACT_NONE);
+  }
+
+  void build();
+};
+
+}  // namespace kd
+
+#include "unet_build.inc"  // Builder::build(): the walk over the module tree
+#include "api.inc"         // sampler loop + extern "C" entry points
+

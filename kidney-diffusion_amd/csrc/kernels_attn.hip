@@ -1,0 +1,353 @@
+// Attention core, GlobalContext pooling and the small-M ("skinny") linear layers.
+//
+// The attention core is < 2 % of the UNet's FLOPs (QK^T/AV 0.1-1.8 %),
+// its projections are GEMMs and run on the MFMA kernel in kernels_conv.hip.  The core here is
+// a flash-style single pass with fp32 online softmax on the vector ALU: one lane owns one
+// query row (q and the output row live in VGPRs), K/V tiles are staged in LDS and read as
+// wave-wide broadcasts.  Multi-query layout (one shared K/V head) is handled by
+// Hkv = 1.
+#include "common.h"
+
+namespace kd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float act_f(float v, int act) {
+  if (act == ACT_SILU) return v / (1.0f + expf(-v));
+  if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+
+// ------------------------------------------------------------------------- attention (D = 64)
+constexpr int AT_D = 64;
+constexpr int AT_KT = 64;  // keys per LDS tile
+
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, int ldq,
+                                                        const float* __restrict__ null_k,
+                                                        const float* __restrict__ null_v, KVSeg s0, KVSeg s1,
+                                                        float* __restrict__ out, int ldo, int Nq, int Hkv,
+                                                        float scale) {
+  __shared__ __attribute__((aligned(16))) float Ks[AT_KT * AT_D];
+  __shared__ __attribute__((aligned(16))) float Vs[AT_KT * AT_D];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int hk = Hkv == 1 ? 0 : h;
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  const bool active = qi < Nq;
+
+  float qr[AT_D], o[AT_D];
+  if (active) {
+    const float* qp = q + ((int64_t)b * Nq + qi) * ldq + h * AT_D;
+#pragma unroll
+    for (int d4 = 0; d4 < AT_D / 4; ++d4) {
+      f32x4 t = *(const f32x4*)(qp + d4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qr[d4 * 4 + e] = t[e] * scale;
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < AT_D; ++d) qr[d] = 0.f;
+  }
+#pragma unroll
+  for (int d = 0; d < AT_D; ++d) o[d] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;
+
+  const int n_null = null_k ? 1 : 0;
+  const int Nk = n_null + s0.n + s1.n;
+  for (int j0 = 0; j0 < Nk; j0 += AT_KT) {
+    const int nj = min(AT_KT, Nk - j0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nj * (AT_D / 4); idx += 256) {
+      int j = idx / (AT_D / 4), d4 = idx - j * (AT_D / 4);
+      int key = j0 + j;
+      const float *kp, *vp;
+      if (key < n_null) {
+        kp = null_k;
+        vp = null_v;
+      } else if (key < n_null + s0.n) {
+        int64_t r = (int64_t)b * s0.n + (key - n_null);
+        kp = s0.k + r * s0.ld + hk * AT_D;
+        vp = s0.v + r * s0.ld + hk * AT_D;
+      } else {
+        int64_t r = (int64_t)b * s1.n + (key - n_null - s0.n);
+        kp = s1.k + r * s1.ld + hk * AT_D;
+        vp = s1.v + r * s1.ld + hk * AT_D;
+      }
+      *(f32x4*)(Ks + j * AT_D + d4 * 4) = *(const f32x4*)(kp + d4 * 4);
+      *(f32x4*)(Vs + j * AT_D + d4 * 4) = *(const f32x4*)(vp + d4 * 4);
+    }
+    __syncthreads();
+    for (int j = 0; j < nj; ++j) {
+      float s0a = 0.f, s1a = 0.f, s2a = 0.f, s3a = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < AT_D / 4; ++d4) {
+        f32x4 kk = *(const f32x4*)(Ks + j * AT_D + d4 * 4);  // same address in every lane: broadcast
+        s0a = fmaf(qr[d4 * 4 + 0], kk[0], s0a);
+        s1a = fmaf(qr[d4 * 4 + 1], kk[1], s1a);
+        s2a = fmaf(qr[d4 * 4 + 2], kk[2], s2a);
+        s3a = fmaf(qr[d4 * 4 + 3], kk[3], s3a);
+      }
+      float sc = (s0a + s1a) + (s2a + s3a);
+      float mnew = fmaxf(mrun, sc);
+      float corr = expf(mrun - mnew);  // exp(-inf) = 0 on the first key
+      float pj = expf(sc - mnew);
+      lrun = lrun * corr + pj;
+      if (corr != 1.0f) {
+#pragma unroll
+        for (int d = 0; d < AT_D; ++d) o[d] *= corr;
+      }
+#pragma unroll
+      for (int d4 = 0; d4 < AT_D / 4; ++d4) {
+        f32x4 vv = *(const f32x4*)(Vs + j * AT_D + d4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[d4 * 4 + e] = fmaf(pj, vv[e], o[d4 * 4 + e]);
+      }
+      mrun = mnew;
+    }
+  }
+  if (active) {
+    float inv = 1.0f / lrun;
+    float* op = out + ((int64_t)b * Nq + qi) * ldo + h * AT_D;
+#pragma unroll
+    for (int d4 = 0; d4 < AT_D / 4; ++d4) {
+      f32x4 t = {o[d4 * 4] * inv, o[d4 * 4 + 1] * inv, o[d4 * 4 + 2] * inv, o[d4 * 4 + 3] * inv};
+      *(f32x4*)(op + d4 * 4) = t;
+    }
+  }
+}
+
+int launch_attention(const float* q, int ldq, const float* null_k, const float* null_v, KVSeg s0, KVSeg s1,
+                     float* out, int ldo, int B, int Nq, int H, int Hkv, float scale, hipStream_t s) {
+  KD_REQUIRE(Hkv == 1 || Hkv == H, "attention: Hkv must be 1 (multi-query) or H");
+  KD_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && (s0.n == 0 || s0.ld % 4 == 0) && (s1.n == 0 || s1.ld % 4 == 0),
+             "attention: strides % 4");
+  KD_REQUIRE((null_k ? 1 : 0) + s0.n + s1.n > 0 && Nq > 0, "attention: empty");
+  hipLaunchKernelGGL(attention_kernel, dim3((Nq + 255) / 256, H, B), dim3(256), 0, s, q, ldq, null_k, null_v, s0,
+                     s1, out, ldo, Nq, Hkv, scale);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------- skinny linear (M <= 16 per pass)
+// y[m][n] = act( sum_k in_act(x[m][k]) * w[n][k] + bias[n] ).  Weight-bandwidth bound: every
+// wave streams 4 weight rows with 16-B loads, x is staged once per block in LDS.
+constexpr int SK_M = 16;
+constexpr int SK_KC = 1024;
+constexpr int SK_NW = 4;  // outputs per wave
+
+__global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                            int ldy, int M, int K, int N, int in_act, int act) {
+  __shared__ __attribute__((aligned(16))) float xs[SK_M * SK_KC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nb = (blockIdx.x * 4 + wave) * SK_NW;
+  const int m0 = blockIdx.y * SK_M;
+  const int mcnt = min(SK_M, M - m0);
+  float acc[SK_NW][SK_M];
+#pragma unroll
+  for (int i = 0; i < SK_NW; ++i)
+#pragma unroll
+    for (int m = 0; m < SK_M; ++m) acc[i][m] = 0.f;
+  const bool vec = (K & 3) == 0 && (ldx & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)w) & 15) == 0;
+
+  for (int k0 = 0; k0 < K; k0 += SK_KC) {
+    const int kc = min(SK_KC, K - k0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < SK_M * kc; idx += 256) {
+      int m = idx / kc, kk = idx - m * kc;
+      float v = m < mcnt ? x[(int64_t)(m0 + m) * ldx + k0 + kk] : 0.f;
+      xs[m * SK_KC + kk] = act_f(v, in_act);
+    }
+    __syncthreads();
+    if (vec) {
+      for (int kk = lane * 4; kk < kc; kk += 256) {
+        f32x4 wv[SK_NW];
+#pragma unroll
+        for (int i = 0; i < SK_NW; ++i) {
+          int n = nb + i;
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          wv[i] = n < N ? *(const f32x4*)(w + (int64_t)n * K + k0 + kk) : z;
+        }
+#pragma unroll
+        for (int m = 0; m < SK_M; ++m) {
+          f32x4 xv = *(const f32x4*)(xs + m * SK_KC + kk);
+#pragma unroll
+          for (int i = 0; i < SK_NW; ++i) {
+            acc[i][m] = fmaf(xv[0], wv[i][0], acc[i][m]);
+            acc[i][m] = fmaf(xv[1], wv[i][1], acc[i][m]);
+            acc[i][m] = fmaf(xv[2], wv[i][2], acc[i][m]);
+            acc[i][m] = fmaf(xv[3], wv[i][3], acc[i][m]);
+          }
+        }
+      }
+    } else {
+      for (int kk = lane; kk < kc; kk += 64) {
+        float wv[SK_NW];
+#pragma unroll
+        for (int i = 0; i < SK_NW; ++i) wv[i] = (nb + i) < N ? w[(int64_t)(nb + i) * K + k0 + kk] : 0.f;
+#pragma unroll
+        for (int m = 0; m < SK_M; ++m) {
+          float xv = xs[m * SK_KC + kk];
+#pragma unroll
+          for (int i = 0; i < SK_NW; ++i) acc[i][m] = fmaf(xv, wv[i], acc[i][m]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < SK_NW; ++i) {
+#pragma unroll
+    for (int m = 0; m < SK_M; ++m) {
+      float t = wave_sum(acc[i][m]);
+      int n = nb + i;
+      if (lane == 0 && n < N && m < mcnt) {
+        t += bias ? bias[n] : 0.f;
+        y[(int64_t)(m0 + m) * ldy + n] = act_f(t, act);
+      }
+    }
+  }
+}
+
+int launch_linear_skinny(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int M,
+                         int K, int N, int in_act, int act, hipStream_t s) {
+  KD_REQUIRE(M > 0 && N > 0 && K > 0, "skinny linear: empty");
+  dim3 grid((N + 4 * SK_NW - 1) / (4 * SK_NW), (M + SK_M - 1) / SK_M);
+  hipLaunchKernelGGL(linear_skinny_kernel, grid, dim3(256), 0, s, x, ldx, w, bias, y, ldy, M, K, N, in_act, act);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------- GlobalContext pooling
+// logits[b][p] = x[b][p][:]·wk + bk ; w = softmax_p(logits) ; pooled[b][c] = sum_p w[p] x[b][p][c]
+__global__ __launch_bounds__(256) void gca_logits_kernel(const float* __restrict__ x, const float* __restrict__ wk,
+                                                         const float* __restrict__ bk, float* __restrict__ logits,
+                                                         int64_t rows, int C) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + row * C;
+  float s = 0.f;
+  for (int c4 = lane; c4 < (C >> 2); c4 += 64) {
+    f32x4 v = *(const f32x4*)(xr + c4 * 4);
+    f32x4 ww = *(const f32x4*)(wk + c4 * 4);
+    s += (v[0] * ww[0] + v[1] * ww[1]) + (v[2] * ww[2] + v[3] * ww[3]);
+  }
+  s = wave_sum(s);
+  if (lane == 0) logits[row] = s + bk[0];
+}
+
+// one block per b: max and sum(exp) over HW -> ms[b] = {max, 1/sum}
+__global__ __launch_bounds__(256) void gca_softmax_stats_kernel(const float* __restrict__ logits,
+                                                                float* __restrict__ ms, int HW) {
+  const int b = blockIdx.x;
+  const float* l = logits + (int64_t)b * HW;
+  __shared__ float red[4];
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < HW; i += 256) m = fmaxf(m, l[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) s += expf(l[i] - m);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ms[b * 2] = m;
+    ms[b * 2 + 1] = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+  }
+}
+
+constexpr int GCA_ROWS = 128;
+// grid (chunks, B): partial[b][chunk][c] = sum_{p in chunk} softmax_w[p] * x[b][p][c]
+__global__ __launch_bounds__(256) void gca_pool_partial_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ logits,
+                                                               const float* __restrict__ ms,
+                                                               float* __restrict__ partial, int HW, int C) {
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int p0 = chunk * GCA_ROWS, p1 = min(HW, p0 + GCA_ROWS);
+  __shared__ float wgt[GCA_ROWS];
+  const float m = ms[b * 2], inv = ms[b * 2 + 1];
+  for (int i = threadIdx.x; i < p1 - p0; i += 256) wgt[i] = expf(logits[(int64_t)b * HW + p0 + i] - m) * inv;
+  __syncthreads();
+  const int C4 = C >> 2;
+  for (int c4 = threadIdx.x; c4 < C4; c4 += 256) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int p = p0; p < p1; ++p) {
+      f32x4 v = *(const f32x4*)(x + ((int64_t)b * HW + p) * C + c4 * 4);
+      acc += v * wgt[p - p0];
+    }
+    *(f32x4*)(partial + (((int64_t)b * gridDim.x + chunk) * C4 + c4) * 4) = acc;
+  }
+}
+__global__ void gca_pool_reduce_kernel(const float* __restrict__ partial, float* __restrict__ pooled, int chunks,
+                                       int C, int total) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;  // b*C + c
+  if (i >= total) return;
+  int b = i / C, c = i - b * C;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += partial[((int64_t)b * chunks + k) * C + c];
+  pooled[i] = s;
+}
+
+size_t gca_scratch_floats(int B, int HW, int C) {
+  int chunks = (HW + GCA_ROWS - 1) / GCA_ROWS;
+  return (size_t)B * 2 + (size_t)B * chunks * C;
+}
+
+int launch_gca_pool(const float* x, const float* wk, const float* bk, float* logits, float* pooled,
+                    float* scratch, int B, int HW, int C, hipStream_t s) {
+  KD_REQUIRE(C % 4 == 0, "gca needs C % 4 == 0");
+  int64_t rows = (int64_t)B * HW;
+  float* ms = scratch;
+  float* partial = scratch + (size_t)B * 2;
+  int chunks = (HW + GCA_ROWS - 1) / GCA_ROWS;
+  hipLaunchKernelGGL(gca_logits_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, wk, bk, logits, rows,
+                     C);
+  hipLaunchKernelGGL(gca_softmax_stats_kernel, dim3(B), dim3(256), 0, s, logits, ms, HW);
+  hipLaunchKernelGGL(gca_pool_partial_kernel, dim3(chunks, B), dim3(256), 0, s, x, logits, ms, partial, HW, C);
+  hipLaunchKernelGGL(gca_pool_reduce_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, partial, pooled, chunks,
+                     C, B * C);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------- learned sinusoidal embedding
+__global__ void sinu_emb_kernel(const float* __restrict__ t, const float* __restrict__ w, float* __restrict__ out,
+                                int B, int half) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int W = 2 * half + 1;
+  if (i >= B * W) return;
+  int b = i / W, j = i - b * W;
+  float tv = t[b];
+  float r;
+  if (j == 0) {
+    r = tv;
+  } else {
+    int f = (j - 1) % half;
+    float fr = tv * w[f] * 2.0f * 3.14159265358979323846f;  // (x*w)*2*pi, left to right as torch evaluates it
+    r = (j - 1) < half ? sinf(fr) : cosf(fr);
+  }
+  out[i] = r;
+}
+int launch_sinu_emb(const float* t, const float* w, float* out, int B, int half, hipStream_t s) {
+  int total = B * (2 * half + 1);
+  hipLaunchKernelGGL(sinu_emb_kernel, dim3((total + 63) / 64), dim3(64), 0, s, t, w, out, B, half);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace kd

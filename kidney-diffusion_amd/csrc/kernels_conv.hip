@@ -1,0 +1,329 @@
+// Implicit-GEMM convolution / token GEMM on the fp32 matrix cores of gfx950.
+//
+//   y[m][n] = epilogue( sum_{tap} sum_{c} x[pixel(m, tap)][c] * w[tap][n][c] )
+//
+// m runs over the B*Ho*Wo output pixels (NHWC order), n over Cout.  Both operands are staged
+// into LDS as rows of BK = 32 contiguous k (channels of one tap), so the A tile (activations)
+// and the B tile (weights, packed [tap][Cout][Cin] at plan-build time) share one loader.
+// The product runs on v_mfma_f32_32x32x2_f32: exact fp32 (bitwise a k-ordered fmaf chain),
+// 64 FLOP/clk/SIMD, which is the fp32 roofline of the chip (157 TFLOP/s).
+//
+// LDS rows are padded to 36 floats: a ds_read_b128 of 16 lanes on 16 different rows then
+// touches 16 different 16-B slots of the 256-B bank row (conflict-free).
+// Each lane's b128 read supplies 4 consecutive k for 4 MFMA steps: lanes 0-31 (k-half 0) read
+// k = 8j..8j+3 and lanes 32-63 read k = 8j+4..8j+7; A and B use the same map, and k is only a
+// summation label, so the pairing is consistent.
+#include "common.h"
+
+namespace kd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == ACT_SILU) return v / (1.0f + __expf(-v));
+  if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  if (act == ACT_SIGMOID) return 1.0f / (1.0f + __expf(-v));
+  return v;
+}
+
+// Finishes 4 consecutive output channels n..n+3 of output pixel m (vec) or one channel (scalar).
+template <int W>
+__device__ __forceinline__ void epilogue_store(const ConvParams& p, int64_t m, int n, float* v) {
+  const int hw_o = p.Ho * p.Wo;
+  const int b = (int)(m / hw_o);
+#pragma unroll
+  for (int e = 0; e < W; ++e) v[e] = act_apply(v[e] + (p.bias ? p.bias[n + e] : 0.f), p.act);
+  if (p.gate_src) {
+#pragma unroll
+    for (int e = 0; e < W; ++e) v[e] += p.gate_src[m * p.ldgs + n + e] * p.gate[(int64_t)b * p.Cout + n + e];
+  }
+  if (p.res) {
+#pragma unroll
+    for (int e = 0; e < W; ++e) v[e] += p.res[m * p.ldres + n + e];
+  }
+  float* dst;
+  if (p.out_mode == OUT_NHWC) {
+    dst = p.y + m * p.ldy + p.yoff + n;
+  } else if (p.out_mode == OUT_PIXSHUF) {
+    // weight rows were packed as n' = (i*2+j)*Co + c ; output NHWC [B][2Ho][2Wo][Co]
+    int Co = p.Cout >> 2;
+    int q = n / Co, c = n - q * Co;
+    int rem = (int)(m - (int64_t)b * hw_o);
+    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    int64_t o = (((int64_t)b * 2 * p.Ho + 2 * oy + (q >> 1)) * (2 * p.Wo) + 2 * ox + (q & 1));
+    dst = p.y + o * p.ldy + p.yoff + c;
+  } else {  // OUT_NCHW planar [B][Cout][Ho][Wo] (scalar path only)
+    int rem = (int)(m - (int64_t)b * hw_o);
+    dst = p.y + ((int64_t)b * p.Cout + n) * hw_o + rem;
+  }
+  if (W == 4) {
+    f32x4 o4 = {v[0], v[1], v[2], v[3]};
+    *(f32x4*)dst = o4;
+  } else {
+    dst[0] = v[0];
+  }
+}
+
+constexpr int BK = 32;
+constexpr int LDS_LD = 36;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvParams p) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int ROWS_PER_PASS = NT / 8;
+  constexpr int A_PASSES = BM / ROWS_PER_PASS;
+  constexpr int B_PASSES = BN / ROWS_PER_PASS;
+  constexpr int TM = BM / WAVES_M / 32;
+  constexpr int TN = BN / WAVES_N / 32;
+  static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile/loader mismatch");
+
+  constexpr int C_LD = WAVES_N * 32 + 4;  // epilogue staging: one 32-column group per wave column
+  constexpr int LDS_FLOATS = (BM + BN) * LDS_LD > BM * C_LD ? (BM + BN) * LDS_LD : BM * C_LD;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  float* As = lds;
+  float* Bs = lds + BM * LDS_LD;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+
+  const int64_t M = (int64_t)p.B * p.Ho * p.Wo;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- loader coordinates
+  const int seg = tid & 7;
+  const int lrow = tid >> 3;
+  int a_iy0[A_PASSES], a_ix0[A_PASSES];
+  int64_t a_img[A_PASSES];  // pixel offset of the image start, or -1 if the row is past M
+#pragma unroll
+  for (int q = 0; q < A_PASSES; ++q) {
+    int64_t m = m0 + lrow + q * ROWS_PER_PASS;
+    if (m < M) {
+      int hw = p.Ho * p.Wo;
+      int b = (int)(m / hw);
+      int rem = (int)(m - (int64_t)b * hw);
+      int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_iy0[q] = oy * p.stride - p.pad;
+      a_ix0[q] = ox * p.stride - p.pad;
+      a_img[q] = (int64_t)b * p.Hi * p.Wi;
+    } else {
+      a_iy0[q] = 0;
+      a_ix0[q] = 0;
+      a_img[q] = -1;
+    }
+  }
+  bool b_ok[B_PASSES];
+#pragma unroll
+  for (int q = 0; q < B_PASSES; ++q) b_ok[q] = (n0 + lrow + q * ROWS_PER_PASS) < p.Cout;
+
+  const int chunks_per_tap = (p.Cin + BK - 1) / BK;
+  const int ntaps = p.KH * p.KW;
+  const int nchunks = ntaps * chunks_per_tap;
+
+  f32x4 ra[A_PASSES], rb[B_PASSES];
+
+  auto load_chunk = [&](int chunk) {
+    int tap = chunk / chunks_per_tap;
+    int c0 = (chunk - tap * chunks_per_tap) * BK + seg * 4;
+    int kh = tap / p.KW, kw = tap - kh * p.KW;
+    bool c_ok = c0 < p.Cin;
+#pragma unroll
+    for (int q = 0; q < A_PASSES; ++q) {
+      int iy = a_iy0[q] + kh, ix = a_ix0[q] + kw;
+      bool ok = c_ok && a_img[q] >= 0 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *(const f32x4*)(p.x + (a_img[q] + (int64_t)iy * p.Wi + ix) * p.ldx + c0);
+      ra[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < B_PASSES; ++q) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c_ok && b_ok[q])
+        v = *(const f32x4*)(p.w + ((int64_t)tap * p.Cout + n0 + lrow + q * ROWS_PER_PASS) * p.Cin + c0);
+      rb[q] = v;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int q = 0; q < A_PASSES; ++q)
+      *(f32x4*)(As + (lrow + q * ROWS_PER_PASS) * LDS_LD + seg * 4) = ra[q];
+#pragma unroll
+    for (int q = 0; q < B_PASSES; ++q)
+      *(f32x4*)(Bs + (lrow + q * ROWS_PER_PASS) * LDS_LD + seg * 4) = rb[q];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31;
+  const int fk = (lane >> 5) * 4;
+  const float* a_base = As + (wm * TM * 32 + frow) * LDS_LD + fk;
+  const float* b_base = Bs + (wn * TN * 32 + frow) * LDS_LD + fk;
+
+  load_chunk(0);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    store_chunk();
+    __syncthreads();
+    if (chunk + 1 < nchunks) load_chunk(chunk + 1);  // in flight while the MFMAs below run
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(a_base + i * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(b_base + j * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue.  The accumulators go through LDS so that global stores (and the residual /
+  // gate reads) are 16-B per lane along n.  C/D map of the 32x32 MFMA: col = lane&31,
+  // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The main loop ended on a barrier, LDS is free.
+  const bool vec_ok = p.out_mode != OUT_NCHW && (p.Cout & 3) == 0 && (p.ldy & 3) == 0 && (p.yoff & 3) == 0 &&
+                      (((uintptr_t)p.y) & 15) == 0 && (!p.res || ((p.ldres & 3) == 0 && (((uintptr_t)p.res) & 15) == 0)) &&
+                      (!p.gate_src || (p.ldgs & 3) == 0) && (p.out_mode != OUT_PIXSHUF || (p.Cout & 15) == 0);
+  float* Cs = lds;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rowb = (wm * TM + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Cs[(rowb + (r & 3) + 8 * (r >> 2)) * C_LD + wn * 32 + (lane & 31)] = acc[i][j][r];
+    }
+    __syncthreads();
+    constexpr int V_PER_ROW = WAVES_N * 8;
+    if (vec_ok) {
+      for (int idx = tid; idx < BM * V_PER_ROW; idx += NT) {
+        int row = idx / V_PER_ROW, c4 = idx - row * V_PER_ROW;
+        int wn_ = c4 >> 3, c = (c4 & 7) * 4;
+        int n = n0 + (wn_ * TN + j) * 32 + c;
+        int64_t m = m0 + row;
+        if (m < M && n < p.Cout) {
+          f32x4 t = *(const f32x4*)(Cs + row * C_LD + wn_ * 32 + c);
+          float v[4] = {t[0], t[1], t[2], t[3]};
+          epilogue_store<4>(p, m, n, v);
+        }
+      }
+    } else {
+      for (int idx = tid; idx < BM * WAVES_N * 32; idx += NT) {
+        int row = idx / (WAVES_N * 32), cc = idx - row * (WAVES_N * 32);
+        int wn_ = cc >> 5, c = cc & 31;
+        int n = n0 + (wn_ * TN + j) * 32 + c;
+        int64_t m = m0 + row;
+        if (m < M && n < p.Cout) {
+          float v[1] = {Cs[row * C_LD + wn_ * 32 + c]};
+          epilogue_store<1>(p, m, n, v);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int64_t conv_macs(const ConvParams& p) {
+  return (int64_t)p.B * p.Ho * p.Wo * p.Cout * p.Cin * p.KH * p.KW;
+}
+
+int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
+  KD_REQUIRE(p.Cin % 4 == 0 && p.ldx % 4 == 0, "igemm needs Cin and ldx multiples of 4");
+  KD_REQUIRE(((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.w & 15) == 0, "igemm operands must be 16-B aligned");
+  if (p.out_mode == OUT_PIXSHUF) KD_REQUIRE(p.Cout % 4 == 0, "pixel-shuffle needs Cout % 4 == 0");
+  int64_t M = (int64_t)p.B * p.Ho * p.Wo;
+  KD_REQUIRE(M > 0 && p.Cout > 0, "empty conv");
+  if (p.Cout <= 32) {
+    dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 31) / 32);
+    hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, p);
+  } else if (p.Cout <= 64) {
+    dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 63) / 64);
+    hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2>), grid, dim3(256), 0, s, p);
+  } else if (M <= 64) {
+    dim3 grid((unsigned)((M + 63) / 64), (p.Cout + 127) / 128);
+    hipLaunchKernelGGL((conv_igemm_kernel<64, 128, 1, 4>), grid, dim3(256), 0, s, p);
+  } else {
+    dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 127) / 128);
+    hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, p);
+  }
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ weight packing
+__global__ void pack_oihw_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int Ireal, int I,
+                                 int KH, int KW) {
+  int64_t total = (int64_t)O * I * KH * KW;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    // out index: ((tap*O + o)*I + i)
+    int i = (int)(idx % I);
+    int64_t t = idx / I;
+    int o = (int)(t % O);
+    int tap = (int)(t / O);
+    out[idx] = i < Ireal ? w[((int64_t)o * Ireal + i) * KH * KW + tap] : 0.f;
+  }
+}
+int launch_pack_oihw(const float* w, float* out, int O, int Ireal, int I, int KH, int KW, hipStream_t s) {
+  int64_t total = (int64_t)O * I * KH * KW;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_oihw_kernel, dim3(blocks), dim3(256), 0, s, w, out, O, Ireal, I, KH, KW);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void pack_unshuffle_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int C) {
+  int64_t total = (int64_t)O * C * 4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(idx % C);
+    int64_t t = idx / C;
+    int o = (int)(t % O);
+    int tap = (int)(t / O);  // s1*2+s2
+    out[idx] = w[(int64_t)o * 4 * C + c * 4 + tap];
+  }
+}
+int launch_pack_unshuffle(const float* w, float* out, int O, int C, hipStream_t s) {
+  int64_t total = (int64_t)O * C * 4;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_unshuffle_kernel, dim3(blocks), dim3(256), 0, s, w, out, O, C);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void pack_shuffle_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                    float* __restrict__ wout, float* __restrict__ bout, int Co, int I) {
+  int64_t total = (int64_t)4 * Co * I;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int i = (int)(idx % I);
+    int np = (int)(idx / I);  // packed row (q*Co + c)
+    int q = np / Co, c = np - q * Co;
+    wout[idx] = w[((int64_t)c * 4 + q) * I + i];
+    if (i == 0) bout[np] = b[c * 4 + q];
+  }
+}
+int launch_pack_shuffle(const float* w, const float* b, float* wout, float* bout, int Co, int I, hipStream_t s) {
+  int64_t total = (int64_t)4 * Co * I;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_shuffle_kernel, dim3(blocks), dim3(256), 0, s, w, b, wout, bout, Co, I);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace kd

@@ -1,0 +1,353 @@
+// HBM-bound normalisation / elementwise kernels on NHWC fp32 feature maps.
+// All of them move 16 B per lane and reduce with wavefront (64-lane) shuffles.
+#include "common.h"
+
+namespace kd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------- GroupNorm statistics
+// grid (chunks, G, B).  Each block sums x and x^2 (fp64 accumulators: CDNA runs fp64 VALU at
+// full rate and the kernel is HBM-bound) over its pixel slice of group g, writes one partial.
+constexpr int GN_ROWS_PER_BLOCK = 256;
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int ldx,
+                                                         double* __restrict__ partial, int HW, int C, int G) {
+  const int g = blockIdx.y, b = blockIdx.z, chunk = blockIdx.x;
+  const int Cg = C / G;
+  const int Cg4 = Cg >> 2;
+  const int p0 = chunk * GN_ROWS_PER_BLOCK;
+  const int p1 = min(HW, p0 + GN_ROWS_PER_BLOCK);
+  const float* base = x + ((int64_t)b * HW) * ldx + g * Cg;
+  double s = 0.0, ss = 0.0;
+  const int total = (p1 - p0) * Cg4;
+  for (int idx = threadIdx.x; idx < total; idx += 256) {
+    int row = idx / Cg4, c4 = idx - row * Cg4;
+    f32x4 v = *(const f32x4*)(base + (int64_t)(p0 + row) * ldx + c4 * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      double d = (double)v[e];
+      s += d;
+      ss += d * d;
+    }
+  }
+  __shared__ double red[2][4];
+  s = wave_sum_d(s);
+  ss = wave_sum_d(ss);
+  int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][wave] = s;
+    red[1][wave] = ss;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    double tss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    int64_t o = (((int64_t)b * G + g) * gridDim.x + chunk) * 2;
+    partial[o] = ts;
+    partial[o + 1] = tss;
+  }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ partial, float* __restrict__ stats, int chunks,
+                                   int BG, double count, float eps) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BG) return;
+  double s = 0.0, ss = 0.0;
+  for (int c = 0; c < chunks; ++c) {
+    s += partial[((int64_t)i * chunks + c) * 2];
+    ss += partial[((int64_t)i * chunks + c) * 2 + 1];
+  }
+  double mean = s / count;
+  double var = ss / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[i * 2] = (float)mean;
+  stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+size_t gn_partial_bytes(int B, int HW, int C, int G) {
+  int chunks = (HW + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK;
+  return (size_t)B * G * chunks * 2 * sizeof(double);
+}
+
+int launch_gn_stats(const float* x, int ldx, float* stats, double* partial, int B, int HW, int C, int G,
+                    float eps, hipStream_t s) {
+  KD_REQUIRE(C % G == 0 && (C / G) % 4 == 0 && ldx % 4 == 0, "GroupNorm needs (C/G) % 4 == 0");
+  int chunks = (HW + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, G, B), dim3(256), 0, s, x, ldx, partial, HW, C, G);
+  int BG = B * G;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((BG + 63) / 64), dim3(64), 0, s, partial, stats, chunks, BG,
+                     (double)HW * (C / G), eps);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------- GroupNorm apply
+// y = silu( ((x-mean)*rstd*gamma + beta) * (scale+1) + shift ), folded to silu(x*A + Bc) per (b,c).
+constexpr int GA_ROWS_PER_BLOCK = 64;
+
+__global__ __launch_bounds__(256) void gn_apply_silu_kernel(const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ scale_shift,
+                                                            int ld_ss, float* __restrict__ y, int HW, int C,
+                                                            int G) {
+  const int b = blockIdx.y;
+  const int C4 = C >> 2;
+  const int W = C4 < 256 ? C4 : 256;
+  const int RP = 256 / W;
+  const int rsub = threadIdx.x / W;
+  if (rsub >= RP) return;
+  const int Cg = C / G;
+  const int p0 = blockIdx.x * GA_ROWS_PER_BLOCK;
+  const int p1 = min(HW, p0 + GA_ROWS_PER_BLOCK);
+  for (int c4 = threadIdx.x - rsub * W; c4 < C4; c4 += W) {
+    float A[4], Bc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int c = c4 * 4 + e;
+      int g = c / Cg;
+      float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+      float a = rstd * gamma[c];
+      float bb = beta[c] - mean * a;
+      if (scale_shift) {
+        float sc = scale_shift[(int64_t)b * ld_ss + c] + 1.0f;
+        float sh = scale_shift[(int64_t)b * ld_ss + C + c];
+        a *= sc;
+        bb = bb * sc + sh;
+      }
+      A[e] = a;
+      Bc[e] = bb;
+    }
+    for (int row = p0 + rsub; row < p1; row += RP) {
+      int64_t pix = (int64_t)b * HW + row;
+      f32x4 v = *(const f32x4*)(x + pix * ldx + c4 * 4);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = silu_f(v[e] * A[e] + Bc[e]);
+      *(f32x4*)(y + pix * C + c4 * 4) = o;
+    }
+  }
+}
+
+int launch_gn_apply_silu(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
+                         const float* scale_shift, int ld_ss, float* y, int B, int HW, int C, int G,
+                         hipStream_t s) {
+  KD_REQUIRE(C % 4 == 0 && ldx % 4 == 0, "GroupNorm apply needs C % 4 == 0");
+  int chunks = (HW + GA_ROWS_PER_BLOCK - 1) / GA_ROWS_PER_BLOCK;
+  hipLaunchKernelGGL(gn_apply_silu_kernel, dim3(chunks, B), dim3(256), 0, s, x, ldx, stats, gamma, beta,
+                     scale_shift, ld_ss, y, HW, C, G);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------- LayerNorm (one wave per row)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ beta,
+                                                        const float* __restrict__ res, float* __restrict__ y,
+                                                        int rows, int C, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + (int64_t)row * C;
+  float* yr = y + (int64_t)row * C;
+  const int C4 = C >> 2;
+  float s = 0.f;
+  for (int c4 = lane; c4 < C4; c4 += 64) {
+    f32x4 v = *(const f32x4*)(xr + c4 * 4);
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  const float mean = wave_sum_f(s) / (float)C;
+  float ss = 0.f;
+  for (int c4 = lane; c4 < C4; c4 += 64) {
+    f32x4 v = *(const f32x4*)(xr + c4 * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float d = v[e] - mean;
+      ss += d * d;
+    }
+  }
+  const float var = wave_sum_f(ss) / (float)C;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  for (int c4 = lane; c4 < C4; c4 += 64) {
+    f32x4 v = *(const f32x4*)(xr + c4 * 4);
+    f32x4 gg = *(const f32x4*)(g + c4 * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * gg[e];
+    if (beta) {
+      f32x4 bb = *(const f32x4*)(beta + c4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += bb[e];
+    }
+    if (res) {
+      f32x4 rr = *(const f32x4*)(res + (int64_t)row * C + c4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += rr[e];
+    }
+    *(f32x4*)(yr + c4 * 4) = o;
+  }
+}
+
+int launch_layernorm(const float* x, const float* g, const float* beta, const float* res, float* y, int rows,
+                     int C, float eps, hipStream_t s) {
+  KD_REQUIRE(C % 4 == 0, "LayerNorm needs C % 4 == 0");
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, beta, res, y, rows, C, eps);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------- concat / gate / add
+__global__ void concat2_kernel(const float* __restrict__ a, int Ca4, const float* __restrict__ b, int Cb4,
+                               float scale_b, float* __restrict__ y, int64_t rows) {
+  const int W = Ca4 + Cb4;
+  const int64_t total = rows * W;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = idx / W;
+    int c4 = (int)(idx - row * W);
+    f32x4 v;
+    if (c4 < Ca4) {
+      v = *(const f32x4*)(a + (row * Ca4 + c4) * 4);
+    } else {
+      v = *(const f32x4*)(b + (row * Cb4 + (c4 - Ca4)) * 4);
+      v *= scale_b;
+    }
+    *(f32x4*)(y + idx * 4) = v;
+  }
+}
+static inline int grid_for(int64_t n_items) {
+  int64_t b = (n_items + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+int launch_concat2(const float* a, int Ca, const float* b, int Cb, float scale_b, float* y, int64_t rows,
+                   hipStream_t s) {
+  KD_REQUIRE(Ca % 4 == 0 && Cb % 4 == 0, "concat needs channel counts % 4 == 0");
+  hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(rows * (Ca + Cb) / 4)), dim3(256), 0, s, a, Ca / 4, b, Cb / 4,
+                     scale_b, y, rows);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void gate_add_kernel(const float* __restrict__ a, const float* __restrict__ gate,
+                                const float* __restrict__ r, float* __restrict__ y, int64_t HW, int C4,
+                                int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t pix = idx / C4;
+    int c4 = (int)(idx - pix * C4);
+    int b = (int)(pix / HW);
+    f32x4 v = *(const f32x4*)(a + idx * 4);
+    f32x4 rr = *(const f32x4*)(r + idx * 4);
+    if (gate) {
+      f32x4 g = *(const f32x4*)(gate + ((int64_t)b * C4 + c4) * 4);
+      v = v * g + rr;
+    } else {
+      v = v + rr;
+    }
+    *(f32x4*)(y + idx * 4) = v;
+  }
+}
+int launch_gate_add(const float* a, const float* gate, const float* r, float* y, int B, int HW, int C,
+                    hipStream_t s) {
+  KD_REQUIRE(C % 4 == 0, "gate_add needs C % 4 == 0");
+  int64_t total = (int64_t)B * HW * (C / 4);
+  hipLaunchKernelGGL(gate_add_kernel, dim3(grid_for(total)), dim3(256), 0, s, a, gate, r, y, (int64_t)HW, C / 4,
+                     total);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                           int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = a[i] + b[i];
+}
+int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, y, n);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void act_kernel(const float* __restrict__ a, float* __restrict__ y, int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = a[i];
+    if (act == ACT_SILU) v = silu_f(v);
+    else if (act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    else if (act == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+    y[i] = v;
+  }
+}
+int launch_act(const float* a, float* y, int64_t n, int act, hipStream_t s) {
+  hipLaunchKernelGGL(act_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, y, n, act);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------- init image assembly
+// NCHW planes (cond | x | lowres) -> NHWC [B][HW][Cpad], zero padded.  Channel order follows
+// Unet.forward: x = cat(x, lowres); x = cat(cond_images, x)   (SURVEY A.1 / §3.2).
+__global__ void pack_init_kernel(const float* __restrict__ cond, int Cc, const float* __restrict__ x,
+                                 const float* __restrict__ lowres, int Cl, float* __restrict__ y, int Cpad,
+                                 int64_t HW, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t pix = idx;  // b*HW + p
+    int64_t b = pix / HW, p = pix - b * HW;
+    float* o = y + pix * Cpad;
+    int c = 0;
+    for (int i = 0; i < Cc; ++i) o[c++] = cond[(b * Cc + i) * HW + p];
+    for (int i = 0; i < 3; ++i) o[c++] = x[(b * 3 + i) * HW + p];
+    for (int i = 0; i < Cl; ++i) o[c++] = lowres[(b * Cl + i) * HW + p];
+    for (; c < Cpad; ++c) o[c] = 0.f;
+  }
+}
+int launch_pack_init(const float* cond, int Cc, const float* x, const float* lowres, int Cl, float* y, int Cpad,
+                     int B, int HW, hipStream_t s) {
+  int64_t total = (int64_t)B * HW;
+  hipLaunchKernelGGL(pack_init_kernel, dim3(grid_for(total)), dim3(256), 0, s, cond, Cc, x, lowres, Cl, y, Cpad,
+                     (int64_t)HW, total);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void copy_rows_kernel(const float* __restrict__ src, int64_t sbs, int lds_, float* __restrict__ dst,
+                                 int64_t dbs, int ldd, int rows, int C, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(idx % C);
+    int64_t t = idx / C;
+    int r = (int)(t % rows);
+    int64_t b = t / rows;
+    dst[b * dbs + (int64_t)r * ldd + c] = src[b * sbs + (int64_t)r * lds_ + c];
+  }
+}
+int launch_copy_rows(const float* src, int64_t sbs, int ld_src, float* dst, int64_t dbs, int ld_dst, int rows,
+                     int C, int B, hipStream_t s) {
+  int64_t total = (int64_t)B * rows * C;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, sbs, ld_src, dst, dbs, ld_dst,
+                     rows, C, total);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_bcast_row(const float* src, float* dst, int64_t dst_bstride, int C, int B, hipStream_t s) {
+  return launch_copy_rows(src, 0, C, dst, dst_bstride, C, 1, C, B, s);
+}
+
+}  // namespace kd
