@@ -153,6 +153,9 @@ int kd_sample_loop(kd_unet_t* u, const kd_schedule_t* sched, const kd_sample_arg
  * to time exactly K steps, and by tests to compare intermediate states). */
 int kd_sample_steps(kd_unet_t* u, const kd_schedule_t* sched, const kd_sample_args_t* args,
                     float* d_img, int k_begin, int k_end, void* stream);
+/* The tail of p_sample_loop on its own: clamp(-1,1), paste of the known inpaint pixels,
+ * (x+1)/2.  kd_sample_loop == kd_sample_steps(0,T) + kd_sample_finalize. */
+int kd_sample_finalize(kd_unet_t* u, const kd_sample_args_t* args, float* d_img, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Individual kernels, exported so that tests/ can check each one against the oracle through

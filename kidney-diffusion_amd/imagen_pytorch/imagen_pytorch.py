@@ -1,0 +1,744 @@
+"""Drop-in `imagen_pytorch` surface for the sampling path of jameshball/kidney-diffusion,
+backed by the MI355X HIP engine (``libkd_engine.so``).
+
+What the reference imports and calls:
+  * ``Unet(...)``     kwargs at train_ultra_res.py:29-60, train.py:30-65, train_uncond.py:30-61
+  * ``NullUnet``      subclassed at train_ultra_res.py:65-75
+  * ``Imagen(...)``   kwargs at train_ultra_res.py:79-90, train.py:83-93, train_uncond.py:79-90
+  * ``imagen.sample`` sample_ultra_res.py:183-195, outpainting.py:146-157
+  * checkpoint dict   {'model', 'version', ...}  sample_ultra_res.py:53-63
+
+The classes are ``nn.Module``s whose parameter tree (names, shapes, default init) follows
+imagen-pytorch 1.18.5 so that ``state_dict`` / ``load_state_dict(strict=True)``
+behave as the reference expects; they hold no torch arithmetic.  ``Unet.forward`` and
+``Imagen.sample`` hand device pointers to the engine.  Without the HIP library or a GPU they raise
+— there is no CPU fallback in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _engine as E
+
+
+def exists(v):
+    return v is not None
+
+
+def default(v, d):
+    if exists(v):
+        return v
+    return d() if callable(d) else d
+
+
+def cast_tuple(v, length=None):
+    if isinstance(v, list):
+        v = tuple(v)
+    out = v if isinstance(v, tuple) else ((v,) * default(length, 1))
+    if exists(length):
+        assert len(out) == length, f"expected a tuple of length {length}, got {out}"
+    return out
+
+
+# ============================================================================ parameter tree
+# Containers below only declare parameters; `_no_forward` documents that the arithmetic lives in
+# the engine.
+class _Decl(nn.Module):
+    def forward(self, *a, **k):
+        raise RuntimeError(f"{type(self).__name__} holds parameters only; the forward pass runs in libkd_engine")
+
+
+class LayerNorm(_Decl):  # gain-only
+    def __init__(self, feats):
+        super().__init__()
+        self.g = nn.Parameter(torch.ones(feats))
+
+
+class _Stateless(_Decl):  # placeholder that keeps nn.Sequential indices aligned with the library
+    pass
+
+
+class LearnedSinusoidalPosEmb(_Decl):
+    def __init__(self, dim):
+        super().__init__()
+        assert dim % 2 == 0
+        self.weights = nn.Parameter(torch.randn(dim // 2))
+
+
+class CrossEmbedLayer(_Decl):
+    def __init__(self, dim_in, kernel_sizes, dim_out, stride=1):
+        super().__init__()
+        kernel_sizes = sorted(kernel_sizes)
+        scales = [int(dim_out / (2 ** i)) for i in range(1, len(kernel_sizes))]
+        scales.append(dim_out - sum(scales))
+        self.convs = nn.ModuleList(
+            [nn.Conv2d(dim_in, s, k, stride=stride, padding=(k - stride) // 2) for k, s in zip(kernel_sizes, scales)])
+
+
+def _downsample(dim, dim_out):
+    return nn.Sequential(_Stateless(), nn.Conv2d(dim * 4, dim_out, 1))
+
+
+class PixelShuffleUpsample(_Decl):
+    def __init__(self, dim, dim_out):
+        super().__init__()
+        conv = nn.Conv2d(dim, dim_out * 4, 1)
+        self.net = nn.Sequential(conv, _Stateless(), _Stateless())
+        o, i, h, w = conv.weight.shape
+        w0 = torch.empty(o // 4, i, h, w)
+        nn.init.kaiming_uniform_(w0)
+        with torch.no_grad():
+            conv.weight.copy_(w0.repeat_interleave(4, dim=0))
+            conv.bias.zero_()
+
+
+class Parallel(_Decl):
+    def __init__(self, *fns):
+        super().__init__()
+        self.fns = nn.ModuleList(fns)
+
+
+class Attention(_Decl):
+    def __init__(self, dim, *, dim_head, heads, context_dim=None):
+        super().__init__()
+        inner = dim_head * heads
+        self.norm = LayerNorm(dim)
+        self.null_kv = nn.Parameter(torch.randn(2, dim_head))
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_kv = nn.Linear(dim, dim_head * 2, bias=False)
+        self.to_context = (nn.Sequential(nn.LayerNorm(context_dim), nn.Linear(context_dim, dim_head * 2))
+                           if exists(context_dim) else None)
+        self.to_out = nn.Sequential(nn.Linear(inner, dim, bias=False), LayerNorm(dim))
+
+
+class CrossAttention(_Decl):
+    def __init__(self, dim, *, context_dim, dim_head, heads):
+        super().__init__()
+        inner = dim_head * heads
+        self.norm = LayerNorm(dim)
+        self.null_kv = nn.Parameter(torch.randn(2, dim_head))
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_kv = nn.Linear(context_dim, inner * 2, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, dim, bias=False), LayerNorm(dim))
+
+
+def _feed_forward(dim, mult):
+    hidden = int(dim * mult)
+    return nn.Sequential(LayerNorm(dim), nn.Linear(dim, hidden, bias=False), _Stateless(), LayerNorm(hidden),
+                         nn.Linear(hidden, dim, bias=False))
+
+
+class TransformerBlock(_Decl):
+    def __init__(self, dim, *, depth, heads, dim_head, ff_mult, context_dim=None):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            nn.ModuleList([Attention(dim, dim_head=dim_head, heads=heads, context_dim=context_dim),
+                           _feed_forward(dim, ff_mult)]) for _ in range(depth)])
+
+
+class PerceiverAttention(_Decl):
+    def __init__(self, *, dim, dim_head, heads):
+        super().__init__()
+        inner = dim_head * heads
+        self.norm = nn.LayerNorm(dim)
+        self.norm_latents = nn.LayerNorm(dim)
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_kv = nn.Linear(dim, inner * 2, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, dim, bias=False), nn.LayerNorm(dim))
+
+
+class PerceiverResampler(_Decl):
+    def __init__(self, *, dim, depth, dim_head, heads, num_latents, num_latents_mean_pooled=4, max_seq_len=512,
+                 ff_mult=4):
+        super().__init__()
+        self.pos_emb = nn.Embedding(max_seq_len, dim)
+        self.latents = nn.Parameter(torch.randn(num_latents, dim))
+        self.to_latents_from_mean_pooled_seq = nn.Sequential(
+            LayerNorm(dim), nn.Linear(dim, dim * num_latents_mean_pooled), _Stateless())
+        self.layers = nn.ModuleList([
+            nn.ModuleList([PerceiverAttention(dim=dim, dim_head=dim_head, heads=heads), _feed_forward(dim, ff_mult)])
+            for _ in range(depth)])
+        self.num_tokens = num_latents + num_latents_mean_pooled
+
+
+class GlobalContext(_Decl):
+    def __init__(self, *, dim_in, dim_out):
+        super().__init__()
+        self.to_k = nn.Conv2d(dim_in, 1, 1)
+        hidden = max(3, dim_out // 2)
+        self.net = nn.Sequential(nn.Conv2d(dim_in, hidden, 1), _Stateless(), nn.Conv2d(hidden, dim_out, 1),
+                                 _Stateless())
+
+
+class Block(_Decl):
+    def __init__(self, dim, dim_out, groups):
+        super().__init__()
+        self.groupnorm = nn.GroupNorm(groups, dim)
+        self.project = nn.Conv2d(dim, dim_out, 3, padding=1)
+
+
+class ResnetBlock(_Decl):
+    def __init__(self, dim, dim_out, *, cond_dim=None, time_cond_dim=None, groups=8, use_gca=False, heads=8,
+                 dim_head=64):
+        super().__init__()
+        if exists(time_cond_dim):
+            self.time_mlp = nn.Sequential(_Stateless(), nn.Linear(time_cond_dim, dim_out * 2))
+        if exists(cond_dim):
+            self.cross_attn = CrossAttention(dim_out, context_dim=cond_dim, dim_head=dim_head, heads=heads)
+        self.block1 = Block(dim, dim_out, groups)
+        self.block2 = Block(dim_out, dim_out, groups)
+        if use_gca:
+            self.gca = GlobalContext(dim_in=dim_out, dim_out=dim_out)
+        if dim != dim_out:
+            self.res_conv = nn.Conv2d(dim, dim_out, 1)
+
+
+# ============================================================================ Unet
+class Unet(nn.Module):
+    """Same constructor surface as ``imagen_pytorch.Unet`` for every kwarg the reference passes;
+    library defaults elsewhere.  Unsupported library switches raise early."""
+
+    def __init__(
+        self, *, dim, text_embed_dim=768, num_resnet_blocks=1, cond_dim=None, num_time_tokens=2,
+        learned_sinu_pos_emb_dim=16, dim_mults=(1, 2, 4, 8), cond_images_channels=0, channels=3,
+        channels_out=None, attn_dim_head=64, attn_heads=8, ff_mult=2.0, lowres_cond=False, layer_attns=True,
+        layer_attns_depth=1, attend_at_middle=True, layer_cross_attns=True, use_linear_attn=False,
+        use_linear_cross_attn=False, cond_on_text=True, max_text_len=256, resnet_groups=8,
+        init_cross_embed=True, init_cross_embed_kernel_sizes=(3, 7, 15), cross_embed_downsample=False,
+        attn_pool_text=True, attn_pool_num_latents=32, dropout=0.0, memory_efficient=False,
+        init_conv_to_final_conv_residual=False, use_global_context_attn=True, scale_skip_connection=True,
+        final_resnet_block=True, final_conv_kernel_size=3, self_cond=False, pixel_shuffle_upsample=True,
+    ):
+        super().__init__()
+        self._locals = {k: v for k, v in locals().items() if k not in ("self", "__class__")}
+        unsupported = dict(use_linear_attn=use_linear_attn, use_linear_cross_attn=use_linear_cross_attn,
+                           cross_embed_downsample=cross_embed_downsample, self_cond=self_cond)
+        bad = [k for k, v in unsupported.items() if (any(v) if isinstance(v, (tuple, list)) else bool(v))]
+        required = dict(init_cross_embed=init_cross_embed, scale_skip_connection=scale_skip_connection,
+                        final_resnet_block=final_resnet_block, pixel_shuffle_upsample=pixel_shuffle_upsample)
+        bad += [k for k, v in required.items() if not v]
+        if bad or final_conv_kernel_size != 3 or tuple(init_cross_embed_kernel_sizes) != (3, 7, 15) \
+                or layer_attns_depth != 1 or attn_dim_head != 64 or channels != 3:
+            raise NotImplementedError(
+                f"Unet option outside what the reference's configs use and the HIP engine plans: {bad or 'see kwargs'}")
+
+        self.channels = channels
+        self.channels_out = default(channels_out, channels)
+        self.lowres_cond = lowres_cond
+        self.cond_on_text = cond_on_text
+        self.cond_images_channels = cond_images_channels
+        self.has_cond_image = cond_images_channels > 0
+        self.memory_efficient = memory_efficient
+        self.init_conv_to_final_conv_residual = init_conv_to_final_conv_residual
+        self.max_text_len = max_text_len
+        self.dim = dim
+        init_channels = channels * (1 + int(lowres_cond)) + cond_images_channels
+
+        self.init_conv = CrossEmbedLayer(init_channels, init_cross_embed_kernel_sizes, dim, stride=1)
+        dims = [dim, *[dim * m for m in dim_mults]]
+        in_out = list(zip(dims[:-1], dims[1:]))
+        L = len(in_out)
+        cond_dim = default(cond_dim, dim)
+        tcd = dim * 4 * (2 if lowres_cond else 1)
+        self.cond_dim, self.time_cond_dim = cond_dim, tcd
+        sw = learned_sinu_pos_emb_dim + 1
+
+        def trio():
+            return (nn.Sequential(LearnedSinusoidalPosEmb(learned_sinu_pos_emb_dim), nn.Linear(sw, tcd), _Stateless()),
+                    nn.Sequential(nn.Linear(tcd, tcd)),
+                    nn.Sequential(nn.Linear(tcd, cond_dim * num_time_tokens), _Stateless()))
+
+        self.to_time_hiddens, self.to_time_cond, self.to_time_tokens = trio()
+        if lowres_cond:
+            self.to_lowres_time_hiddens, self.to_lowres_time_cond, self.to_lowres_time_tokens = trio()
+        self.norm_cond = nn.LayerNorm(cond_dim)
+        self.text_to_cond = None
+        if cond_on_text:
+            assert exists(text_embed_dim), "text_embed_dim must be given to the unet if cond_on_text is True"
+            self.text_to_cond = nn.Linear(text_embed_dim, cond_dim)
+        self.attn_pool = PerceiverResampler(dim=cond_dim, depth=2, dim_head=attn_dim_head, heads=attn_heads,
+                                            num_latents=attn_pool_num_latents) if attn_pool_text else None
+        self.null_text_embed = nn.Parameter(torch.randn(1, max_text_len, cond_dim))
+        self.null_text_hidden = nn.Parameter(torch.randn(1, tcd))
+        self.to_text_non_attn_cond = None
+        if cond_on_text:
+            self.to_text_non_attn_cond = nn.Sequential(nn.LayerNorm(cond_dim), nn.Linear(cond_dim, tcd),
+                                                       _Stateless(), nn.Linear(tcd, tcd))
+
+        ak = dict(heads=attn_heads, dim_head=attn_dim_head)
+        nrb = cast_tuple(num_resnet_blocks, L)
+        groups = cast_tuple(resnet_groups, L)
+        attns = cast_tuple(layer_attns, L)
+        cross = cast_tuple(layer_cross_attns, L)
+        assert len(set(groups)) == 1, "per-level resnet_groups are not planned by the engine"
+        self._plan = dict(dim=dim, dim_mults=tuple(dim_mults), num_resnet_blocks=nrb, layer_attns=attns,
+                          layer_cross_attns=cross, attn_heads=attn_heads, attn_dim_head=attn_dim_head,
+                          ff_mult=ff_mult, num_time_tokens=num_time_tokens, sinu_dim=learned_sinu_pos_emb_dim,
+                          groups=groups[0], attend_at_middle=attend_at_middle, use_gca=use_global_context_attn)
+
+        self.init_resnet_block = ResnetBlock(dim, dim, time_cond_dim=tcd, groups=groups[0],
+                                             use_gca=use_global_context_attn, **ak) if memory_efficient else None
+        self.downs = nn.ModuleList([])
+        self.ups = nn.ModuleList([])
+        skip_dims = []
+        for ind, ((d_in, d_out), n, g, la, lc) in enumerate(zip(in_out, nrb, groups, attns, cross)):
+            is_last = ind >= L - 1
+            cur = d_in
+            pre = None
+            if memory_efficient:
+                pre = _downsample(d_in, d_out)
+                cur = d_out
+            skip_dims.append(cur)
+            post = None
+            if not memory_efficient:
+                post = _downsample(cur, d_out) if not is_last else Parallel(
+                    nn.Conv2d(d_in, d_out, 3, padding=1), nn.Conv2d(d_in, d_out, 1))
+            self.downs.append(nn.ModuleList([
+                pre,
+                ResnetBlock(cur, cur, cond_dim=cond_dim if lc else None, time_cond_dim=tcd, groups=g, **ak),
+                nn.ModuleList([ResnetBlock(cur, cur, time_cond_dim=tcd, groups=g, use_gca=use_global_context_attn)
+                               for _ in range(n)]),
+                TransformerBlock(cur, depth=1, ff_mult=ff_mult, context_dim=cond_dim, **ak) if la else _Stateless(),
+                post,
+            ]))
+        mid = dims[-1]
+        self.mid_block1 = ResnetBlock(mid, mid, cond_dim=cond_dim, time_cond_dim=tcd, groups=groups[-1], **ak)
+        self.mid_attn = TransformerBlock(mid, depth=1, ff_mult=2, **ak) if attend_at_middle else None
+        self.mid_block2 = ResnetBlock(mid, mid, cond_dim=cond_dim, time_cond_dim=tcd, groups=groups[-1], **ak)
+        for ind, ((d_in, d_out), n, g, la, lc) in enumerate(
+                zip(reversed(in_out), reversed(nrb), reversed(groups), reversed(attns), reversed(cross))):
+            is_last = ind == L - 1
+            sd = skip_dims.pop()
+            self.ups.append(nn.ModuleList([
+                ResnetBlock(d_out + sd, d_out, cond_dim=cond_dim if lc else None, time_cond_dim=tcd, groups=g, **ak),
+                nn.ModuleList([ResnetBlock(d_out + sd, d_out, time_cond_dim=tcd, groups=g,
+                                           use_gca=use_global_context_attn) for _ in range(n)]),
+                TransformerBlock(d_out, depth=1, ff_mult=ff_mult, context_dim=cond_dim, **ak) if la else _Stateless(),
+                PixelShuffleUpsample(d_out, d_in) if (not is_last or memory_efficient) else _Stateless(),
+            ]))
+        fin = dim + (dim if init_conv_to_final_conv_residual else 0)
+        self.final_res_block = ResnetBlock(fin, dim, time_cond_dim=tcd, groups=groups[0], use_gca=True)
+        self.final_conv = nn.Conv2d(dim + (channels if lowres_cond else 0), self.channels_out, 3, padding=1)
+        nn.init.zeros_(self.final_conv.weight)
+        nn.init.zeros_(self.final_conv.bias)
+
+        self._engines = {}
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_engine())
+
+    # ---- library API used by Imagen
+    def cast_model_parameters(self, *, lowres_cond, text_embed_dim, channels, channels_out, cond_on_text):
+        if (lowres_cond == self.lowres_cond and channels == self.channels and cond_on_text == self.cond_on_text
+                and text_embed_dim == self._locals["text_embed_dim"] and channels_out == self.channels_out):
+            return self
+        return self.__class__(**{**self._locals, **dict(
+            lowres_cond=lowres_cond, text_embed_dim=text_embed_dim, channels=channels, channels_out=channels_out,
+            cond_on_text=cond_on_text)})
+
+    # ---- engine plumbing
+    def invalidate_engine(self):
+        lib = E._lib
+        for h in self._engines.values():
+            if lib is not None:
+                lib.kd_unet_destroy(h)
+        self._engines = {}
+
+    def _apply(self, fn, *a, **k):  # .to()/.cuda()/.float() move parameters: packed copies are stale
+        self.invalidate_engine()
+        return super()._apply(fn, *a, **k)
+
+    def __del__(self):
+        try:
+            self.invalidate_engine()
+        except Exception:
+            pass
+
+    @property
+    def n_text_tokens(self):
+        return self.attn_pool.num_tokens if (self.cond_on_text and exists(self.attn_pool)) else 0
+
+    def engine(self, batch: int, image_size: int, device, with_text: bool) -> C.c_void_p:
+        """Creates (or returns the cached) execution plan for a static (batch, image_size)."""
+        E.require_gpu()
+        lib = E.load()
+        device = torch.device(device)
+        key = (batch, image_size, device.index, bool(with_text))
+        if key in self._engines:
+            return self._engines[key]
+        p = self._plan
+        cfg = E.kd_unet_config_t()
+        L = len(p["dim_mults"])
+        assert L <= E.KD_MAX_LEVELS
+        cfg.dim, cfg.num_levels = p["dim"], L
+        for i in range(L):
+            cfg.dim_mults[i] = int(p["dim_mults"][i])
+            cfg.num_resnet_blocks[i] = int(p["num_resnet_blocks"][i])
+            cfg.layer_attns[i] = int(bool(p["layer_attns"][i]))
+            cfg.layer_cross_attns[i] = int(bool(p["layer_cross_attns"][i]))
+        cfg.cond_dim, cfg.channels = self.cond_dim, self.channels
+        cfg.cond_images_channels = self.cond_images_channels
+        cfg.lowres_cond = int(self.lowres_cond)
+        cfg.memory_efficient = int(self.memory_efficient)
+        cfg.init_conv_to_final_conv_residual = int(self.init_conv_to_final_conv_residual)
+        cfg.cond_on_text = int(self.cond_on_text)
+        cfg.text_tokens = self.n_text_tokens if with_text else 0
+        cfg.attn_heads, cfg.attn_dim_head = p["attn_heads"], p["attn_dim_head"]
+        ff2 = p["ff_mult"] * 2
+        assert float(ff2).is_integer(), "ff_mult must be a multiple of 0.5"
+        cfg.ff_mult_x2 = int(ff2)
+        cfg.num_time_tokens, cfg.sinu_dim = p["num_time_tokens"], p["sinu_dim"]
+        cfg.resnet_groups = p["groups"]
+        cfg.attend_at_middle, cfg.use_gca = int(p["attend_at_middle"]), int(p["use_gca"])
+        cfg.batch, cfg.image_size = batch, image_size
+
+        with torch.cuda.device(device):
+            sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous()
+                  for k, v in self.state_dict().items()}
+            torch.cuda.synchronize()
+            names = list(sd.keys())
+            arr = (E.kd_param_t * len(names))()
+            keep = []
+            for i, n in enumerate(names):
+                b = n.encode()
+                keep.append(b)
+                arr[i].name = b
+                arr[i].d_data = sd[n].data_ptr()
+                arr[i].numel = sd[n].numel()
+            handle = C.c_void_p()
+            E.check(lib.kd_unet_create(C.byref(cfg), arr, len(names), C.byref(handle)))
+            del sd
+        self._engines[key] = handle
+        return handle
+
+    def forward(self, x, time, *, lowres_cond_img=None, lowres_noise_times=None, text_embeds=None, text_mask=None,
+                cond_images=None, self_cond=None, cond_drop_prob=0.0):
+        """One UNet forward on the engine.  ``time`` is the log-SNR, as in the library."""
+        assert not (self.lowres_cond and not exists(lowres_cond_img)), "low resolution conditioning image must be present"
+        assert not (self.lowres_cond and not exists(lowres_noise_times)), "low resolution conditioning noise time must be present"
+        assert not (self.has_cond_image ^ exists(cond_images)), \
+            "you either requested to condition on an image on the unet, but the conditioning image is not supplied, or vice versa"
+        if exists(text_embeds) and self.cond_on_text:
+            raise NotImplementedError("text conditioning on the engine is planned (SURVEY §8f); not in this round")
+        E.require_gpu()
+        b, _, s, _ = x.shape
+        f32 = lambda t: None if t is None else t.to(device=x.device, dtype=torch.float32).contiguous()
+        if exists(cond_images):
+            assert cond_images.shape[1] == self.cond_images_channels, "invalid number of channels in conditioning image"
+            cond_images = resize_image_to(cond_images, s)
+        x, lowres_cond_img, cond_images = f32(x), f32(lowres_cond_img), f32(cond_images)
+        time, lowres_noise_times = f32(time), f32(lowres_noise_times)
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            h = self.engine(b, s, x.device, with_text=False)
+            E.check(E.load().kd_unet_forward(h, E.ptr(x), E.ptr(lowres_cond_img), E.ptr(cond_images), E.ptr(time),
+                                             E.ptr(lowres_noise_times), None, None, E.ptr(out), E.current_stream()))
+        return out
+
+    def forward_with_cond_scale(self, *args, cond_scale=1.0, **kwargs):
+        if cond_scale != 1:
+            raise NotImplementedError("classifier-free guidance (cond_scale != 1) is planned (SURVEY §8f)")
+        return self.forward(*args, **kwargs)
+
+
+class NullUnet(nn.Module):
+    """Placeholder; the reference subclasses it (train_ultra_res.py:65-75)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.lowres_cond = False
+        self.dummy_parameter = nn.Parameter(torch.tensor([0.0]))
+
+    def cast_model_parameters(self, *_, **__):
+        return self
+
+    def forward(self, x, *args, **kwargs):
+        return x
+
+
+class SRUnet1024(Unet):
+    """Imported by the reference (train_ultra_res.py:8), never instantiated there."""
+
+    def __init__(self, *args, **kwargs):
+        d = dict(dim_mults=(1, 2, 4, 8), num_resnet_blocks=(2, 4, 8, 8), layer_attns=False,
+                 layer_cross_attns=(False, False, False, True), attn_heads=8, ff_mult=2.0, memory_efficient=True)
+        super().__init__(*args, **{**d, **kwargs})
+
+
+class ElucidatedImagen(nn.Module):
+    """Imported by the reference, only used in commented-out code (train.py:97-110)."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("ElucidatedImagen is outside the reference's live sampling path")
+
+
+# ============================================================================ schedules (host scalars)
+def _log(t, eps=1e-12):
+    return torch.log(t.clamp(min=eps))
+
+
+def beta_linear_log_snr(t):
+    return -torch.log(torch.expm1(1e-4 + 10 * (t ** 2)))
+
+
+def alpha_cosine_log_snr(t, s: float = 0.008):
+    return -_log((torch.cos((t + s) / (1 + s) * math.pi * 0.5) ** -2) - 1, eps=1e-5)
+
+
+def log_snr_to_alpha_sigma(log_snr):
+    return torch.sqrt(torch.sigmoid(log_snr)), torch.sqrt(torch.sigmoid(-log_snr))
+
+
+class GaussianDiffusionContinuousTimes(nn.Module):
+    """Per-step scalars, computed on the host in fp32 with the library's op order;
+    the per-pixel arithmetic they feed runs in the engine's sampler kernels."""
+
+    def __init__(self, *, noise_schedule, timesteps=1000):
+        super().__init__()
+        if noise_schedule == "linear":
+            self.log_snr = beta_linear_log_snr
+        elif noise_schedule == "cosine":
+            self.log_snr = alpha_cosine_log_snr
+        else:
+            raise ValueError(f"invalid noise schedule {noise_schedule}")
+        self.num_timesteps = timesteps
+
+    def step_tables(self):
+        ts = torch.linspace(1.0, 0.0, self.num_timesteps + 1)
+        t, t_next = ts[:-1], ts[1:]
+        ls, ls_next = self.log_snr(t), self.log_snr(t_next)
+        alpha, sigma = log_snr_to_alpha_sigma(ls)
+        alpha_next, sigma_next = log_snr_to_alpha_sigma(ls_next)
+        c = -torch.expm1(ls - ls_next)
+        log_var = _log((sigma_next ** 2) * c, eps=1e-20)
+        noise_scale = (1 - (t_next == 0).float()) * (0.5 * log_var).exp()
+        # q_sample_from_to(t_next -> t): x*(alpha_to/alpha) + n*(sigma_to*alpha - sigma*alpha_to)/alpha
+        rn_a = alpha / alpha_next
+        rn_b = (sigma * alpha_next - sigma_next * alpha) / alpha_next
+        names = ("log_snr", "alpha", "sigma", "alpha_next", "sigma_next", "c", "noise_scale", "rn_a", "rn_b")
+        vals = (ls, alpha, sigma, alpha_next, sigma_next, c, noise_scale, rn_a, rn_b)
+        return {n: v.to(torch.float32).contiguous() for n, v in zip(names, vals)}
+
+
+def resize_image_to(image, target_image_size, mode="nearest"):
+    if image.shape[-1] == target_image_size:
+        return image
+    return F.interpolate(image, target_image_size, mode=mode)
+
+
+# ============================================================================ Imagen
+class Imagen(nn.Module):
+    def __init__(self, unets, *, image_sizes, text_encoder_name=None, text_embed_dim=None, channels=3,
+                 timesteps=1000, cond_drop_prob=0.1, loss_type="l2", noise_schedules="cosine",
+                 pred_objectives="noise", random_crop_sizes=None, lowres_noise_schedule="linear",
+                 lowres_sample_noise_level=0.2, per_sample_random_aug_noise_level=False, condition_on_text=True,
+                 auto_normalize_img=True, dynamic_thresholding=True, dynamic_thresholding_percentile=0.95,
+                 only_train_unet_number=None, **ignored_training_kwargs):
+        super().__init__()
+        assert auto_normalize_img, "the engine's finalize step assumes auto_normalize_img=True"
+        self.condition_on_text = condition_on_text
+        self.unconditional = not condition_on_text
+        self.channels = channels
+        unets = cast_tuple(unets)
+        n = len(unets)
+        timesteps = cast_tuple(timesteps, n)
+        ns = cast_tuple(noise_schedules)
+        ns = (*ns, *("cosine",) * max(0, 2 - len(ns)))
+        ns = (*ns, *("linear",) * max(0, n - len(ns)))
+        self.noise_schedulers = nn.ModuleList(
+            [GaussianDiffusionContinuousTimes(noise_schedule=s, timesteps=t) for t, s in zip(timesteps, ns)])
+        self.random_crop_sizes = cast_tuple(random_crop_sizes, n)
+        self.lowres_noise_schedule = GaussianDiffusionContinuousTimes(noise_schedule=lowres_noise_schedule)
+        self.pred_objectives = cast_tuple(pred_objectives, n)
+        self.text_embed_dim = default(text_embed_dim, 768)  # google/t5-v1_1-base
+        self.unets = nn.ModuleList([])
+        for ind, u in enumerate(unets):
+            assert isinstance(u, (Unet, NullUnet)), "unets must be Unet or NullUnet instances"
+            u = u.cast_model_parameters(
+                lowres_cond=ind != 0, cond_on_text=condition_on_text,
+                text_embed_dim=self.text_embed_dim if condition_on_text else None, channels=channels,
+                channels_out=channels)
+            self.unets.append(u)
+        self.image_sizes = cast_tuple(image_sizes)
+        assert n == len(self.image_sizes), \
+            f"you did not supply the correct number of u-nets ({n}) for resolutions {self.image_sizes}"
+        lowres = tuple(u.lowres_cond for u in self.unets)
+        assert lowres == (False, *((True,) * (n - 1))), \
+            "the first unet must be unconditioned (by low resolution image), the rest must have lowres_cond=True"
+        self.lowres_sample_noise_level = lowres_sample_noise_level
+        self.cond_drop_prob = cond_drop_prob
+        self.dynamic_thresholding = cast_tuple(dynamic_thresholding, n)
+        self.dynamic_thresholding_percentile = dynamic_thresholding_percentile
+        self.register_buffer("_temp", torch.tensor([0.0]), persistent=False)
+
+    @property
+    def device(self):
+        return self._temp.device
+
+    def get_unet(self, unet_number):
+        assert 0 < unet_number <= len(self.unets)
+        return self.unets[unet_number - 1]
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training is outside the sampling hot path this package replaces (SURVEY §2)")
+
+    # ------------------------------------------------------------------ sampling
+    @torch.no_grad()
+    def sample(self, texts=None, text_masks=None, text_embeds=None, video_frames=None, cond_images=None,
+               cond_video_frames=None, post_cond_video_frames=None, inpaint_videos=None, inpaint_images=None,
+               inpaint_masks=None, inpaint_resample_times=5, init_images=None, skip_steps=None, batch_size=1,
+               cond_scale=1.0, lowres_sample_noise_level=None, start_at_unet_number=1, start_image_or_video=None,
+               stop_at_unet_number=None, return_all_unet_outputs=False, return_pil_images=False, device=None,
+               use_tqdm=True, use_one_unet_in_gpu=True, *, noise_fn: Optional[Callable] = None,
+               seed: Optional[int] = None, use_graph: bool = True, trace: Optional[list] = None):
+        """Signature of the library's ``Imagen.sample``.  Extensions (keyword-only):
+        ``noise_fn(tag, shape)`` injects every Gaussian draw (parity tests, see oracle/sampler_ref.py
+        for the tags); ``seed`` keys the on-device Philox stream when no ``noise_fn`` is given
+        (default: drawn from torch's global generator, so ``torch.manual_seed`` reproduces a run)."""
+        for name, v in dict(texts=texts, video_frames=video_frames, cond_video_frames=cond_video_frames,
+                            post_cond_video_frames=post_cond_video_frames, inpaint_videos=inpaint_videos,
+                            init_images=init_images, skip_steps=skip_steps).items():
+            if exists(v):
+                raise NotImplementedError(f"sample({name}=...) is not used by the reference and not planned")
+        E.require_gpu()
+        device = torch.device(default(device, self.device))
+        if device.type != "cuda":
+            raise E.EngineUnavailable(f"sampling runs on the HIP engine only; got device {device}")
+        self.eval()
+
+        if not self.unconditional:
+            assert exists(text_embeds), "text must be passed in if the network was not trained without text `condition_on_text` must be set to `False` when training"
+            text_masks = default(text_masks, lambda: torch.any(text_embeds != 0.0, dim=-1))
+            batch_size = text_embeds.shape[0]
+        if exists(inpaint_images):
+            if self.unconditional and batch_size == 1:
+                batch_size = inpaint_images.shape[0]
+            assert inpaint_images.shape[0] == batch_size, \
+                "number of inpainting images must be equal to the specified batch size on sample `sample(batch_size=<int>)``"
+        assert not (self.condition_on_text and not exists(text_embeds)), "text or text encodings must be passed into imagen if specified"
+        assert not (not self.condition_on_text and exists(text_embeds)), "imagen specified not to be conditioned on text, yet it is presented"
+        assert not (exists(text_embeds) and text_embeds.shape[-1] != self.text_embed_dim), \
+            f"invalid text embedding dimension being passed in (should be {self.text_embed_dim})"
+        assert not (exists(inpaint_images) ^ exists(inpaint_masks)), "inpaint images and masks must be both passed in to do inpainting"
+        if exists(text_embeds):
+            raise NotImplementedError("text conditioning on the engine is planned (SURVEY §8f); not in this round")
+
+        lowres_sample_noise_level = default(lowres_sample_noise_level, self.lowres_sample_noise_level)
+        n = len(self.unets)
+        cond_scale = cast_tuple(cond_scale, n)
+        if exists(cond_images) and cond_images.dtype == torch.uint8:
+            cond_images = cond_images.float() / 255.0
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+
+        f32 = lambda t: None if t is None else t.to(device=device, dtype=torch.float32).contiguous()
+        img = None
+        if start_at_unet_number > 1:
+            assert start_at_unet_number <= n, "must start a unet that is less than the total number of unets"
+            assert not exists(stop_at_unet_number) or start_at_unet_number <= stop_at_unet_number
+            assert exists(start_image_or_video), "starting image or video must be supplied if only doing upscaling"
+            img = resize_image_to(f32(start_image_or_video), self.image_sizes[start_at_unet_number - 2])
+
+        outputs = []
+        for num, unet, size, sched, obj, dyn, cs in zip(
+                range(1, n + 1), self.unets, self.image_sizes, self.noise_schedulers, self.pred_objectives,
+                self.dynamic_thresholding, cond_scale):
+            if num < start_at_unet_number:
+                continue
+            assert not isinstance(unet, NullUnet), "one cannot sample from null / placeholder unets"
+            if cs != 1:
+                raise NotImplementedError("classifier-free guidance (cond_scale != 1) is planned (SURVEY §8f)")
+            img = self._p_sample_loop(
+                unet, num, size, sched, obj, dyn, batch_size, device, img, cond_images, inpaint_images,
+                inpaint_masks, inpaint_resample_times, lowres_sample_noise_level, noise_fn, seed, use_graph, trace)
+            outputs.append(img)
+            if exists(stop_at_unet_number) and stop_at_unet_number == num:
+                break
+
+        out = outputs if return_all_unet_outputs else outputs[-1]
+        if not return_pil_images:
+            return out
+        from PIL import Image  # noqa: local import, PIL only needed for this branch
+        to_pil = lambda t: [Image.fromarray((i.clamp(0, 1).permute(1, 2, 0).cpu().numpy() * 255).round().astype("uint8"))
+                            for i in t]
+        return [to_pil(o) for o in out] if return_all_unet_outputs else to_pil(out)
+
+    def _p_sample_loop(self, unet, stage, size, sched, objective, dynamic_threshold, batch, device, prev_img,
+                       cond_images, inpaint_images, inpaint_masks, resample_times, lowres_level, noise_fn, seed,
+                       use_graph, trace):
+        lib = E.load()
+        shape = (batch, self.channels, size, size)
+        f32 = lambda t: None if t is None else t.to(device=device, dtype=torch.float32).contiguous()
+        stage_seed = (seed + 0x9E3779B97F4A7C15 * stage) % (2 ** 64)
+
+        def gauss(tag, shp, sid):
+            if exists(noise_fn):
+                return f32(noise_fn(tag, tuple(shp)))
+            out = torch.empty(shp, device=device, dtype=torch.float32)
+            E.check(lib.kd_philox_normal(E.ptr(out), out.numel(), stage_seed, sid, E.current_stream()))
+            return out
+
+        with torch.cuda.device(device):
+            lowres = lowres_log_snr = None
+            if unet.lowres_cond:
+                t_lr = torch.full((batch,), lowres_level, dtype=torch.float32)
+                ls = self.lowres_noise_schedule.log_snr(t_lr)
+                a, s = log_snr_to_alpha_sigma(ls)
+                lowres = resize_image_to(prev_img, size) * 2 - 1
+                lowres = (a.to(device)[:, None, None, None] * lowres
+                          + s.to(device)[:, None, None, None] * gauss(("lowres", stage), lowres.shape, (16 << 32) | 1))
+                lowres = lowres.contiguous()
+                lowres_log_snr = ls.to(device)
+            cond = None
+            if exists(cond_images):
+                assert cond_images.shape[1] == unet.cond_images_channels, "invalid number of channels in conditioning image"
+                cond = f32(resize_image_to(f32(cond_images), size))
+            has_inpaint = exists(inpaint_images) and exists(inpaint_masks)
+            R = resample_times if has_inpaint else 1
+            inp = msk = None
+            if has_inpaint:
+                inp = f32(resize_image_to(f32(inpaint_images) * 2 - 1, size))
+                msk = f32(resize_image_to(f32(inpaint_masks)[:, None], size).bool().float())
+            T = sched.num_timesteps
+            tables = sched.step_tables()
+            sc = E.kd_schedule_t()
+            sc.T = T
+            for name, v in tables.items():
+                setattr(sc, name, v.numpy().ctypes.data_as(C.POINTER(C.c_float)))
+            args = E.kd_sample_args_t()
+            args.objective = {"noise": 0, "v": 1, "x_start": 2}[objective]
+            args.dynamic_threshold = int(bool(dynamic_threshold))
+            args.percentile = self.dynamic_thresholding_percentile
+            args.resample_times = R
+            args.d_lowres, args.d_lowres_log_snr, args.d_cond_images = E.ptr(lowres), E.ptr(lowres_log_snr), E.ptr(cond)
+            args.d_inpaint_images, args.d_inpaint_masks = E.ptr(inp), E.ptr(msk)
+            args.seed = stage_seed
+            args.use_graph = int(bool(use_graph))
+            keep = []
+            if exists(noise_fn):
+                def stack(kind):
+                    ts = [noise_fn((kind, stage, k, r), shape) for k in range(T) for r in reversed(range(R))]
+                    t = f32(torch.stack(ts))
+                    keep.append(t)
+                    return E.ptr(t)
+                args.d_noise_step = stack("step")
+                if has_inpaint:
+                    args.d_noise_inpaint = stack("inpaint")
+                    if R > 1:
+                        args.d_noise_renoise = stack("renoise")
+            img = gauss(("init", stage), shape, (16 << 32) | 2)
+            h = unet.engine(batch, size, device, with_text=False)
+            if exists(trace):
+                for k in range(T):
+                    E.check(lib.kd_sample_steps(h, C.byref(sc), C.byref(args), E.ptr(img), k, k + 1, E.current_stream()))
+                    trace.append(img.clone())
+                E.check(lib.kd_sample_finalize(h, C.byref(args), E.ptr(img), E.current_stream()))
+            else:
+                E.check(lib.kd_sample_loop(h, C.byref(sc), C.byref(args), E.ptr(img), E.current_stream()))
+            torch.cuda.current_stream().synchronize()  # host tables / noise buffers must outlive the launches
+            del keep
+        return img

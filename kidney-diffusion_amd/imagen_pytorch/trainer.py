@@ -1,0 +1,141 @@
+"""Sampling-side surface of ``imagen_pytorch.trainer`` as the reference uses it:
+
+  * ``restore_parts``      sample_ultra_res.py:12,63 / outpainting.py (partial state-dict load)
+  * ``ImagenTrainer(imagen=...)`` + ``.load(path)`` + ``.sample(**kwargs)``
+                           sample_uncond.py:22-55, sample_cond.py:26-48, sample.py:23-60
+
+Training methods are outside the hot path and raise ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+import copy
+from contextlib import contextmanager
+from pathlib import Path
+
+import torch
+from packaging import version
+from torch import nn
+
+from .imagen_pytorch import Imagen, NullUnet, exists
+from .version import __version__
+
+
+def restore_parts(state_dict_target, state_dict_from):
+    """Copies every same-named, same-shaped tensor; reports and skips the rest."""
+    for name, param in state_dict_from.items():
+        if name not in state_dict_target:
+            continue
+        if param.size() == state_dict_target[name].size():
+            state_dict_target[name].copy_(param)
+        else:
+            print(f"layer {name}({param.size()} different than target: {state_dict_target[name].size()}")
+    return state_dict_target
+
+
+def _open(path):
+    try:
+        from fsspec.core import url_to_fs
+
+        fs, _ = url_to_fs(str(path))
+        return fs, fs.open(str(path))
+    except ImportError:  # plain local files still work
+        return None, open(path, "rb")
+
+
+class ImagenTrainer(nn.Module):
+    def __init__(self, imagen=None, imagen_checkpoint_path=None, use_ema=True, lr=1e-4, fp16=False,
+                 max_grad_norm=None, dl_tuple_output_keywords_names=("images", "text_embeds", "text_masks",
+                                                                      "cond_images"),
+                 **ignored_training_kwargs):
+        super().__init__()
+        assert exists(imagen) ^ exists(imagen_checkpoint_path), \
+            "either imagen instance is passed into the trainer, or a checkpoint path that contains the imagen config"
+        assert isinstance(imagen, Imagen), "checkpoint-path construction is not used by the reference"
+        if fp16:
+            raise NotImplementedError("the engine computes in fp32, as the reference samples (fp16=False)")
+        self.imagen = imagen
+        self.use_ema = use_ema
+        self.num_unets = len(imagen.unets)
+        # EMA copies, filled by load(); sampling through the trainer uses them
+        self.ema_unets = nn.ModuleList([copy.deepcopy(u) for u in imagen.unets]) if use_ema else None
+        self.register_buffer("steps", torch.tensor([0] * self.num_unets))
+        self.register_buffer("_temp", torch.tensor([0.0]), persistent=False)
+
+    @property
+    def device(self):
+        return self.imagen.device
+
+    # ---- checkpoint
+    def load(self, path, only_model=False, strict=True, noop_if_not_exist=False):
+        fs, f = _open(path)
+        if noop_if_not_exist and ((fs is not None and not fs.exists(str(path))) or
+                                  (fs is None and not Path(path).exists())):
+            print(f"trainer checkpoint not found at {path}")
+            return
+        with f:
+            loaded_obj = torch.load(f, map_location="cpu")
+        if "version" in loaded_obj and version.parse(__version__) != version.parse(loaded_obj["version"]):
+            print(f'loading saved imagen at version {loaded_obj["version"]}, but current package version is {__version__}')
+        try:
+            self.imagen.load_state_dict(loaded_obj["model"], strict=strict)
+        except RuntimeError:
+            print("Failed loading state dict. Trying partial load")
+            self.imagen.load_state_dict(restore_parts(self.imagen.state_dict(), loaded_obj["model"]))
+        if only_model:
+            return loaded_obj
+        if "steps" in loaded_obj:
+            self.steps.copy_(loaded_obj["steps"])
+        if self.use_ema:
+            ema_sd = loaded_obj.get("ema")
+            if exists(ema_sd):
+                self._load_ema(ema_sd)
+            else:  # no EMA section: sample from the online weights
+                for e, u in zip(self.ema_unets, self.imagen.unets):
+                    e.load_state_dict(u.state_dict())
+        return loaded_obj
+
+    def _load_ema(self, ema_sd):
+        """'ema' is the state_dict of a ModuleList of ema-pytorch wrappers: keys
+        ``{i}.ema_model.<unet key>`` (+ ``{i}.online_model.*``, ``{i}.initted``, ``{i}.step``)."""
+        for i, e in enumerate(self.ema_unets):
+            prefix = f"{i}.ema_model."
+            sub = {k[len(prefix):]: v for k, v in ema_sd.items() if k.startswith(prefix)}
+            if not sub or isinstance(e, NullUnet):
+                continue
+            try:
+                e.load_state_dict(sub, strict=True)
+            except RuntimeError:
+                print(f"Failed loading EMA state dict of unet {i + 1}. Trying partial load")
+                e.load_state_dict(restore_parts(e.state_dict(), sub))
+
+    def save(self, *a, **k):
+        raise NotImplementedError("training-side checkpoint writing is outside the sampling hot path")
+
+    # ---- sampling
+    @contextmanager
+    def use_ema_unets(self):
+        if not self.use_ema:
+            yield
+            return
+        online = self.imagen.unets
+        self.imagen.unets = self.ema_unets
+        try:
+            yield
+        finally:
+            self.imagen.unets = online
+
+    @torch.no_grad()
+    def sample(self, *args, **kwargs):
+        kwargs.setdefault("device", self.device)
+        max_batch_size = kwargs.pop("max_batch_size", None)
+        if exists(max_batch_size):
+            raise NotImplementedError("max_batch_size chunking is not used by the reference's samplers")
+        with self.use_ema_unets():
+            return self.imagen.sample(*args, **kwargs)
+
+    # ---- training surface (out of scope)
+    def _no_training(self, *a, **k):
+        raise NotImplementedError("training is outside the sampling hot path this package replaces (SURVEY §2)")
+
+    train_step = valid_step = add_train_dataset = add_valid_dataset = add_train_dataloader = _no_training
+    add_valid_dataloader = update = forward = _no_training

@@ -207,8 +207,8 @@ class Imagen(nn.Module):
                     renoised = noise_scheduler.q_sample_from_to(
                         img, times_next, times, noise_fn(("renoise", stage, k, r), shape))
                     img = torch.where(_pad(img, is_last_timestep), img, renoised)
-                if exists(trace):
-                    trace.append(img.clone())
+            if exists(trace):  # state after timestep k (all resamples done)
+                trace.append(img.clone())
         img = img.clamp(-1.0, 1.0)
         if has_inpainting:
             img = img * ~inpaint_masks + inpaint_images * inpaint_masks

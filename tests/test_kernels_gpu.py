@@ -1,0 +1,151 @@
+"""GPU parity of the individual HIP kernels against plain torch fp32 ops (the oracle's building
+blocks), called through the C ABI (include/kd_engine.h)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from imagen_pytorch import _engine as E
+
+    return E.load()
+
+
+def _E():
+    from imagen_pytorch import _engine as E
+
+    return E
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# fp32 tolerance for one contraction: |err| <= tol * sum|a||b| bound, expressed as rel-L2
+CONV_REL = 2e-6
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,K,stride,pad,act", [
+    (2, 16, 16, 32, 64, 3, 1, 1, 0),      # plain 3x3
+    (1, 8, 8, 256, 128, 3, 1, 1, 0),      # deep K
+    (3, 9, 7, 36, 40, 3, 1, 1, 1),        # ragged sizes, Cin not /32, Cout not /32, SiLU
+    (2, 16, 16, 64, 96, 1, 1, 0, 2),      # 1x1 + GELU
+    (2, 16, 16, 32, 48, 2, 2, 0, 0),      # 2x2 stride 2 (pixel-unshuffle downsample)
+    (1, 20, 20, 12, 16, 7, 1, 3, 0),      # init-conv shapes: tiny Cin, wide window
+    (1, 20, 20, 12, 16, 15, 1, 7, 0),
+    (2, 8, 8, 132, 3, 3, 1, 1, 0),        # final conv: Cout = 3
+    (1, 1, 40, 128, 512, 1, 1, 0, 0),     # token GEMM, M = 40 < tile
+    (16, 16, 16, 128, 128, 3, 1, 1, 0),   # several M tiles x 1 N tile
+])
+def test_conv_igemm(lib, device, B, H, W, Cin, Cout, K, stride, pad, act):
+    E = _E()
+    x = torch.randn(B, Cin, H, W, generator=g(1))
+    w = torch.randn(Cout, Cin, K, K, generator=g(2)) * (Cin * K * K) ** -0.5
+    b = torch.randn(Cout, generator=g(3))
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad)
+    ref32 = F.conv2d(x, w, b, stride=stride, padding=pad)
+    if act == 1:
+        ref, ref32 = F.silu(ref), F.silu(ref32)
+    elif act == 2:
+        ref, ref32 = F.gelu(ref), F.gelu(ref32)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(device)
+    Ho, Wo = ref.shape[-2:]
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), device=device)
+    E.check(lib.kd_conv2d_nhwc(E.ptr(xd), E.ptr(w.to(device)), E.ptr(b.to(device)), E.ptr(y), B, H, W, Cin, Cout, K,
+                               K, stride, pad, act, E.current_stream()))
+    got = y.permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    err = float((got.double() - ref).norm() / ref.norm())
+    err_cpu = float((ref32.double() - ref).norm() / ref.norm())
+    # the engine must be as close to the fp64 truth as the CPU fp32 path is (x3 slack), and within CONV_REL*sqrt(K)
+    assert err <= max(3 * err_cpu, CONV_REL), (err, err_cpu)
+
+
+@pytest.mark.parametrize("B,HW,C,G,film", [(2, 64, 32, 8, False), (3, 100, 96, 8, True), (1, 4096, 128, 8, True),
+                                           (2, 16, 1024, 8, True), (2, 300, 384, 8, False)])
+def test_groupnorm_film_silu(lib, device, B, HW, C, G, film):
+    E = _E()
+    x = torch.randn(B, HW, C, generator=g(4)) * 2 + 0.5
+    gamma, beta = torch.randn(C, generator=g(5)), torch.randn(C, generator=g(6))
+    ss = torch.randn(B, 2 * C, generator=g(7)) * 0.3 if film else None
+    xn = x.permute(0, 2, 1)  # [B,C,HW]
+    ref = F.group_norm(xn.double(), G, gamma.double(), beta.double(), eps=1e-5)
+    if film:
+        sc, sh = ss.double()[:, :C, None], ss.double()[:, C:, None]
+        ref = ref * (sc + 1) + sh
+    ref = F.silu(ref).permute(0, 2, 1)
+    y = torch.empty(B, HW, C, device=device)
+    E.check(lib.kd_groupnorm_silu_nhwc(E.ptr(x.to(device)), E.ptr(gamma.to(device)), E.ptr(beta.to(device)),
+                                       E.ptr(ss.to(device)) if film else None, E.ptr(y), B, HW, C, G, 1e-5,
+                                       E.current_stream()))
+    assert torch.allclose(y.cpu().double(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("rows,C,bias", [(7, 32, False), (300, 256, True), (64, 2048, False), (5, 4096, True)])
+def test_layernorm(lib, device, rows, C, bias):
+    E = _E()
+    x = torch.randn(rows, C, generator=g(8)) * 3 + 1
+    gg = torch.randn(C, generator=g(9))
+    bb = torch.randn(C, generator=g(10)) if bias else None
+    ref = F.layer_norm(x.double(), (C,), gg.double(), bb.double() if bias else None, eps=1e-5)
+    y = torch.empty(rows, C, device=device)
+    E.check(lib.kd_layernorm(E.ptr(x.to(device)), E.ptr(gg.to(device)), E.ptr(bb.to(device)) if bias else None,
+                             E.ptr(y), rows, C, 1e-5, E.current_stream()))
+    assert torch.allclose(y.cpu().double(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,Nq,Nk,H,Hkv", [(2, 64, 69, 8, 1), (1, 300, 5, 8, 8), (2, 256, 261, 8, 1),
+                                           (1, 1000, 1029, 4, 1)])
+def test_attention(lib, device, B, Nq, Nk, H, Hkv):
+    E = _E()
+    D = 64
+    q = torch.randn(B, Nq, H, D, generator=g(11)) * 0.5
+    k = torch.randn(B, Nk, Hkv, D, generator=g(12))
+    v = torch.randn(B, Nk, Hkv, D, generator=g(13))
+    kk = k.expand(B, Nk, H, D) if Hkv == 1 else k
+    vv = v.expand(B, Nk, H, D) if Hkv == 1 else v
+    sim = torch.einsum("bihd,bjhd->bhij", q.double(), kk.double())
+    ref = torch.einsum("bhij,bjhd->bihd", sim.softmax(dim=-1), vv.double())
+    out = torch.empty(B, Nq, H, D, device=device)
+    E.check(lib.kd_attention(E.ptr(q.to(device)), E.ptr(k.to(device).contiguous()), E.ptr(v.to(device).contiguous()),
+                             E.ptr(out), B, Nq, Nk, H, Hkv, D, E.current_stream()))
+    assert torch.allclose(out.cpu().double(), ref, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,n,q", [(3, 12288, 0.95), (2, 196608, 0.95), (1, 1000, 0.5), (2, 37, 0.0), (2, 37, 1.0),
+                                   (4, 4096, 0.95)])
+def test_quantile_abs_matches_torch(lib, device, B, n, q):
+    E = _E()
+    x = torch.randn(B, n, generator=g(14)) * 1.7
+    if n == 4096:  # heavy duplicates: forces the equal-bin branch of the radix select
+        x = (x * 2).round() / 2
+    ref = torch.quantile(x.abs(), q, dim=-1)
+    ws_bytes = lib.kd_quantile_workspace_bytes(B)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    out = torch.empty(B, device=device)
+    E.check(lib.kd_quantile_abs(E.ptr(x.to(device)), E.ptr(out), B, n, q, C.c_void_p(ws.data_ptr()), ws_bytes,
+                                E.current_stream()))
+    # order statistics are selected exactly; the final lerp is one fp32 fma apart at most
+    assert torch.allclose(out.cpu(), ref, rtol=0, atol=2e-7 * float(ref.abs().max()) + 1e-12), (out.cpu(), ref)
+
+
+def test_philox_normal_matches_host_reference_and_is_normal(lib, device):
+    from oracle.philox_ref import philox_normal
+
+    E = _E()
+    n = 1 << 20
+    out = torch.empty(n, device=device)
+    E.check(lib.kd_philox_normal(E.ptr(out), n, 0x1234567, (16 << 32) | 2, E.current_stream()))
+    got = out.cpu().numpy()
+    ref = philox_normal(n, 0x1234567, (16 << 32) | 2)
+    assert np.abs(got - ref).max() < 2e-5   # same counters; only libm vs ocml ulps differ
+    assert abs(got.mean()) < 5e-3 and abs(got.std() - 1) < 5e-3
+    out2 = torch.empty(n, device=device)
+    E.check(lib.kd_philox_normal(E.ptr(out2), n, 0x1234567, (16 << 32) | 3, E.current_stream()))
+    assert abs(float((out * out2).mean())) < 5e-3  # streams are independent

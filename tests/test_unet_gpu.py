@@ -1,0 +1,134 @@
+"""GPU parity of the whole UNet forward and of the sampler loop against the CPU oracle, through
+the drop-in Python surface (which calls the C ABI).  Same weights, same inputs, same noise."""
+import pytest
+import torch
+
+import helpers as H
+from oracle import sampler_ref as RS
+
+pytestmark = pytest.mark.gpu
+
+# Stated fp32 tolerances (north_star: "within a stated fp32 tolerance").
+FWD_REL_L2 = 2e-5        # one UNet forward: relative L2 of the output vs the CPU fp32 oracle
+SAMPLE_ABS = 2e-3        # images in [0,1] after T denoising steps (error compounds through the loop)
+
+
+def _inputs(name, B, S, lowres, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    kw = H.UNET_KW[name]
+    x = torch.randn(B, 3, S, S, generator=g)
+    lr = torch.randn(B, 3, S, S, generator=g) if lowres else None
+    cc = kw.get("cond_images_channels", 0)
+    cond = torch.rand(B, cc, 2 * S, 2 * S, generator=g) if cc else None   # resized inside (nearest)
+    t = torch.randn(B, generator=g) * 3
+    tl = torch.full((B,), -1.3) if lowres else None
+    return x, lr, cond, t, tl
+
+
+@pytest.mark.parametrize("name,lowres,B,S", [
+    ("small1", False, 2, 16),
+    ("small2", True, 2, 32),
+    ("ultra1", False, 2, 32),     # train_ultra_res.py:29-36 at dim 32 (cond images, attention at 3 levels)
+    ("ultra2", True, 3, 64),      # train_ultra_res.py:39-48 (memory efficient SR unet)  <- headline UNet
+    ("ultra3", True, 1, 64),      # train_ultra_res.py:51-60 (blocks 2,4,6,8, no self-attention but mid)
+    ("uncond1", False, 1, 32),    # train_uncond.py:30-36 (cond_dim 64 here)
+])
+def test_unet_forward_matches_oracle(device, name, lowres, B, S):
+    ou = H.oracle_unet(name, lowres_cond=lowres, seed=11).eval()
+    pu = H.product_unet_like(ou).to(device)
+    x, lr, cond, t, tl = _inputs(name, B, S, lowres)
+    with torch.no_grad():
+        ref = ou(x, t, lowres_cond_img=lr, lowres_noise_times=tl, cond_images=cond)
+    dv = lambda v: None if v is None else v.to(device)
+    got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    err = H.rel_l2(got, ref)
+    assert err < FWD_REL_L2, f"{name}: rel-L2 {err:.3e}"
+    # second call reuses the cached plan and must be bit-identical (no stale state in the workspace)
+    got2 = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
+    assert torch.equal(got, got2)
+
+
+def test_engine_mac_count_matches_survey_appendix_b(device):
+    """unet2 64->256 (train_ultra_res.py:39-48, 3 cond channels) = 229.2 GMAC/sample."""
+    import imagen_pytorch as ip
+    from imagen_pytorch import _engine as E
+
+    with torch.device("meta"):
+        u = ip.Unet(dim=128, dim_mults=(1, 2, 4, 8), num_resnet_blocks=2, memory_efficient=True,
+                    layer_attns=(False, False, False, True), layer_cross_attns=(False, False, True, True),
+                    init_conv_to_final_conv_residual=True, cond_images_channels=3, lowres_cond=True,
+                    cond_on_text=False, text_embed_dim=None)
+    u = u.to_empty(device=device)
+    h = u.engine(1, 256, device, with_text=False)
+    gmac = E.load().kd_unet_macs(h) / 1e9
+    assert abs(gmac - 229.2) / 229.2 < 0.01, gmac
+
+
+def _imagen_pair(device, names, sizes, timesteps, objectives, seed=5):
+    import imagen_pytorch as ip
+
+    ous = [H.oracle_unet(n, lowres_cond=i > 0, seed=seed + i) for i, n in enumerate(names)]
+    oim = RS.Imagen(ous, image_sizes=sizes, timesteps=timesteps, pred_objectives=objectives, condition_on_text=False)
+    pus = [ip.Unet(**{k: v for k, v in u._locals.items()}) for u in oim.unets]
+    pim = ip.Imagen(pus, image_sizes=sizes, timesteps=timesteps, pred_objectives=objectives, condition_on_text=False)
+    pim.load_state_dict(oim.state_dict(), strict=True)
+    return oim, pim.to(device)
+
+
+@pytest.mark.parametrize("objective", ["noise", "v"])
+def test_sample_base_unet_matches_oracle(device, objective):
+    """BASELINE config 1 shape (uncond base UNet, DDPM loop) at reduced dim/T: sample_uncond.py:49-55."""
+    oim, pim = _imagen_pair(device, ["small1"], (16,), (6,), (objective,))
+    nf = RS.generator_noise_fn(77)
+    otrace, ptrace = [], []
+    ref = oim.sample(noise_fn=nf, batch_size=2, trace=otrace)
+    got = pim.sample(noise_fn=nf, batch_size=2, trace=ptrace, device=device)
+    assert len(otrace) == len(ptrace) == 6
+    for k, (a, b) in enumerate(zip(ptrace, otrace)):
+        assert H.rel_l2(a, b) < 1e-4 * (k + 1), (k, H.rel_l2(a, b))
+    assert (got.cpu() - ref).abs().max() < SAMPLE_ABS
+    # graph replay and eager launches give the same result bit for bit
+    got_graph = pim.sample(noise_fn=nf, batch_size=2, device=device, use_graph=True)
+    got_eager = pim.sample(noise_fn=nf, batch_size=2, device=device, use_graph=False)
+    assert torch.equal(got_graph, got_eager)
+    assert (got_graph.cpu() - ref).abs().max() < SAMPLE_ABS
+
+
+def test_sample_sr_unet_with_cond_and_inpainting_matches_oracle(device):
+    """The ultra-res call shape (sample_ultra_res.py:183-195): start at unet 2, cond image, inpaint
+    patch + mask with resampling."""
+    oim, pim = _imagen_pair(device, ["small1", "small2"], (16, 32), (4, 5), ("noise", "v"))
+    g = torch.Generator().manual_seed(9)
+    start = torch.rand(1, 3, 16, 16, generator=g)
+    cond = torch.rand(1, 3, 64, 64, generator=g)
+    inp = torch.rand(1, 3, 32, 32, generator=g)
+    mask = torch.zeros(1, 32, 32)
+    mask[:, :8, :] = 1
+    mask[:, :, :8] = 1
+    nf = RS.generator_noise_fn(123)
+    kw = dict(batch_size=1, cond_images=cond, start_image_or_video=start, start_at_unet_number=2,
+              stop_at_unet_number=2, inpaint_images=inp, inpaint_masks=mask, inpaint_resample_times=3)
+    ref = oim.sample(noise_fn=nf, **kw)
+    dv = lambda t: t.to(device)
+    got = pim.sample(noise_fn=nf, device=device, **{k: (dv(v) if torch.is_tensor(v) else v) for k, v in kw.items()})
+    assert got.shape == (1, 3, 32, 32)
+    assert (got.cpu() - ref).abs().max() < SAMPLE_ABS
+    # known pixels are pasted back exactly (final inpaint step)
+    m = mask.bool()[:, None].expand_as(ref)
+    assert torch.equal(got.cpu()[m], ref[m])
+
+
+def test_sample_without_noise_fn_is_seeded_and_bounded(device):
+    """Production path: on-device Philox noise; same seed -> same image, different seed -> different."""
+    _, pim = _imagen_pair(device, ["small1"], (16,), (5,), ("noise",))
+    a = pim.sample(batch_size=2, device=device, seed=42)
+    b = pim.sample(batch_size=2, device=device, seed=42)
+    c = pim.sample(batch_size=2, device=device, seed=43)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert a.min() >= 0 and a.max() <= 1
+    torch.manual_seed(7)
+    d = pim.sample(batch_size=2, device=device)
+    torch.manual_seed(7)
+    e = pim.sample(batch_size=2, device=device)
+    assert torch.equal(d, e)
