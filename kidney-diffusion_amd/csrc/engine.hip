@@ -142,11 +142,13 @@ struct kd_unet {
   int s_tables_cap = 0;
   // cached graph of one iteration
   hipGraphExec_t graph_exec = nullptr;
+  hipStream_t cap_stream = nullptr;
   std::vector<uint64_t> graph_key;
 
   float* P(size_t off) const { return (float*)(ws + off); }
   ~kd_unet() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
     void* frees[] = {ws, s_pred, s_x0, s_thresh, s_time, s_tables, s_iter, s_qws};
     for (void* p : frees)
       if (p) (void)hipFree(p);

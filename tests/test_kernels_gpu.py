@@ -57,8 +57,9 @@ def test_conv_igemm(lib, device, B, H, W, Cin, Cout, K, stride, pad, act):
     xd = x.permute(0, 2, 3, 1).contiguous().to(device)
     Ho, Wo = ref.shape[-2:]
     y = torch.full((B, Ho, Wo, Cout), float("nan"), device=device)
-    E.check(lib.kd_conv2d_nhwc(E.ptr(xd), E.ptr(w.to(device)), E.ptr(b.to(device)), E.ptr(y), B, H, W, Cin, Cout, K,
-                               K, stride, pad, act, E.current_stream()))
+    wd, bd = w.to(device), b.to(device)  # keep the device tensors alive across the call
+    E.check(lib.kd_conv2d_nhwc(E.ptr(xd), E.ptr(wd), E.ptr(bd), E.ptr(y), B, H, W, Cin, Cout, K, K, stride, pad, act,
+                               E.current_stream()))
     got = y.permute(0, 3, 1, 2).cpu()
     assert torch.isfinite(got).all()
     err = float((got.double() - ref).norm() / ref.norm())
@@ -81,8 +82,9 @@ def test_groupnorm_film_silu(lib, device, B, HW, C, G, film):
         ref = ref * (sc + 1) + sh
     ref = F.silu(ref).permute(0, 2, 1)
     y = torch.empty(B, HW, C, device=device)
-    E.check(lib.kd_groupnorm_silu_nhwc(E.ptr(x.to(device)), E.ptr(gamma.to(device)), E.ptr(beta.to(device)),
-                                       E.ptr(ss.to(device)) if film else None, E.ptr(y), B, HW, C, G, 1e-5,
+    xd, gd, bd = x.to(device), gamma.to(device), beta.to(device)
+    sd = ss.to(device) if film else None
+    E.check(lib.kd_groupnorm_silu_nhwc(E.ptr(xd), E.ptr(gd), E.ptr(bd), E.ptr(sd), E.ptr(y), B, HW, C, G, 1e-5,
                                        E.current_stream()))
     assert torch.allclose(y.cpu().double(), ref, rtol=2e-5, atol=2e-5)
 
@@ -95,8 +97,9 @@ def test_layernorm(lib, device, rows, C, bias):
     bb = torch.randn(C, generator=g(10)) if bias else None
     ref = F.layer_norm(x.double(), (C,), gg.double(), bb.double() if bias else None, eps=1e-5)
     y = torch.empty(rows, C, device=device)
-    E.check(lib.kd_layernorm(E.ptr(x.to(device)), E.ptr(gg.to(device)), E.ptr(bb.to(device)) if bias else None,
-                             E.ptr(y), rows, C, 1e-5, E.current_stream()))
+    xd, gd = x.to(device), gg.to(device)
+    bd = bb.to(device) if bias else None
+    E.check(lib.kd_layernorm(E.ptr(xd), E.ptr(gd), E.ptr(bd), E.ptr(y), rows, C, 1e-5, E.current_stream()))
     assert torch.allclose(y.cpu().double(), ref, rtol=2e-5, atol=2e-5)
 
 
@@ -113,8 +116,8 @@ def test_attention(lib, device, B, Nq, Nk, H, Hkv):
     sim = torch.einsum("bihd,bjhd->bhij", q.double(), kk.double())
     ref = torch.einsum("bhij,bjhd->bihd", sim.softmax(dim=-1), vv.double())
     out = torch.empty(B, Nq, H, D, device=device)
-    E.check(lib.kd_attention(E.ptr(q.to(device)), E.ptr(k.to(device).contiguous()), E.ptr(v.to(device).contiguous()),
-                             E.ptr(out), B, Nq, Nk, H, Hkv, D, E.current_stream()))
+    qd, kd, vd = q.to(device), k.to(device).contiguous(), v.to(device).contiguous()
+    E.check(lib.kd_attention(E.ptr(qd), E.ptr(kd), E.ptr(vd), E.ptr(out), B, Nq, Nk, H, Hkv, D, E.current_stream()))
     assert torch.allclose(out.cpu().double(), ref, rtol=1e-4, atol=2e-5)
 
 
@@ -129,7 +132,8 @@ def test_quantile_abs_matches_torch(lib, device, B, n, q):
     ws_bytes = lib.kd_quantile_workspace_bytes(B)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
     out = torch.empty(B, device=device)
-    E.check(lib.kd_quantile_abs(E.ptr(x.to(device)), E.ptr(out), B, n, q, C.c_void_p(ws.data_ptr()), ws_bytes,
+    xd = x.to(device)
+    E.check(lib.kd_quantile_abs(E.ptr(xd), E.ptr(out), B, n, q, C.c_void_p(ws.data_ptr()), ws_bytes,
                                 E.current_stream()))
     # order statistics are selected exactly; the final lerp is one fp32 fma apart at most
     assert torch.allclose(out.cpu(), ref, rtol=0, atol=2e-7 * float(ref.abs().max()) + 1e-12), (out.cpu(), ref)
