@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoising-steps/sec of the 64->256 super-res UNet (train_ultra_res.py:39-48
+kwargs, 3 cond-image channels, low-res conditioned) at batch 16 on N MI355X (BASELINE.json).
+
+One "step" = one (t -> t_next) iteration of the DDPM sampling loop for the whole batch: inpaint-free,
+cond_scale 1 => exactly one UNet forward + x0/quantile/posterior/noise kernels.
+Weights are random-init (no checkpoints exist offline), inputs synthetic; everything is resident in
+HBM before the timed region.  N > 1: one process per GPU, every rank runs its own batch of 16 (the
+path has no cross-sample exchange: replicas of independent batches, weak scaling, no collective in
+the data path); rank 0 prints ONE JSON line.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (ROOT, ROOT / "kidney-diffusion_amd"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+import torch  # noqa: E402
+
+BATCH, SIZE, T_SCHED = 16, 256, 250
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix = vector peak (v_mfma_f32_32x32x2_f32, exact fp32)
+SR_UNET_KW = dict(dim=128, dim_mults=(1, 2, 4, 8), num_resnet_blocks=2, memory_efficient=True,
+                  layer_attns=(False, False, False, True), layer_cross_attns=(False, False, True, True),
+                  init_conv_to_final_conv_residual=True, cond_images_channels=3)  # train_ultra_res.py:39-48
+
+
+def build_unet(seed=0):
+    import imagen_pytorch as ip
+
+    torch.manual_seed(seed)
+    u = ip.Unet(**SR_UNET_KW, lowres_cond=True, cond_on_text=False, text_embed_dim=None)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():  # the library zero-inits final_conv; re-init so outputs are non-trivial
+        u.final_conv.weight.copy_(torch.randn(u.final_conv.weight.shape, generator=g) * 0.02)
+        u.final_conv.bias.copy_(torch.randn(u.final_conv.bias.shape, generator=g) * 0.02)
+    return u
+
+
+def synthetic_inputs(batch, device=None, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(batch, 3, SIZE, SIZE, generator=g)
+    start = torch.rand(batch, 3, 64, 64, generator=g)
+    cond = torch.rand(batch, 3, SIZE, SIZE, generator=g)  # already at the UNet's resolution
+    lowres = torch.nn.functional.interpolate(start, SIZE, mode="nearest") * 2 - 1
+    lowres_noise = torch.randn(batch, 3, SIZE, SIZE, generator=g)
+    mv = (lambda t: t.to(device).contiguous()) if device is not None else (lambda t: t)
+    return mv(x), mv(lowres), mv(lowres_noise), mv(cond)
+
+
+def cpu_baseline(unet_product, device_tables):
+    """The oracle (CPU fp32 torch restatement) timed on this host, bounded sample: batch 2 (1/8 of the
+    headline batch), one warm-up step + one timed step.  steps/s is scaled to batch 16."""
+    from oracle import imagen_ref as R
+    from oracle import sampler_ref as RS
+
+    nthreads = torch.get_num_threads()
+    ou = R.Unet(**SR_UNET_KW, lowres_cond=True, cond_on_text=False, text_embed_dim=None)
+    ou.load_state_dict(unet_product.state_dict(), strict=True)
+    ou.eval()
+    oim = RS.Imagen([R.NullUnet(), ou], image_sizes=(64, SIZE), timesteps=(T_SCHED, T_SCHED),
+                    pred_objectives=("noise", "noise"), condition_on_text=False)
+    b = 2
+    x, lowres, lowres_noise, cond = synthetic_inputs(b)
+    sched = oim.noise_schedulers[1]
+    t_lr = torch.full((b,), 0.2)
+    lowres = oim.lowres_noise_schedule.q_sample(lowres, t_lr, lowres_noise)
+    times = sched.get_sampling_timesteps(b)
+    g = torch.Generator().manual_seed(99)
+    kw = dict(noise_scheduler=sched, text_embeds=None, text_mask=None, cond_images=cond, lowres_cond_img=lowres,
+              lowres_noise_times=t_lr, cond_scale=1.0, pred_objective="noise", dynamic_threshold=True)
+    dts = []
+    with torch.no_grad():
+        for k in range(2):
+            t, tn = times[k]
+            t0 = time.perf_counter()
+            x, _ = oim.p_sample(ou, x, t, torch.randn(x.shape, generator=g), t_next=tn, **kw)
+            dts.append(time.perf_counter() - t0)
+    sec_per_step_b16 = dts[-1] * (BATCH / b)
+    return {"value": 1.0 / sec_per_step_b16, "unit": "denoising-steps/s (batch 16)", "cores": nthreads,
+            "kind": "port",
+            "sample": f"oracle p_sample on CPU at batch {b} (1/8 of the batch), 1 warm-up + 1 timed step "
+                      f"({dts[-1]:.2f} s), scaled x{BATCH // b} to batch 16; torch {torch.__version__} oneDNN fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    distributed = world > 1
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # RCCL; used for the barrier / max-reduce only
+
+    from imagen_pytorch import _engine as E
+    from imagen_pytorch.imagen_pytorch import GaussianDiffusionContinuousTimes, log_snr_to_alpha_sigma, \
+        beta_linear_log_snr
+
+    lib = E.load()
+    unet = build_unet(0)
+    handle = unet.engine(BATCH, SIZE, device, with_text=False)
+    macs = lib.kd_unet_macs(handle)
+    flop_per_step = 2.0 * macs
+    launches = lib.kd_unet_num_launches(handle)
+
+    x, lowres, lowres_noise, cond = synthetic_inputs(BATCH, device, seed=1234 + rank)
+    ls_lr = beta_linear_log_snr(torch.full((BATCH,), 0.2))
+    a, s = log_snr_to_alpha_sigma(ls_lr)
+    lowres = (a.to(device)[:, None, None, None] * lowres + s.to(device)[:, None, None, None] * lowres_noise).contiguous()
+    lowres_log_snr = ls_lr.to(device)
+    sched = GaussianDiffusionContinuousTimes(noise_schedule="cosine", timesteps=T_SCHED)  # stage 2: cosine
+    tables = sched.step_tables()
+    sc = E.kd_schedule_t()
+    sc.T = T_SCHED
+    for name, v in tables.items():
+        setattr(sc, name, v.numpy().ctypes.data_as(C.POINTER(C.c_float)))
+    sa = E.kd_sample_args_t()
+    sa.objective, sa.dynamic_threshold, sa.percentile, sa.resample_times = 0, 1, 0.95, 1
+    sa.d_lowres, sa.d_lowres_log_snr, sa.d_cond_images = E.ptr(lowres), E.ptr(lowres_log_snr), E.ptr(cond)
+    sa.seed = 1234 + rank  # per-step noise: on-device Philox inside the fused DDPM-update kernel
+    sa.use_graph = 0 if args.no_graph else 1
+
+    def run_steps(k0, n):
+        """n consecutive denoising steps starting at schedule index k0 (wraps around T)."""
+        while n > 0:
+            k0 %= T_SCHED
+            m = min(n, T_SCHED - k0)
+            E.check(lib.kd_sample_steps(handle, C.byref(sc), C.byref(sa), E.ptr(x), k0, k0 + m, E.current_stream()))
+            k0 += m
+            n -= m
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(0, args.warmup)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run_steps(args.warmup, args.steps)
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the graph is launched on
+    assert torch.isfinite(x).all(), "sampler state went non-finite"
+    if distributed:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        dev_ms_per_step = dev_ms / args.steps
+        achieved = flop_per_step / (dev_ms_per_step * 1e-3) / 1e12
+        traffic = None
+        tf = ROOT / "profiles" / "hbm_traffic.json"
+        if tf.exists():
+            traffic = json.loads(tf.read_text()).get("bytes_per_step")
+        out = {
+            "metric": "denoising-steps/sec (64->256 SR UNet, bs16)",
+            "value": world * args.steps / elapsed,
+            "unit": "denoising-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: stage-2 super-res UNet 64->256 (train_ultra_res.py:39-48, "
+                                   "3 cond channels), batch 16 per GPU, cosine schedule T=250, dynamic thresholding, "
+                                   "random-init weights, Philox noise on device, hipGraph-replayed step",
+                       "batch_per_gpu": BATCH, "image_size": SIZE, "launches_per_step": launches,
+                       "parallelism": f"{world} independent batch replicas (no data-path collective)"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "one denoising-step graph (UNet forward + x0/quantile/DDPM update); "
+                                   f"{flop_per_step / 1e12:.3f} TFLOP algorithmic per launch (2 x "
+                                   f"{macs / 1e9 / BATCH:.1f} GMAC/sample x {BATCH}), device time by HIP events "
+                                   f"{dev_ms_per_step:.2f} ms/launch; fp32 MFMA peak"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(unet, tables)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,10 @@ int64_t kd_unet_hbm_bytes(const kd_unet_t* u);
 int64_t kd_unet_macs(const kd_unet_t* u);
 int kd_unet_num_launches(const kd_unet_t* u);
 
+/* Diagnostic: per-launch device time of one forward as CSV "index,label,macs,avg_us" (uses the
+ * inputs of the preceding kd_unet_forward call; synchronises the stream). */
+int kd_unet_profile(kd_unet_t* u, int iters, char* buf, size_t buflen, void* stream);
+
 /* Replaces `unet.forward_with_cond_scale(x, log_snr(t), lowres_cond_img=..,
  * lowres_noise_times=.., cond_images=.., text_embeds=..)` at cond_scale == 1.
  *   d_x            [B,3,S,S]

@@ -126,6 +126,8 @@ using namespace kd;
 struct kd_unet {
   kd_unet_config_t cfg;
   std::vector<std::function<int(hipStream_t)>> ops;
+  std::vector<std::string> op_label;  // per-op description + algorithmic MACs (kd_unet_profile)
+  std::vector<int64_t> op_macs;
   WeightPool wpool;
   char* ws = nullptr;
   size_t ws_bytes = 0;
@@ -236,7 +238,11 @@ struct Builder {
       arena.release(t.off);
     }
   }
-  void emit(std::function<int(hipStream_t)> f) { u->ops.push_back(std::move(f)); }
+  void emit(std::function<int(hipStream_t)> f, std::string label = "op", int64_t macs = 0) {
+    u->ops.push_back(std::move(f));
+    u->op_label.push_back(std::move(label));
+    u->op_macs.push_back(macs);
+  }
 
   // ---- conv / GEMM emission
   struct ConvOpt {
@@ -287,7 +293,12 @@ struct Builder {
       return launch_conv_igemm(q, s);
     });
     int cin = o.cin_logical > 0 ? o.cin_logical : x.C;
-    u->macs += (int64_t)x.B * Ho * Wo * Cout * cin * K * K;
+    int64_t m = (int64_t)x.B * Ho * Wo * Cout * cin * K * K;
+    u->op_label.back() = "conv k" + std::to_string(K) + " s" + std::to_string(stride) + " M" +
+                         std::to_string((int64_t)x.B * Ho * Wo) + " Cin" + std::to_string(x.C) + " Cout" +
+                         std::to_string(Cout);
+    u->op_macs.back() = m;
+    u->macs += m;
     return y;
   }
   // token GEMM y[M,N] = x[M,K] @ w[N,K]^T
