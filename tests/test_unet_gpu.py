@@ -132,3 +132,43 @@ def test_sample_without_noise_fn_is_seeded_and_bounded(device):
     torch.manual_seed(7)
     e = pim.sample(batch_size=2, device=device)
     assert torch.equal(d, e)
+
+
+# ------------------------------------------------------------------------------- engine vs committed golden vectors
+import numpy as np  # noqa: E402
+from pathlib import Path  # noqa: E402
+
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.mark.parametrize("fname,name,lowres", [("unet_small1.npz", "small1", False),
+                                               ("unet_small2_lowres.npz", "small2", True)])
+def test_engine_unet_forward_matches_golden(device, fname, name, lowres):
+    g = np.load(GOLD / fname)
+    t = lambda k: torch.from_numpy(g[k]).to(device) if k in g else None
+    ou = H.oracle_unet(name, lowres_cond=lowres, seed=int(g["seed"]))
+    pu = H.product_unet_like(ou).to(device)
+    got = pu(t("x"), t("t"), lowres_cond_img=t("lowres"), lowres_noise_times=t("t_lowres"), cond_images=t("cond"))
+    assert H.rel_l2(got, torch.from_numpy(g["y"])) < FWD_REL_L2
+
+
+def test_engine_cascade_sampler_matches_golden(device):
+    import imagen_pytorch as ip
+
+    g = np.load(GOLD / "sampler_cascade.npz")
+    seed = int(g["seed"])
+    ous = [H.oracle_unet("small1", seed=seed), H.oracle_unet("small2", lowres_cond=True, seed=seed + 1)]
+    oim = RS.Imagen(ous, image_sizes=(16, 32), timesteps=(5, 4), pred_objectives=("noise", "v"),
+                    condition_on_text=False)
+    pim = ip.Imagen([ip.Unet(**u._locals) for u in oim.unets], image_sizes=(16, 32), timesteps=(5, 4),
+                    pred_objectives=("noise", "v"), condition_on_text=False)
+    pim.load_state_dict(oim.state_dict(), strict=True)
+    pim = pim.to(device)
+    nf = RS.generator_noise_fn(seed)
+    t = lambda k: torch.from_numpy(g[k]).to(device)
+    base = pim.sample(noise_fn=nf, batch_size=1, stop_at_unet_number=1, device=device)
+    assert (base.cpu() - torch.from_numpy(g["base"])).abs().max() < SAMPLE_ABS
+    sr = pim.sample(noise_fn=nf, batch_size=1, cond_images=t("cond"), start_image_or_video=t("base"),
+                    start_at_unet_number=2, inpaint_images=t("inpaint"), inpaint_masks=t("mask"),
+                    inpaint_resample_times=2, device=device)
+    assert (sr.cpu() - torch.from_numpy(g["sr"])).abs().max() < SAMPLE_ABS
