@@ -65,6 +65,62 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, int64_t m, i
   }
 }
 
+// ---- shared epilogue.  The accumulators go through LDS so that global stores (and the residual /
+// gate reads) are 16 B per lane along n.  C/D map of the 32x32 MFMA: col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Callers end their main loop on a barrier: LDS is free.
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void store_tile(const ConvParams& p, float* lds,
+                                           f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32], int64_t m0, int n0,
+                                           int64_t M) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int TM = BM / WAVES_M / 32;
+  constexpr int TN = BN / WAVES_N / 32;
+  constexpr int C_LD = WAVES_N * 32 + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const bool vec_ok = p.out_mode != OUT_NCHW && (p.Cout & 3) == 0 && (p.ldy & 3) == 0 && (p.yoff & 3) == 0 &&
+                      (((uintptr_t)p.y) & 15) == 0 && (!p.res || ((p.ldres & 3) == 0 && (((uintptr_t)p.res) & 15) == 0)) &&
+                      (!p.gate_src || (p.ldgs & 3) == 0) && (p.out_mode != OUT_PIXSHUF || (p.Cout & 15) == 0);
+  float* Cs = lds;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rowb = (wm * TM + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Cs[(rowb + (r & 3) + 8 * (r >> 2)) * C_LD + wn * 32 + (lane & 31)] = acc[i][j][r];
+    }
+    __syncthreads();
+    constexpr int V_PER_ROW = WAVES_N * 8;
+    if (vec_ok) {
+      for (int idx = tid; idx < BM * V_PER_ROW; idx += NT) {
+        int row = idx / V_PER_ROW, c4 = idx - row * V_PER_ROW;
+        int wn_ = c4 >> 3, c = (c4 & 7) * 4;
+        int n = n0 + (wn_ * TN + j) * 32 + c;
+        int64_t m = m0 + row;
+        if (m < M && n < p.Cout) {
+          f32x4 t = *(const f32x4*)(Cs + row * C_LD + wn_ * 32 + c);
+          float v[4] = {t[0], t[1], t[2], t[3]};
+          epilogue_store<4>(p, m, n, v);
+        }
+      }
+    } else {
+      for (int idx = tid; idx < BM * WAVES_N * 32; idx += NT) {
+        int row = idx / (WAVES_N * 32), cc = idx - row * (WAVES_N * 32);
+        int wn_ = cc >> 5, c = cc & 31;
+        int n = n0 + (wn_ * TN + j) * 32 + c;
+        int64_t m = m0 + row;
+        if (m < M && n < p.Cout) {
+          float v[1] = {Cs[row * C_LD + wn_ * 32 + c]};
+          epilogue_store<1>(p, m, n, v);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 
@@ -192,50 +248,176 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
     __syncthreads();
   }
 
-  // ---- epilogue.  The accumulators go through LDS so that global stores (and the residual /
-  // gate reads) are 16-B per lane along n.  C/D map of the 32x32 MFMA: col = lane&31,
-  // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The main loop ended on a barrier, LDS is free.
-  const bool vec_ok = p.out_mode != OUT_NCHW && (p.Cout & 3) == 0 && (p.ldy & 3) == 0 && (p.yoff & 3) == 0 &&
-                      (((uintptr_t)p.y) & 15) == 0 && (!p.res || ((p.ldres & 3) == 0 && (((uintptr_t)p.res) & 15) == 0)) &&
-                      (!p.gate_src || (p.ldgs & 3) == 0) && (p.out_mode != OUT_PIXSHUF || (p.Cout & 15) == 0);
-  float* Cs = lds;
+  store_tile<BM, BN, WAVES_M, WAVES_N>(p, lds, acc, m0, n0, M);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast path (Cin % 32 == 0): operands go global -> LDS directly with `buffer_load_dwordx4 ... lds`
+// (no VGPR staging, no ds_write).  Per lane only a 32-bit byte offset is kept (fixed per tap for the
+// activations, fixed for the whole kernel for the weights); the advance along K is a SCALAR offset
+// and padding pixels / rows past the edge use an out-of-range offset (the buffer range check returns
+// 0), so a K-chunk costs no vector ALU for addressing.  LDS rows are 128 B unpadded (one
+// wave-instruction writes 1 KiB linearly = 8 rows); ds_read_b128 bank conflicts are removed by an XOR
+// swizzle applied to the SOURCE segment (lane holding LDS slot s of row r fetches 16-B segment
+// s ^ ((r>>1)&7)) and to the READ address.  Two LDS stages, static stage index (loop unrolled by 2),
+// counted vmcnt + raw s_barrier so the next chunk's DMA stays in flight across the barrier.
+// Measured on MI355X (profiles/): 113-133 TFLOP/s vs 97-116 for the register-staged kernel.
+constexpr uint32_t OOB_OFF = 0x80000000u;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist on the device side only
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int ROWS_PER_PASS = NT / 8;
+  constexpr int A_PASSES = BM / ROWS_PER_PASS;
+  constexpr int B_PASSES = BN / ROWS_PER_PASS;
+  constexpr int NLOADS = A_PASSES + B_PASSES;
+  constexpr int TM = BM / WAVES_M / 32;
+  constexpr int TN = BN / WAVES_N / 32;
+  constexpr int STAGE = (BM + BN) * BK;  // floats
+  constexpr int C_LD = WAVES_N * 32 + 4;
+  constexpr int LDS_FLOATS = 2 * STAGE > BM * C_LD ? 2 * STAGE : BM * C_LD;
+  __shared__ __attribute__((aligned(1024))) float lds[LDS_FLOATS];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int64_t M = (int64_t)p.B * p.Ho * p.Wo;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int lrow = tid >> 3;
+  const int gseg = (tid & 7) ^ ((lrow >> 1) & 7);
+
+  // activations: buffer based at the image of the tile's first pixel (keeps offsets < 2^31)
+  const int hw = p.Ho * p.Wo;
+  const int img0 = (int)(m0 / hw);
+  const int64_t img_elems = (int64_t)p.Hi * p.Wi * p.ldx;
+  const int64_t a_total = ((int64_t)p.B - img0) * img_elems * 4;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.x + (int64_t)img0 * img_elems), 0, (int)(a_total > 0x7fffffff ? 0x7fffffff : a_total), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.w, 0, (int)((int64_t)p.KH * p.KW * p.Cout * p.Cin * 4), 0x00020000);
+
+  int a_iy0[A_PASSES], a_ix0[A_PASSES];
+  int a_img[A_PASSES];  // pixel offset of the row's image relative to img0, or -1 past the edge
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int rowb = (wm * TM + i) * 32 + 4 * (lane >> 5);
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        Cs[(rowb + (r & 3) + 8 * (r >> 2)) * C_LD + wn * 32 + (lane & 31)] = acc[i][j][r];
-    }
-    __syncthreads();
-    constexpr int V_PER_ROW = WAVES_N * 8;
-    if (vec_ok) {
-      for (int idx = tid; idx < BM * V_PER_ROW; idx += NT) {
-        int row = idx / V_PER_ROW, c4 = idx - row * V_PER_ROW;
-        int wn_ = c4 >> 3, c = (c4 & 7) * 4;
-        int n = n0 + (wn_ * TN + j) * 32 + c;
-        int64_t m = m0 + row;
-        if (m < M && n < p.Cout) {
-          f32x4 t = *(const f32x4*)(Cs + row * C_LD + wn_ * 32 + c);
-          float v[4] = {t[0], t[1], t[2], t[3]};
-          epilogue_store<4>(p, m, n, v);
-        }
-      }
+  for (int q = 0; q < A_PASSES; ++q) {
+    int64_t m = m0 + lrow + q * ROWS_PER_PASS;
+    if (m < M) {
+      int b = (int)(m / hw);
+      int rem = (int)(m - (int64_t)b * hw);
+      int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_iy0[q] = oy * p.stride - p.pad;
+      a_ix0[q] = ox * p.stride - p.pad;
+      a_img[q] = (b - img0) * p.Hi * p.Wi;
     } else {
-      for (int idx = tid; idx < BM * WAVES_N * 32; idx += NT) {
-        int row = idx / (WAVES_N * 32), cc = idx - row * (WAVES_N * 32);
-        int wn_ = cc >> 5, c = cc & 31;
-        int n = n0 + (wn_ * TN + j) * 32 + c;
-        int64_t m = m0 + row;
-        if (m < M && n < p.Cout) {
-          float v[1] = {Cs[row * C_LD + wn_ * 32 + c]};
-          epilogue_store<1>(p, m, n, v);
-        }
-      }
+      a_iy0[q] = 0;
+      a_ix0[q] = 0;
+      a_img[q] = -1;
     }
-    __syncthreads();
   }
+  uint32_t voffB[B_PASSES];
+#pragma unroll
+  for (int q = 0; q < B_PASSES; ++q) {
+    int n = n0 + lrow + q * ROWS_PER_PASS;
+    voffB[q] = n < p.Cout ? (uint32_t)((n * p.Cin + gseg * 4) * 4) : OOB_OFF;
+  }
+  uint32_t voffA[A_PASSES];
+  const int chunks_per_tap = p.Cin / BK;
+  const int nchunks = p.KH * p.KW * chunks_per_tap;
+  int cur_tap = -1, cur_cc = chunks_per_tap;
+  uint32_t soffA = 0, soffB = 0;
+  const uint32_t tap_stride_b = (uint32_t)p.Cout * p.Cin * 4;
+
+  auto next_tap = [&]() {
+    ++cur_tap;
+    cur_cc = 0;
+    int kh = cur_tap / p.KW, kw = cur_tap - kh * p.KW;
+#pragma unroll
+    for (int q = 0; q < A_PASSES; ++q) {
+      int iy = a_iy0[q] + kh, ix = a_ix0[q] + kw;
+      bool ok = a_img[q] >= 0 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+      voffA[q] = ok ? (uint32_t)(((a_img[q] + iy * p.Wi + ix) * p.ldx + gseg * 4) * 4) : OOB_OFF;
+    }
+    soffA = 0;
+    soffB = (uint32_t)cur_tap * tap_stride_b;
+  };
+  auto issue = [&](float* stage_base) {  // DMA of the next K-chunk into the given stage
+    if (cur_cc == chunks_per_tap) next_tap();
+    __attribute__((address_space(3))) float* sb =
+        (__attribute__((address_space(3))) float*)(stage_base + wave * 8 * BK);
+#pragma unroll
+    for (int q = 0; q < A_PASSES; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, sb + q * ROWS_PER_PASS * BK, 16, voffA[q], soffA, 0, 0);
+#pragma unroll
+    for (int q = 0; q < B_PASSES; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, sb + BM * BK + q * ROWS_PER_PASS * BK, 16, voffB[q], soffB, 0, 0);
+    soffA += BK * 4;
+    soffB += BK * 4;
+    ++cur_cc;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31;
+  const int fsw = (frow >> 1) & 7;
+  const int khalf = lane >> 5;
+  const int a_row = (wm * TM * 32 + frow) * BK;
+  const int b_row = BM * BK + (wn * TN * 32 + frow) * BK;
+  auto compute = [&](const float* base) {
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      const int slot = ((2 * kk + khalf) ^ fsw) * 4;
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(base + a_row + i * 32 * BK + slot);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(base + b_row + j * 32 * BK + slot);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  float* const s0 = lds;
+  float* const s1 = lds + STAGE;
+  issue(s0);
+  for (int c = 0; c < nchunks; c += 2) {
+    if (c + 1 < nchunks) {
+      issue(s1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    compute(s0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (c + 1 >= nchunks) break;
+    if (c + 2 < nchunks) {
+      issue(s0);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    compute(s1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  __syncthreads();
+  store_tile<BM, BN, WAVES_M, WAVES_N>(p, lds, acc, m0, n0, M);
+#endif
 }
 
 int64_t conv_macs(const ConvParams& p) {
@@ -248,7 +430,24 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
   if (p.out_mode == OUT_PIXSHUF) KD_REQUIRE(p.Cout % 4 == 0, "pixel-shuffle needs Cout % 4 == 0");
   int64_t M = (int64_t)p.B * p.Ho * p.Wo;
   KD_REQUIRE(M > 0 && p.Cout > 0, "empty conv");
-  if (p.Cout <= 32) {
+  const int64_t w_bytes = (int64_t)p.KH * p.KW * p.Cout * p.Cin * 4;
+  // the fast kernel addresses the activations with 32-bit byte offsets relative to the image of the
+  // tile's first pixel: every image a 256-row tile can touch must lie within 2^31 bytes of it
+  const int64_t img_bytes = (int64_t)p.Hi * p.Wi * p.ldx * 4;
+  const int64_t hw_o = (int64_t)p.Ho * p.Wo;
+  const int64_t span = (hw_o % 256 == 0) ? 1 : 255 / hw_o + 2;
+  const bool fast = (p.Cin % BK) == 0 && p.Cout > 64 && M > 64 && w_bytes < 0x7fffffff &&
+                    span * img_bytes < 0x7fffffff && (((uintptr_t)p.x | (uintptr_t)p.w) & 15) == 0;
+  if (fast) {
+    const int64_t tiles256 = ((M + 255) / 256) * ((p.Cout + 127) / 128);
+    if (tiles256 >= 512) {  // enough 256x128 tiles for two rounds of the 256 CUs
+      dim3 grid((unsigned)((M + 255) / 256), (p.Cout + 127) / 128);
+      hipLaunchKernelGGL((conv_buf_kernel<256, 128, 4, 2, 2>), grid, dim3(512), 0, s, p);
+    } else {
+      dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 127) / 128);
+      hipLaunchKernelGGL((conv_buf_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, s, p);
+    }
+  } else if (p.Cout <= 32) {
     dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 31) / 32);
     hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, p);
   } else if (p.Cout <= 64) {

@@ -41,7 +41,12 @@ CONV_REL = 2e-6
     (1, 20, 20, 12, 16, 15, 1, 7, 0),
     (2, 8, 8, 132, 3, 3, 1, 1, 0),        # final conv: Cout = 3
     (1, 1, 40, 128, 512, 1, 1, 0, 0),     # token GEMM, M = 40 < tile
-    (16, 16, 16, 128, 128, 3, 1, 1, 0),   # several M tiles x 1 N tile
+    (16, 16, 16, 128, 128, 3, 1, 1, 0),   # several M tiles x 1 N tile (buffer-DMA fast path, 128x128 tiles)
+    (3, 17, 13, 64, 200, 3, 1, 1, 1),     # fast path, ragged M and N edges, SiLU
+    (2, 32, 32, 96, 136, 2, 2, 0, 0),     # fast path, stride 2
+    (5, 8, 8, 32, 72, 3, 1, 1, 0),        # fast path, tiles span several small images
+    (8, 128, 128, 32, 128, 3, 1, 1, 0),   # fast path, 256x128 tiles / 8 waves
+    (2, 64, 64, 160, 128, 1, 1, 0, 2),    # fast path, 1x1 + GELU
 ])
 def test_conv_igemm(lib, device, B, H, W, Cin, Cout, K, stride, pad, act):
     E = _E()
