@@ -103,6 +103,8 @@ int launch_attention(const float* q, int ldq, const float* null_k, const float* 
 // y[m][n] = act( sum_k f(x[m][k]) * w[n][k] + bias[n] ) for small M (<= 64); in_act applied to x
 int launch_linear_skinny(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int M,
                          int K, int N, int in_act, int act, hipStream_t s);
+int launch_linear_skinny_valu(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int M,
+                              int K, int N, int in_act, int act, hipStream_t s);
 // GlobalContext: logits[b][p] = x[b][p][:]·wk + bk ; pooled[b][c] = sum_p softmax_p(logits) x[b][p][c]
 int launch_gca_pool(const float* x, const float* wk, const float* bk, float* logits, float* pooled,
                     float* scratch, int B, int HW, int C, hipStream_t s);

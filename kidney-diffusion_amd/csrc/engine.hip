@@ -323,7 +323,7 @@ struct Builder {
     kd_unet* uu = u;
     emit([=](hipStream_t s) {
       return launch_linear_skinny(uu->P(x_off), ldx, w, bias, uu->P(y_off), ldy, M, K, N, in_act, act, s);
-    });
+    }, "skinny M" + std::to_string(M) + " K" + std::to_string(K) + " N" + std::to_string(N), (int64_t)M * K * N);
     u->macs += (int64_t)M * K * N;
   }
 
@@ -335,7 +335,7 @@ struct Builder {
     kd_unet* uu = u;
     emit([=](hipStream_t s) {
       return launch_layernorm(uu->P(xo), g, beta, hr ? uu->P(ro) : nullptr, uu->P(yo), rows, C, 1e-5f, s);
-    });
+    }, "ln rows" + std::to_string(rows) + " C" + std::to_string(C));
     return y;
   }
 
@@ -352,7 +352,7 @@ struct Builder {
     emit([=](hipStream_t s) {
       if (launch_gn_stats(uu->P(xo), C, uu->P(so), (double*)uu->P(po), Bx, HW, C, G, 1e-5f, s)) return 1;
       return launch_gn_apply_silu(uu->P(xo), C, uu->P(so), gamma, beta, ss, ld_ss, uu->P(yo), Bx, HW, C, G, s);
-    });
+    }, "gn HW" + std::to_string(HW) + " C" + std::to_string(C));
     return y;
   }
 
@@ -375,7 +375,7 @@ struct Builder {
         KVSeg s0{uu->P(kvo), uu->P(kvo) + inner, 2 * inner, Nc};
         KVSeg s1{nullptr, nullptr, 0, 0};
         return launch_attention(uu->P(qo), inner, nkv, nkv + D, s0, s1, uu->P(oo), inner, Bx, Nq, H, H, scale, s);
-      });
+      }, "xattn Nq" + std::to_string(Nq) + " Nk" + std::to_string(Nc + 1));
       u->macs += (int64_t)Bx * H * Nq * (Nc + 1) * D * 2;
     }
     free(q);
@@ -415,7 +415,7 @@ struct Builder {
         if (has_ctx) s0 = KVSeg{uu->P(co), uu->P(co) + D, 2 * D, Nc};
         KVSeg s1{uu->P(kvo), uu->P(kvo) + D, 2 * D, N};
         return launch_attention(uu->P(qo), inner, nkv, nkv + D, s0, s1, uu->P(oo), inner, Bx, N, H, 1, scale, s);
-      });
+      }, "attn N" + std::to_string(N));
       u->macs += (int64_t)Bx * H * N * (N + Nc + 1) * D * 2;
     }
     free(q);
@@ -455,7 +455,7 @@ struct Builder {
     kd_unet* uu = u;
     emit([=](hipStream_t s) {
       return launch_gca_pool(uu->P(ho), wk, bk, uu->P(lo), uu->P(po), uu->P(so), Bx, HW, C, s);
-    });
+    }, "gca_pool HW" + std::to_string(HW) + " C" + std::to_string(C));
     u->macs += (int64_t)Bx * HW * C * 2;
     free(logits);
     free(scratch);
@@ -498,7 +498,7 @@ struct Builder {
         if (launch_gn_stats(uu->P(xo), C, uu->P(so), (double*)uu->P(po), Bx, HW, C, G, 1e-5f, s)) return 1;
         const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
         return launch_gn_apply_silu(uu->P(xo), C, uu->P(so), gamma, beta, ssp, ld, uu->P(yo), Bx, HW, C, G, s);
-      });
+      }, "gn HW" + std::to_string(HW) + " C" + std::to_string(C));
     }
     bool has_res_conv = has(pre + ".res_conv.weight");
     ConvOpt o2;
@@ -524,7 +524,7 @@ struct Builder {
         kd_unet* uu = u;
         emit([=](hipStream_t s) {
           return launch_gate_add(uu->P(ao), uu->P(go), uu->P(ro), uu->P(yo), Bx, HW, dim_out, s);
-        });
+        }, "gate_add HW" + std::to_string(HW) + " C" + std::to_string(dim_out));
       }
       free(gate);
     } else {  // res_conv without gca: out = conv1x1(x) + h2
@@ -560,7 +560,8 @@ struct Builder {
     int Ca = x.C, Cb = skip.C;
     int64_t rows = x.rows();
     kd_unet* uu = u;
-    emit([=](hipStream_t s) { return launch_concat2(uu->P(ao), Ca, uu->P(bo), Cb, scale, uu->P(yo), rows, s); });
+    emit([=](hipStream_t s) { return launch_concat2(uu->P(ao), Ca, uu->P(bo), Cb, scale, uu->P(yo), rows, s); },
+         "concat rows" + std::to_string(rows) + " C" + std::to_string(Ca + Cb));
     return y;
   }
 

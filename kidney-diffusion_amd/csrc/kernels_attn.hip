@@ -219,108 +219,11 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restr
   }
 }
 
-int launch_linear_skinny(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int M,
-                         int K, int N, int in_act, int act, hipStream_t s) {
+int launch_linear_skinny_valu(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int M,
+                              int K, int N, int in_act, int act, hipStream_t s) {
   KD_REQUIRE(M > 0 && N > 0 && K > 0, "skinny linear: empty");
   dim3 grid((N + 4 * SK_NW - 1) / (4 * SK_NW), (M + SK_M - 1) / SK_M);
   hipLaunchKernelGGL(linear_skinny_kernel, grid, dim3(256), 0, s, x, ldx, w, bias, y, ldy, M, K, N, in_act, act);
-  KD_HIP_CHECK(hipGetLastError());
-  return 0;
-}
-
-// ------------------------------------------------------------------------- GlobalContext pooling
-// logits[b][p] = x[b][p][:]·wk + bk ; w = softmax_p(logits) ; pooled[b][c] = sum_p w[p] x[b][p][c]
-__global__ __launch_bounds__(256) void gca_logits_kernel(const float* __restrict__ x, const float* __restrict__ wk,
-                                                         const float* __restrict__ bk, float* __restrict__ logits,
-                                                         int64_t rows, int C) {
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int lane = threadIdx.x & 63;
-  const float* xr = x + row * C;
-  float s = 0.f;
-  for (int c4 = lane; c4 < (C >> 2); c4 += 64) {
-    f32x4 v = *(const f32x4*)(xr + c4 * 4);
-    f32x4 ww = *(const f32x4*)(wk + c4 * 4);
-    s += (v[0] * ww[0] + v[1] * ww[1]) + (v[2] * ww[2] + v[3] * ww[3]);
-  }
-  s = wave_sum(s);
-  if (lane == 0) logits[row] = s + bk[0];
-}
-
-// one block per b: max and sum(exp) over HW -> ms[b] = {max, 1/sum}
-__global__ __launch_bounds__(256) void gca_softmax_stats_kernel(const float* __restrict__ logits,
-                                                                float* __restrict__ ms, int HW) {
-  const int b = blockIdx.x;
-  const float* l = logits + (int64_t)b * HW;
-  __shared__ float red[4];
-  float m = -INFINITY;
-  for (int i = threadIdx.x; i < HW; i += 256) m = fmaxf(m, l[i]);
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
-  float s = 0.f;
-  for (int i = threadIdx.x; i < HW; i += 256) s += expf(l[i] - m);
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    ms[b * 2] = m;
-    ms[b * 2 + 1] = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
-  }
-}
-
-constexpr int GCA_ROWS = 128;
-// grid (chunks, B): partial[b][chunk][c] = sum_{p in chunk} softmax_w[p] * x[b][p][c]
-__global__ __launch_bounds__(256) void gca_pool_partial_kernel(const float* __restrict__ x,
-                                                               const float* __restrict__ logits,
-                                                               const float* __restrict__ ms,
-                                                               float* __restrict__ partial, int HW, int C) {
-  const int b = blockIdx.y, chunk = blockIdx.x;
-  const int p0 = chunk * GCA_ROWS, p1 = min(HW, p0 + GCA_ROWS);
-  __shared__ float wgt[GCA_ROWS];
-  const float m = ms[b * 2], inv = ms[b * 2 + 1];
-  for (int i = threadIdx.x; i < p1 - p0; i += 256) wgt[i] = expf(logits[(int64_t)b * HW + p0 + i] - m) * inv;
-  __syncthreads();
-  const int C4 = C >> 2;
-  for (int c4 = threadIdx.x; c4 < C4; c4 += 256) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int p = p0; p < p1; ++p) {
-      f32x4 v = *(const f32x4*)(x + ((int64_t)b * HW + p) * C + c4 * 4);
-      acc += v * wgt[p - p0];
-    }
-    *(f32x4*)(partial + (((int64_t)b * gridDim.x + chunk) * C4 + c4) * 4) = acc;
-  }
-}
-__global__ void gca_pool_reduce_kernel(const float* __restrict__ partial, float* __restrict__ pooled, int chunks,
-                                       int C, int total) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;  // b*C + c
-  if (i >= total) return;
-  int b = i / C, c = i - b * C;
-  float s = 0.f;
-  for (int k = 0; k < chunks; ++k) s += partial[((int64_t)b * chunks + k) * C + c];
-  pooled[i] = s;
-}
-
-size_t gca_scratch_floats(int B, int HW, int C) {
-  int chunks = (HW + GCA_ROWS - 1) / GCA_ROWS;
-  return (size_t)B * 2 + (size_t)B * chunks * C;
-}
-
-int launch_gca_pool(const float* x, const float* wk, const float* bk, float* logits, float* pooled,
-                    float* scratch, int B, int HW, int C, hipStream_t s) {
-  KD_REQUIRE(C % 4 == 0, "gca needs C % 4 == 0");
-  int64_t rows = (int64_t)B * HW;
-  float* ms = scratch;
-  float* partial = scratch + (size_t)B * 2;
-  int chunks = (HW + GCA_ROWS - 1) / GCA_ROWS;
-  hipLaunchKernelGGL(gca_logits_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, wk, bk, logits, rows,
-                     C);
-  hipLaunchKernelGGL(gca_softmax_stats_kernel, dim3(B), dim3(256), 0, s, logits, ms, HW);
-  hipLaunchKernelGGL(gca_pool_partial_kernel, dim3(chunks, B), dim3(256), 0, s, x, logits, ms, partial, HW, C);
-  hipLaunchKernelGGL(gca_pool_reduce_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, partial, pooled, chunks,
-                     C, B * C);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

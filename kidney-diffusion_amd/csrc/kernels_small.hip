@@ -1,0 +1,245 @@
+// Small-M linear layers on the matrix cores and the single-pass GlobalContext pooling.
+#include "common.h"
+
+namespace kd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_s(float v, int act) {
+  if (act == ACT_SILU) return v / (1.0f + expf(-v));
+  if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------- skinny linear, M <= 32 per pass
+// y[m][n] = act( sum_k in_act(x[m][k]) * w[n][k] + bias[n] ).  These layers (time MLPs: 113 MB of
+// weights per step; GlobalContext FCs; time-token projections) are weight-bandwidth bound: each
+// wave owns 32 output columns and streams their weight rows straight from HBM into MFMA A-operand
+// registers (lane (i,h) holds w[n0+i][k+4h..k+4h+3]); x (<= 32 rows, L2-resident) is the B operand.
+// v_mfma_f32_32x32x2_f32 keeps the arithmetic exact fp32 and leaves the VALU to the activation.
+constexpr int SKM_UNROLL = 8;
+
+__global__ __launch_bounds__(64) void linear_skinny_mfma_kernel(const float* __restrict__ x, int ldx,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ y, int ldy, int M, int K, int N,
+                                                               int in_act, int act) {
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int n = min(n0 + i, N - 1);  // clamped: rows past N are computed and dropped
+  const int m = m0 + i;
+  const bool m_ok = m < M;
+  const float* wp = w + (int64_t)n * K + 4 * h;
+  const float* xp = x + (int64_t)(m_ok ? m : 0) * ldx + 4 * h;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += 8 * SKM_UNROLL) {
+    f32x4 a[SKM_UNROLL], b[SKM_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SKM_UNROLL; ++u) {
+      int k = k0 + 8 * u + 4 * h;
+      bool ok = k < K;  // K % 4 == 0, so a 4-wide slice is either fully inside or outside
+      a[u] = ok ? *(const f32x4*)(wp + k0 + 8 * u) : z;
+      b[u] = (ok && m_ok) ? *(const f32x4*)(xp + k0 + 8 * u) : z;
+    }
+#pragma unroll
+    for (int u = 0; u < SKM_UNROLL; ++u) {
+      if (in_act != ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[u][e] = act_s(b[u][e], in_act);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][s], b[u][s], acc, 0, 0, 0);
+    }
+  }
+  // D[i=n][j=m]: col = lane&31 = m, row = (r&3) + 8*(r>>2) + 4*h
+  if (!m_ok) return;
+  float* yr = y + (int64_t)m * ldy;
+  const bool vec = (ldy & 3) == 0 && (((uintptr_t)y) & 15) == 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int nb = n0 + 8 * g + 4 * h;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int nn = nb + e;
+      v[e] = act_s(acc[4 * g + e] + ((bias && nn < N) ? bias[nn] : 0.f), act);
+    }
+    if (vec && nb + 3 < N) {
+      f32x4 o = {v[0], v[1], v[2], v[3]};
+      *(f32x4*)(yr + nb) = o;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (nb + e < N) yr[nb + e] = v[e];
+    }
+  }
+}
+
+int launch_linear_skinny(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int M,
+                         int K, int N, int in_act, int act, hipStream_t s) {
+  KD_REQUIRE(M > 0 && N > 0 && K > 0, "skinny linear: empty");
+  const bool mfma_ok = (K & 3) == 0 && (ldx & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)w) & 15) == 0;
+  if (!mfma_ok) return launch_linear_skinny_valu(x, ldx, w, bias, y, ldy, M, K, N, in_act, act, s);
+  dim3 grid((N + 31) / 32, (M + 31) / 32);
+  hipLaunchKernelGGL(linear_skinny_mfma_kernel, grid, dim3(64), 0, s, x, ldx, w, bias, y, ldy, M, K, N, in_act, act);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------- GlobalContext pooling, single pass
+// logits[p] = x[p][:]·wk + bk ; pooled[c] = sum_p softmax_p(logits) x[p][c]   (per batch element)
+// One read of x: every wave keeps a running (max, sum, weighted channel sums) over its rows (online
+// softmax), waves are merged through LDS, blocks through a small partial buffer.
+constexpr int GCA_ROWS = 256;   // pixels per block
+constexpr int GCA_MAXT = 8;     // float4 slices per lane: C <= 2048
+constexpr int GCA_U = 4;        // rows in flight per wave
+
+// T float4 slices per lane; RPW rows per wave-instruction (2 when a row is only 32 float4 wide)
+template <int T, int RPW>
+__global__ __launch_bounds__(256) void gca_partial_kernel(const float* __restrict__ x, const float* __restrict__ wk,
+                                                          const float* __restrict__ bk, float* __restrict__ part,
+                                                          int HW, int C) {
+  extern __shared__ float sm[];  // [4][C] + [4][2]
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int LPR = 64 / RPW;
+  const int sub = RPW == 2 ? (lane >> 5) : 0;
+  const int li = RPW == 2 ? (lane & 31) : lane;
+  const int C4 = C >> 2;
+  const int p0 = chunk * GCA_ROWS, p1 = min(HW, p0 + GCA_ROWS);
+  f32x4 wv[T], acc[T];
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    int c4 = li + LPR * t;
+    wv[t] = c4 < C4 ? *(const f32x4*)(wk + c4 * 4) : z;
+    acc[t] = z;
+  }
+  const float bias = bk[0];
+  float mrun = -INFINITY, lrun = 0.f;
+  const int stride = 4 * RPW;
+  for (int pb = p0 + wave * RPW + sub; pb < p1; pb += stride * GCA_U) {
+    f32x4 xv[GCA_U][T];
+#pragma unroll
+    for (int u = 0; u < GCA_U; ++u) {
+      const int p = pb + u * stride;
+      const float* xr = x + ((int64_t)b * HW + (p < p1 ? p : p0)) * C;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        int c4 = li + LPR * t;
+        xv[u][t] = c4 < C4 ? *(const f32x4*)(xr + c4 * 4) : z;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GCA_U; ++u) {
+      float d = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        d += (xv[u][t][0] * wv[t][0] + xv[u][t][1] * wv[t][1]) + (xv[u][t][2] * wv[t][2] + xv[u][t][3] * wv[t][3]);
+#pragma unroll
+      for (int off = LPR / 2; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+      if (pb + u * stride < p1) {  // uniform within the row's lanes
+        const float logit = d + bias;
+        const float mnew = fmaxf(mrun, logit);
+        const float corr = expf(mrun - mnew), pw = expf(logit - mnew);
+        lrun = lrun * corr + pw;
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = acc[t] * corr + xv[u][t] * pw;
+        mrun = mnew;
+      }
+    }
+  }
+  if (RPW == 2) {  // merge the two half-wave states
+    const float mo = __shfl_xor(mrun, 32, 64), lo = __shfl_xor(lrun, 32, 64);
+    const float mn = fmaxf(mrun, mo);
+    const float e1 = mrun == -INFINITY ? 0.f : expf(mrun - mn), e2 = mo == -INFINITY ? 0.f : expf(mo - mn);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      f32x4 ao;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ao[e] = __shfl_xor(acc[t][e], 32, 64);
+      acc[t] = acc[t] * e1 + ao * e2;
+    }
+    lrun = lrun * e1 + lo * e2;
+    mrun = mn;
+  }
+  // merge the four waves
+  float* sacc = sm;          // [4][C]
+  float* sml = sm + 4 * C;   // [4][2]
+  if (lane == 0) {
+    sml[wave * 2] = mrun;
+    sml[wave * 2 + 1] = lrun;
+  }
+  if (sub == 0) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      int c4 = li + LPR * t;
+      if (c4 < C4) *(f32x4*)(sacc + wave * C + c4 * 4) = acc[t];
+    }
+  }
+  __syncthreads();
+  float mb = fmaxf(fmaxf(sml[0], sml[2]), fmaxf(sml[4], sml[6]));
+  float sc[4], lb = 0.f;
+#pragma unroll
+  for (int wv_ = 0; wv_ < 4; ++wv_) {
+    sc[wv_] = sml[wv_ * 2] == -INFINITY ? 0.f : expf(sml[wv_ * 2] - mb);
+    lb += sml[wv_ * 2 + 1] * sc[wv_];
+  }
+  float* out = part + ((int64_t)b * nchunks + chunk) * (C + 2);
+  for (int c = threadIdx.x; c < C; c += 256)
+    out[2 + c] = (sacc[c] * sc[0] + sacc[C + c] * sc[1]) + (sacc[2 * C + c] * sc[2] + sacc[3 * C + c] * sc[3]);
+  if (threadIdx.x == 0) {
+    out[0] = mb;
+    out[1] = lb;
+  }
+}
+
+__global__ __launch_bounds__(256) void gca_combine_kernel(const float* __restrict__ part, float* __restrict__ pooled,
+                                                          int nchunks, int C) {
+  const int b = blockIdx.x;
+  const float* pb = part + (int64_t)b * nchunks * (C + 2);
+  float mg = -INFINITY;
+  for (int i = 0; i < nchunks; ++i) mg = fmaxf(mg, pb[(int64_t)i * (C + 2)]);
+  float l = 0.f;
+  for (int i = 0; i < nchunks; ++i) l += pb[(int64_t)i * (C + 2) + 1] * expf(pb[(int64_t)i * (C + 2)] - mg);
+  const float inv = 1.0f / l;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int i = 0; i < nchunks; ++i) s += pb[(int64_t)i * (C + 2) + 2 + c] * expf(pb[(int64_t)i * (C + 2)] - mg);
+    pooled[(int64_t)b * C + c] = s * inv;
+  }
+}
+
+size_t gca_scratch_floats(int B, int HW, int C) {
+  int chunks = (HW + GCA_ROWS - 1) / GCA_ROWS;
+  return (size_t)B * chunks * (C + 2);
+}
+
+int launch_gca_pool(const float* x, const float* wk, const float* bk, float* /*logits (unused)*/, float* pooled,
+                    float* scratch, int B, int HW, int C, hipStream_t s) {
+  KD_REQUIRE(C % 4 == 0 && C <= 64 * 4 * GCA_MAXT, "gca needs C % 4 == 0 and C <= 2048");
+  int chunks = (HW + GCA_ROWS - 1) / GCA_ROWS;
+  size_t smem = (size_t)(4 * C + 8) * sizeof(float);
+  const int C4 = C / 4;
+  dim3 grid(chunks, B), blk(256);
+  if (C4 == 32) hipLaunchKernelGGL((gca_partial_kernel<1, 2>), grid, blk, smem, s, x, wk, bk, scratch, HW, C);
+  else if (C4 <= 64) hipLaunchKernelGGL((gca_partial_kernel<1, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C);
+  else if (C4 <= 128) hipLaunchKernelGGL((gca_partial_kernel<2, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C);
+  else if (C4 <= 256) hipLaunchKernelGGL((gca_partial_kernel<4, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C);
+  else hipLaunchKernelGGL((gca_partial_kernel<8, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C);
+  hipLaunchKernelGGL(gca_combine_kernel, dim3(B), dim3(256), 0, s, scratch, pooled, chunks, C);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace kd

@@ -17,6 +17,6 @@ print('total us',tot)
 agg={}
 for r in rows:
     k=r[1]; a=agg.setdefault(k,[0,0.0,0]); a[0]+=1; a[1]+=float(r[3]); a[2]+=int(r[2])
-for k,(n,us,macs) in sorted(agg.items(), key=lambda kv:-kv[1][1])[:45]:
+for k,(n,us,macs) in sorted(agg.items(), key=lambda kv:-kv[1][1])[:200]:
     tf = 2*macs/us/1e6 if us>0 else 0
     print(f"{us/tot*100:6.2f}% n={n:3d} us={us:9.1f} TF/s={tf:7.1f}  {k}")
