@@ -687,7 +687,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
 constexpr uint32_t OOB_OFF = 0x80000000u;
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(ConvParams p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bufx_kernel(ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist on the device side only
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int ROWS_PER_PASS = NT / 8;
@@ -809,6 +809,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
     }
   };
 
+  if (p.act > 0) {  // EXPERIMENT: de-phase the two co-resident workgroups of a CU
+    const int dec = (int)(__builtin_amdgcn_s_getreg(0x1804) & 1u);  // HW_ID.wave_id bit 0 (per wave)
+    if (dec)
+      for (int i = 0; i < p.act; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   float* const s0 = lds;
   float* const s1 = lds + STAGE;
   issue(s0);
@@ -871,7 +876,7 @@ template <int BM, int BN, int WM, int WN, int MINW>
 static void launch_buf(const ConvParams& p, hipStream_t s) {
   int64_t M = (int64_t)p.B * p.Ho * p.Wo;
   dim3 grid((unsigned)((M + BM - 1) / BM), (p.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL((conv_buf_kernel<BM, BN, WM, WN, MINW>), grid, dim3(WM * WN * 64), 0, s, p);
+  hipLaunchKernelGGL((conv_bufx_kernel<BM, BN, WM, WN, MINW>), grid, dim3(WM * WN * 64), 0, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) fprintf(stderr, "conv_buf launch: %s\n", hipGetErrorString(e));
 }
@@ -939,6 +944,9 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
       case 19: launch_pipe<128, 128, 2, 2>(p, zeros, 0); break;        // pipelined, 128x128, 4 waves
       case 20: launch_buf<128, 128, 2, 2, 2>(p, 0); break;             // buffer-DMA, scalar addressing, 2 blocks/CU
       case 21: launch_buf<256, 128, 4, 2, 2>(p, 0); break;             // same, 256x128 / 8 waves
+      case 22: { ConvParams q = p; q.act = 1; launch_buf<128, 128, 2, 2, 2>(q, 0); } break;  // stagger 1k cycles
+      case 23: { ConvParams q = p; q.act = 2; launch_buf<128, 128, 2, 2, 2>(q, 0); } break;  // stagger 2k
+      case 24: { ConvParams q = p; q.act = 4; launch_buf<128, 128, 2, 2, 2>(q, 0); } break;  // stagger 4k
       default: break;
     }
   };
