@@ -40,6 +40,7 @@ struct ConvParams {
   int B, Hi, Wi, Cin, ldx;
   int Ho, Wo, Cout;
   int KH, KW, stride, pad;
+  int rr_cin;  // > 0: row-run mode, channels per input pixel (then KW == 1 and Cin == kernel_width * rr_cin)
   int act;
   const float* res;       // y += res[m][n]   (row stride ldres)
   int ldres;
@@ -56,6 +57,8 @@ int64_t conv_macs(const ConvParams& p);
 // weight re-packing (device→device)
 // OIHW -> [tap][O][Ipad] (zero for i >= I)
 int launch_pack_oihw(const float* w_oihw, float* w_packed, int O, int I, int Ipad, int KH, int KW, hipStream_t s);
+// OIHW -> row-run layout [KH][O][KW*Ipad] (zero for i >= I)
+int launch_pack_oihw_rowrun(const float* w_oihw, float* w_packed, int O, int I, int Ipad, int KH, int KW, hipStream_t s);
 // Downsample conv1x1 over pixel-unshuffled input ([O][4C], k = c*4+s1*2+s2) -> [tap=s1*2+s2][O][C]
 int launch_pack_unshuffle(const float* w, float* w_packed, int O, int C, hipStream_t s);
 // PixelShuffle conv1x1 ([4Co][I], n = c*4+i*2+j) -> rows n' = (i*2+j)*Co + c ; same for bias

@@ -211,6 +211,13 @@ struct Builder {
     return dst;
   }
 
+  const float* pack_conv_rowrun(const std::string& n, int O, int I, int Ipad, int K) {
+    const float* src = raw(n, (int64_t)O * I * K * K);
+    float* dst = u->wpool.alloc((size_t)O * Ipad * K * K);
+    KD_THROW_IF(launch_pack_oihw_rowrun(src, dst, O, I, Ipad, K, K, 0));
+    return dst;
+  }
+
   // ---- activations
   T alloc(int b, int h, int w, int c) {
     T t;
@@ -255,6 +262,7 @@ struct Builder {
     int yoff = 0;
     int cin_logical = -1;
     bool out_external = false;  // OUT_NCHW into u->out
+    bool rowrun = false;        // small-Cin wide-window conv: weights from pack_conv_rowrun
   };
   T conv(const T& x, const float* w, const float* bias, int Cout, int K, int stride, int pad, const ConvOpt& o) {
     int Ho = (x.H + 2 * pad - K) / stride + 1, Wo = (x.W + 2 * pad - K) / stride + 1;
@@ -274,6 +282,11 @@ struct Builder {
     p.B = x.B; p.Hi = x.H; p.Wi = x.W; p.Cin = x.C; p.ldx = x.C;
     p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
     p.KH = K; p.KW = K; p.stride = stride; p.pad = pad;
+    if (o.rowrun) {  // weights packed [KH][Cout][KW*C]: a kernel row is one contiguous K run (kernels_conv.hip)
+      p.KW = 1;
+      p.Cin = K * x.C;
+      p.rr_cin = x.C;
+    }
     p.act = o.act; p.out_mode = o.out_mode;
     p.ldy = (o.out_mode == OUT_NHWC || o.out_mode == OUT_PIXSHUF) ? y.C : 0;
     p.yoff = o.yoff;

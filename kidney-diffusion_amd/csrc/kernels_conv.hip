@@ -187,12 +187,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
     int c0 = (chunk - tap * chunks_per_tap) * BK + seg * 4;
     int kh = tap / p.KW, kw = tap - kh * p.KW;
     bool c_ok = c0 < p.Cin;
+    // row-run mode (rr_cin > 0): one "tap" is a whole kernel ROW; its K range is the contiguous run of
+    // KW*rr_cin floats that starts at input pixel (iy, ox*stride - pad) - NHWC keeps the pixels of a
+    // row adjacent - so small-Cin wide-window convs (the k = 7 / 15 init convs over 12 channels) fill
+    // their 32-wide K chunks instead of wasting 20 of 32 lanes per tap.  Validity is per 16-B segment.
+    const int kwp = p.rr_cin > 0 ? c0 / p.rr_cin : kw;
 #pragma unroll
     for (int q = 0; q < A_PASSES; ++q) {
-      int iy = a_iy0[q] + kh, ix = a_ix0[q] + kw;
+      int iy = a_iy0[q] + kh, ix = a_ix0[q] + kwp;
       bool ok = c_ok && a_img[q] >= 0 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *(const f32x4*)(p.x + (a_img[q] + (int64_t)iy * p.Wi + ix) * p.ldx + c0);
+      const int ixb = p.rr_cin > 0 ? a_ix0[q] : ix;
+      if (ok) v = *(const f32x4*)(p.x + (a_img[q] + (int64_t)iy * p.Wi + ixb) * p.ldx + c0);
       ra[q] = v;
     }
 #pragma unroll
@@ -436,7 +442,7 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
   const int64_t img_bytes = (int64_t)p.Hi * p.Wi * p.ldx * 4;
   const int64_t hw_o = (int64_t)p.Ho * p.Wo;
   const int64_t span = (hw_o % 256 == 0) ? 1 : 255 / hw_o + 2;
-  const bool fast = (p.Cin % BK) == 0 && p.Cout > 64 && M > 64 && w_bytes < 0x7fffffff &&
+  const bool fast = p.rr_cin == 0 && (p.Cin % BK) == 0 && p.Cout > 64 && M > 64 && w_bytes < 0x7fffffff &&
                     span * img_bytes < 0x7fffffff && (((uintptr_t)p.x | (uintptr_t)p.w) & 15) == 0;
   if (fast) {
     const int64_t tiles256 = ((M + 255) / 256) * ((p.Cout + 127) / 128);
@@ -482,6 +488,29 @@ int launch_pack_oihw(const float* w, float* out, int O, int Ireal, int I, int KH
   int64_t total = (int64_t)O * I * KH * KW;
   int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_oihw_kernel, dim3(blocks), dim3(256), 0, s, w, out, O, Ireal, I, KH, KW);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void pack_oihw_rowrun_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int Ireal, int I,
+                                        int KH, int KW) {
+  int64_t total = (int64_t)O * I * KH * KW;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    // out index: ((kh*O + o)*KW + kw)*I + i
+    int i = (int)(idx % I);
+    int64_t t = idx / I;
+    int kw = (int)(t % KW);
+    t /= KW;
+    int o = (int)(t % O);
+    int kh = (int)(t / O);
+    out[idx] = i < Ireal ? w[(((int64_t)o * Ireal + i) * KH + kh) * KW + kw] : 0.f;
+  }
+}
+int launch_pack_oihw_rowrun(const float* w, float* out, int O, int Ireal, int I, int KH, int KW, hipStream_t s) {
+  int64_t total = (int64_t)O * I * KH * KW;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_oihw_rowrun_kernel, dim3(blocks), dim3(256), 0, s, w, out, O, Ireal, I, KH, KW);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

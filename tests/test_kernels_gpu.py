@@ -47,6 +47,9 @@ CONV_REL = 2e-6
     (5, 8, 8, 32, 72, 3, 1, 1, 0),        # fast path, tiles span several small images
     (8, 128, 128, 32, 128, 3, 1, 1, 0),   # fast path, 256x128 tiles / 8 waves
     (2, 64, 64, 160, 128, 1, 1, 0, 2),    # fast path, 1x1 + GELU
+    (2, 20, 24, 12, 32, 15, 1, 7, 0x100),  # row-run K layout (init conv k=15 over 12 padded channels)
+    (1, 33, 17, 12, 16, 7, 1, 3, 0x100),   # row-run, k=7, ragged image
+    (3, 16, 16, 8, 64, 3, 1, 1, 0x101),    # row-run, k=3, SiLU
 ])
 def test_conv_igemm(lib, device, B, H, W, Cin, Cout, K, stride, pad, act):
     E = _E()
@@ -55,9 +58,9 @@ def test_conv_igemm(lib, device, B, H, W, Cin, Cout, K, stride, pad, act):
     b = torch.randn(Cout, generator=g(3))
     ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad)
     ref32 = F.conv2d(x, w, b, stride=stride, padding=pad)
-    if act == 1:
+    if act & 0xff == 1:
         ref, ref32 = F.silu(ref), F.silu(ref32)
-    elif act == 2:
+    elif act & 0xff == 2:
         ref, ref32 = F.gelu(ref), F.gelu(ref32)
     xd = x.permute(0, 2, 3, 1).contiguous().to(device)
     Ho, Wo = ref.shape[-2:]
