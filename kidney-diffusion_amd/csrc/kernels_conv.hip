@@ -442,16 +442,19 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
   const int64_t img_bytes = (int64_t)p.Hi * p.Wi * p.ldx * 4;
   const int64_t hw_o = (int64_t)p.Ho * p.Wo;
   const int64_t span = (hw_o % 256 == 0) ? 1 : 255 / hw_o + 2;
-  const bool fast = p.rr_cin == 0 && (p.Cin % BK) == 0 && p.Cout > 64 && M > 64 && w_bytes < 0x7fffffff &&
+  const bool fast = p.rr_cin == 0 && (p.Cin % BK) == 0 && p.Cout > 32 && M > 64 && w_bytes < 0x7fffffff &&
                     span * img_bytes < 0x7fffffff && (((uintptr_t)p.x | (uintptr_t)p.w) & 15) == 0;
   if (fast) {
     const int64_t tiles256 = ((M + 255) / 256) * ((p.Cout + 127) / 128);
     if (tiles256 >= 512) {  // enough 256x128 tiles for two rounds of the 256 CUs
       dim3 grid((unsigned)((M + 255) / 256), (p.Cout + 127) / 128);
       hipLaunchKernelGGL((conv_buf_kernel<256, 128, 4, 2, 2>), grid, dim3(512), 0, s, p);
-    } else {
+    } else if (((M + 127) / 128) * ((p.Cout + 127) / 128) >= 512) {
       dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 127) / 128);
       hipLaunchKernelGGL((conv_buf_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, s, p);
+    } else {  // few tiles (deep 16x16 levels, attention projections): 128x64 tiles, 3 workgroups per CU
+      dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 63) / 64);
+      hipLaunchKernelGGL((conv_buf_kernel<128, 64, 2, 2, 3>), grid, dim3(256), 0, s, p);
     }
   } else if (p.Cout <= 32) {
     dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 31) / 32);

@@ -944,6 +944,9 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
       case 19: launch_pipe<128, 128, 2, 2>(p, zeros, 0); break;        // pipelined, 128x128, 4 waves
       case 20: launch_buf<128, 128, 2, 2, 2>(p, 0); break;             // buffer-DMA, scalar addressing, 2 blocks/CU
       case 21: launch_buf<256, 128, 4, 2, 2>(p, 0); break;             // same, 256x128 / 8 waves
+      case 25: launch_buf<128, 64, 2, 2, 3>(p, 0); break;              // 128x64 tiles, 3 blocks/CU
+      case 26: launch_buf<64, 128, 2, 2, 3>(p, 0); break;              // 64x128 tiles
+      case 27: launch_buf<128, 64, 4, 1, 3>(p, 0); break;              // 128x64, waves 4x1
       case 22: { ConvParams q = p; q.act = 1; launch_buf<128, 128, 2, 2, 2>(q, 0); } break;  // stagger 1k cycles
       case 23: { ConvParams q = p; q.act = 2; launch_buf<128, 128, 2, 2, 2>(q, 0); } break;  // stagger 2k
       case 24: { ConvParams q = p; q.act = 4; launch_buf<128, 128, 2, 2, 2>(q, 0); } break;  // stagger 4k
