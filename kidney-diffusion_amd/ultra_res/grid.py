@@ -1,0 +1,190 @@
+"""Ultra-res outpainting grid: patch geometry, wavefront order, inpaint-tensor assembly and canvas
+stitch — the host-side logic of the reference's patch driver, restated without its queue/process
+machinery so that it can be scheduled over `torch.distributed` ranks (see `distributed.py`).
+
+Reference being mirrored (jameshball/kidney-diffusion):
+  geometry            sample_ultra_res.py:273-280 (get_patch_width), :304-314 (grid size), :430-431 (canvas)
+  dependency rule     sample_ultra_res.py:92-107, :141-143 and get_next_patches :403-412
+  orientation         sample_ultra_res.py:423-426
+  inpaint patch/mask  sample_ultra_res.py:147-170 (+ fallback crops :128-140)
+  cond images         sample_ultra_res.py:356-400 (roll / fill / centre crop)
+  stitch              sample_ultra_res.py:434-446, outpainting.py:232-243
+Everything here is integer geometry or tensor slicing; no model arithmetic.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+PATCH_SIZE = 1024                       # sample_ultra_res.py:31
+PATCH_SIZES = {1: 64, 2: 256, 3: 1024}  # sample_ultra_res.py:32
+MAG_LEVEL_SIZES = [40000, 6500, 1024]   # ultra_res_patient_dataset.py:18
+MAG_LEVEL_SIZES_AIRS = [10000, 3328, 1024]  # ultra_res_airs.py:23
+
+Pos = Tuple[int, int]
+
+
+def get_patch_width(mag_level: int, sizes: Sequence[int] = MAG_LEVEL_SIZES) -> int:
+    """Width of a mag-(level) patch inside the 1024-px image of the level above."""
+    return int(sizes[mag_level] * PATCH_SIZE / sizes[mag_level - 1])
+
+
+@dataclass(frozen=True)
+class GridGeometry:
+    patch_width: int        # patch footprint in the zoomed (conditioning) image
+    patch_dist: int         # stride in the zoomed image
+    num_patches_width: int
+    out_patch_dist: int     # stride on the output canvas
+    canvas_width: int
+
+    @property
+    def positions(self) -> List[Pos]:
+        n = self.num_patches_width
+        return [(i, j) for i in range(n) for j in range(n)]
+
+
+def grid_geometry(zoomed_width: int, mag_level: int, overlap: float, sizes: Sequence[int] = MAG_LEVEL_SIZES,
+                  prefer_in_bounds: bool = False) -> GridGeometry:
+    pw = get_patch_width(mag_level, sizes)
+    dist = int(pw * (1 - overlap))
+    n = 1 + math.ceil((zoomed_width - pw) / dist)
+    if prefer_in_bounds:  # the 'airs' variant, sample_ultra_res.py:312-314
+        n = max(1, n - 1)
+    out_dist = int(PATCH_SIZE * (1 - overlap))
+    return GridGeometry(pw, dist, n, out_dist, PATCH_SIZE + (n - 1) * out_dist)
+
+
+def get_next_patches(patches: Sequence[Pos], orientation: int):
+    """Patches none of whose three predecessors are in the list (sample_ultra_res.py:403-412)."""
+    s = set(patches)
+    ready = [(i, j) for i, j in patches
+             if (i - 1, j) not in s and (i, j + orientation) not in s and (i - 1, j + orientation) not in s]
+    return ready, [p for p in patches if p not in set(ready)]
+
+
+def choose_orientation(patch_pos: Sequence[Pos]) -> int:
+    """-1 if more patches can start from the top-left than from the top-right (sample_ultra_res.py:423-426)."""
+    return -1 if len(get_next_patches(patch_pos, -1)[0]) > len(get_next_patches(patch_pos, 1)[0]) else 1
+
+
+def dependencies(pos: Pos, patch_pos: Sequence[Pos], orientation: int) -> List[Pos]:
+    i, j = pos
+    s = set(patch_pos)
+    return [p for p in ((i - 1, j), (i, j + orientation), (i - 1, j + orientation)) if p in s]
+
+
+def wavefronts(patch_pos: Sequence[Pos], orientation: int) -> List[List[Pos]]:
+    """Anti-diagonal waves: wave k holds every patch whose predecessors all lie in waves < k.  The
+    reference reaches the same partial order by re-queueing patches that are not ready yet."""
+    remaining = list(patch_pos)
+    waves = []
+    while remaining:
+        ready, remaining = get_next_patches(remaining, orientation)
+        assert ready, "dependency cycle in the patch grid"
+        waves.append(ready)
+    return waves
+
+
+def assemble_inpaint(pos: Pos, patch_pos: Sequence[Pos], done: Dict[Pos, torch.Tensor], size: int, overlap: float,
+                     orientation: int, num_patches_width: int, cond_image: Optional[torch.Tensor] = None,
+                     patch_width: Optional[int] = None):
+    """inpaint_patch (3,S,S) and inpaint_mask (S,S) for one patch from its finished neighbours
+    (`done[pos]` = (3,S,S) tensors of the SAME stage).  Neighbours that were filtered out of
+    `patch_pos` but lie inside the image fall back to bilinear-upscaled crops of the conditioning
+    image, exactly as sample_ultra_res.py:128-140."""
+    i, j = pos
+    s = set(patch_pos)
+    above, next_to, above_next = (i - 1, j), (i, j + orientation), (i - 1, j + orientation)
+    space_above = i != 0
+    space_next = (orientation == 1 and j < num_patches_width - 1) or (orientation == -1 and j > 0)
+
+    def fallback(dy, dx):
+        assert cond_image is not None and patch_width is not None
+        dist = int(patch_width * (1 - overlap))
+        ty = cond_image.shape[1] // 2 - patch_width // 2 + dy * dist
+        tx = cond_image.shape[2] // 2 - patch_width // 2 + dx * dist
+        crop = cond_image[:3, ty:ty + patch_width, tx:tx + patch_width].unsqueeze(0)
+        return F.interpolate(crop, size=(size, size), mode="bilinear", align_corners=False)[0]
+
+    def get(p, has_space, dy, dx):
+        if p in s:
+            return done[p]
+        return fallback(dy, dx) if has_space and cond_image is not None else None
+
+    a = get(above, space_above, -1, 0)
+    n = get(next_to, space_next, 0, orientation)
+    an = get(above_next, space_above and space_next, -1, orientation)
+    ref = next((t for t in (a, n, an) if t is not None), None)
+    kw = dict(device=ref.device, dtype=ref.dtype) if ref is not None else {}
+    patch = torch.zeros(3, size, size, **kw)
+    mask = torch.zeros(size, size, **kw)
+    ov = int(overlap * size)
+    if a is not None:
+        patch[:, :ov, :] = a[:, -ov:, :]
+        mask[:ov, :] = 1
+    if n is not None:
+        if orientation == -1:
+            patch[:, :, :ov] = n[:, :, -ov:]
+            mask[:, :ov] = 1
+        else:
+            patch[:, :, -ov:] = n[:, :, :ov]
+            mask[:, -ov:] = 1
+    if an is not None:
+        if orientation == -1:
+            patch[:, :ov, :ov] = an[:, -ov:, -ov:]
+        else:
+            patch[:, :ov, -ov:] = an[:, -ov:, :ov]
+    return patch, mask
+
+
+def cond_images_for_grid(zoomed_image: torch.Tensor, geom: GridGeometry, patch_pos: Sequence[Pos],
+                         fill_color: float = 0.95, centre_crop_channels: bool = False) -> torch.Tensor:
+    """(N,3|6,1024,1024) conditioning images: the zoomed image shifted so that each patch sits in the
+    centre, gaps filled, centre-cropped to 1024 (sample_ultra_res.py:356-400; `v2` adds the
+    nearest-upsampled centre patch as 3 extra channels)."""
+    W = zoomed_image.shape[3]
+    out = []
+    for i, j in patch_pos:
+        cy = i * geom.patch_dist + geom.patch_width // 2
+        cx = j * geom.patch_dist + geom.patch_width // 2
+        sy, sx = W // 2 - cy, W // 2 - cx
+        img = torch.roll(zoomed_image[0], shifts=(sy, sx), dims=(1, 2))
+        if sy > 0:
+            img[:, :sy, :] = fill_color
+        else:
+            img[:, sy:, :] = fill_color   # sy == 0 fills everything, as the reference's slice does
+        if sx > 0:
+            img[:, :, :sx] = fill_color
+        else:
+            img[:, :, sx:] = fill_color
+        off = (img.shape[-1] - PATCH_SIZE) // 2 if img.shape[-1] > PATCH_SIZE else 0
+        c = img[:, off:off + PATCH_SIZE, off:off + PATCH_SIZE] if img.shape[-1] >= PATCH_SIZE else img
+        if centre_crop_channels:
+            o2 = (c.shape[-1] - geom.patch_width) // 2
+            centre = c[:, o2:o2 + geom.patch_width, o2:o2 + geom.patch_width]
+            centre = F.interpolate(centre.unsqueeze(0), PATCH_SIZE, mode="nearest").squeeze(0)
+            c = torch.cat((c, centre), 0)
+        out.append(c)
+    return torch.stack(out)
+
+
+def stitch_canvas(patches: Sequence[torch.Tensor], patch_pos: Sequence[Pos], geom: GridGeometry,
+                  background: Optional[torch.Tensor] = None, patch_size: int = PATCH_SIZE) -> torch.Tensor:
+    """Pastes (3,P,P) patches at (i*stride, j*stride) in index order — later patches overwrite the
+    overlap, as sample_ultra_res.py:442-446 — onto `background` bilinearly resized to the canvas
+    (ultra-res) or zeros (outpainting.py:235)."""
+    stride = geom.out_patch_dist  # in output pixels of `patch_size`-wide patches
+    width = patch_size + (geom.num_patches_width - 1) * stride
+    ref = patches[0]
+    if background is not None:
+        full = F.interpolate(background.to(ref), size=(width, width), mode="bilinear", align_corners=False)
+    else:
+        full = torch.zeros(1, 3, width, width, device=ref.device, dtype=ref.dtype)
+    for idx, (i, j) in enumerate(patch_pos):
+        y, x = i * stride, j * stride
+        full[0, :, y:y + patch_size, x:x + patch_size] = patches[idx]
+    return full

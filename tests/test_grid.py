@@ -1,0 +1,139 @@
+"""Patch-grid geometry / wavefront / stitch (CPU) and the world_size-2 gloo run of the distributed
+scheduler against the single-process result."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from ultra_res import distributed as D
+from ultra_res import grid as G
+
+
+def test_geometry_matches_survey_numbers():
+    # kidney mag1 -> patch_width 166, dist 124, 8x8, canvas 6400; mag2 -> 161, 120, 53x53
+    g1 = G.grid_geometry(1024, 1, 0.25)
+    assert (g1.patch_width, g1.patch_dist, g1.num_patches_width, g1.out_patch_dist, g1.canvas_width) == \
+        (166, 124, 8, 768, 6400)
+    g2 = G.grid_geometry(6400, 2, 0.25)
+    assert (g2.patch_width, g2.patch_dist, g2.num_patches_width) == (161, 120, 53)
+    ga = G.grid_geometry(1024, 1, 0.25, sizes=G.MAG_LEVEL_SIZES_AIRS, prefer_in_bounds=True)
+    assert (ga.patch_width, ga.patch_dist, ga.num_patches_width, ga.canvas_width) == (340, 255, 3, 2560)
+
+
+@pytest.mark.parametrize("o", [-1, 1])
+def test_wavefront_order_and_dependency_bound(o):
+    pos = G.grid_geometry(1024, 1, 0.25).positions
+    waves = G.wavefronts(pos, o)
+    assert len(waves) == 15 and sorted(len(w) for w in waves) == sorted([1, 2, 3, 4, 5, 6, 7, 8, 7, 6, 5, 4, 3, 2, 1])
+    seen = set()
+    for w in waves:
+        for p in w:
+            assert all(d in seen for d in G.dependencies(p, pos, o))
+        seen |= set(w)
+    first = (0, 0) if o == -1 else (0, 7)
+    assert waves[0] == [first]
+    tasks = D.merged_waves([pos], [o])
+    # 64 / 36 / 22 / 15 sequential slots on 1 / 2 / 4 / 8 GPUs
+    assert [D.schedule_length(tasks, g) for g in (1, 2, 4, 8)] == [64, 36, 22, 15]
+    two = D.merged_waves([pos, pos], [o, o])
+    assert D.schedule_length(two, 8) == 22   # two canvases in flight: 128/22 = 5.8x instead of 4.27x
+
+
+def test_orientation_choice_and_filtered_grid():
+    full = [(i, j) for i in range(4) for j in range(4)]
+    assert G.choose_orientation(full) == 1  # tie -> +1, as the reference's strict '>' does
+    tri = [(i, j) for i in range(4) for j in range(4) if j >= i]   # more free top-left corners
+    assert G.choose_orientation([p for p in tri if p != (0, 0)]) in (-1, 1)
+    waves = G.wavefronts(tri, 1)
+    assert sum(len(w) for w in waves) == len(tri)
+
+
+def test_inpaint_assembly_matches_reference_slicing():
+    S, ov = 16, 4
+    mk = lambda v: torch.full((3, S, S), float(v)) + torch.arange(S).float()[None, None, :] * 0.01 \
+        + torch.arange(S).float()[None, :, None] * 0.1
+    pos = [(i, j) for i in range(2) for j in range(2)]
+    done = {(0, 0): mk(1), (0, 1): mk(2), (1, 0): mk(3)}
+    patch, mask = G.assemble_inpaint((1, 1), pos, done, S, 0.25, -1, 2)
+    assert torch.equal(patch[:, :ov, :], torch.cat((done[(0, 0)][:, -ov:, -ov:], done[(0, 1)][:, -ov:, ov:]), 2))
+    assert torch.equal(patch[:, ov:, :ov], done[(1, 0)][:, ov:, -ov:])
+    assert mask[:ov].all() and mask[:, :ov].all() and mask[ov:, ov:].sum() == 0
+    assert patch[:, ov:, ov:].abs().sum() == 0
+    # orientation +1 mirrors left/right
+    done = {(0, 1): mk(1), (0, 0): mk(2), (1, 1): mk(3)}
+    patch, mask = G.assemble_inpaint((1, 0), pos, done, S, 0.25, 1, 2)
+    assert torch.equal(patch[:, ov:, -ov:], done[(1, 1)][:, ov:, :ov]) and mask[:, -ov:].all()
+    assert torch.equal(patch[:, :ov, -ov:], done[(0, 1)][:, -ov:, :ov])
+    # first patch: nothing known
+    patch, mask = G.assemble_inpaint((0, 0), pos, {}, S, 0.25, -1, 2)
+    assert patch.abs().sum() == 0 and mask.sum() == 0
+
+
+def test_cond_images_and_stitch_semantics():
+    geom = G.GridGeometry(patch_width=8, patch_dist=6, num_patches_width=2, out_patch_dist=768, canvas_width=1792)
+    z = torch.rand(1, 3, 14, 14)
+    pos = geom.positions
+    conds = G.cond_images_for_grid(z, geom, pos, fill_color=0.95)
+    assert conds.shape == (4, 3, 14, 14)
+    # patch (0,0) centre (4,4) moves to the image centre (7,7): shift +3, top/left 3 rows filled
+    assert torch.equal(conds[0][:, 3:, 3:], z[0][:, :-3, :-3]) and (conds[0][:, :3] == 0.95).all()
+    small = G.GridGeometry(8, 6, 2, 12, 28)
+    patches = [torch.full((3, 16, 16), float(k)) for k in range(4)]
+    full = G.stitch_canvas(patches, pos, small, background=None, patch_size=16)
+    assert full.shape == (1, 3, 28, 28)
+    assert (full[0, :, :12, :12] == 0).all() and (full[0, :, 12:, 12:] == 3).all()
+    assert (full[0, :, 12:16, :12] == 2).all()  # later patch overwrites the overlap (index order)
+    bg = torch.zeros(1, 3, 7, 7) + 0.5
+    assert G.stitch_canvas(patches[:1], pos[:1], small, background=bg, patch_size=16)[0, :, 20:, 20:].eq(0.5).all()
+
+
+def _stub_sample_fn(stage, tasks, lows, conds, ips, ims):
+    """Deterministic stand-in for the sampler: a function of every input the real one consumes."""
+    S = G.PATCH_SIZES[stage]
+    outs = []
+    for (c, i, j), low, cond, ip, im in zip(tasks, lows, conds, ips, ims):
+        base = torch.full((3, S, S), 0.01 * (c + 1) + 0.1 * i + 0.001 * j + stage)
+        if low is not None:
+            base = base + torch.nn.functional.interpolate(low[None], S, mode="nearest")[0] * 0.5
+        if cond is not None:
+            base = base + cond[:3].mean() * 0.25
+        base = torch.where(im.bool()[None], ip, base + 0.3 * ip.mean())
+        outs.append(base)
+    return outs
+
+
+def _run_grid(world, rank=0, port=None, out=None):
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pos = [(i, j) for i in range(3) for j in range(3)]
+        g = torch.Generator().manual_seed(0)
+        conds = [torch.rand(9, 3, 8, 8, generator=g), torch.rand(9, 3, 8, 8, generator=g)]
+        res = D.sample_grids(_stub_sample_fn, (1, 2), [pos, pos], conds, 0.25, [3, 3], orientations=[-1, 1])
+        flat = torch.stack([torch.stack(r) for r in res])
+        if out is not None:
+            out[rank] = flat
+        return flat
+    finally:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+
+
+def _worker(rank, world, port, out):
+    _run_grid(world, rank, port, out)
+
+
+def test_two_rank_gloo_schedule_equals_single_process():
+    single = _run_grid(1)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert torch.equal(out[0], single) and torch.equal(out[1], single)
+    # stage 2 really consumed stage 1 and the neighbours: overlaps were pasted from finished patches
+    assert single.shape == (2, 9, 3, 256, 256)
