@@ -82,6 +82,15 @@ int64_t kd_unet_hbm_bytes(const kd_unet_t* u);
 int64_t kd_unet_macs(const kd_unet_t* u);
 int kd_unet_num_launches(const kd_unet_t* u);
 
+/* Step-invariant text conditioning (the text branch of Unet.forward; reached by the
+ * reference through sample_cond.py:36-48 / sample.py:51-60): text_to_cond, null-embedding select,
+ * PerceiverResampler pooling, to_text_non_attn_cond.  Run once per sample call.
+ *   d_text_embeds [B,L,text_embed_dim], d_text_mask [B,L] as 0/1 floats, L <= max_text_len;
+ *   drop = 1 gives the null conditioning (cond_drop_prob = 1, used for classifier-free guidance);
+ *   out: d_text_tokens [B,text_tokens,cond_dim], d_text_hiddens [B,time_cond_dim]. */
+int kd_unet_text_cond(kd_unet_t* u, const float* d_text_embeds, const float* d_text_mask, int L, int drop,
+                      float* d_text_tokens, float* d_text_hiddens, void* stream);
+
 /* Diagnostic: per-launch device time of one forward as CSV "index,label,macs,avg_us" (uses the
  * inputs of the preceding kd_unet_forward call; synchronises the stream). */
 int kd_unet_profile(kd_unet_t* u, int iters, char* buf, size_t buflen, void* stream);
@@ -147,6 +156,11 @@ typedef struct kd_sample_args {
   const float* d_noise_renoise;
   uint64_t seed;
   int use_graph;              /* 1: capture one step into a hipGraph and replay it */
+  /* classifier-free guidance (sample.py:55-59): pred = null + (cond - null) * cond_scale, two UNet
+   * forwards per step when cond_scale != 1; the null conditioning comes from kd_unet_text_cond(drop=1) */
+  float cond_scale;           /* 1.0 = off */
+  const float* d_null_text_tokens;
+  const float* d_null_text_hiddens;
 } kd_sample_args_t;
 
 /* In: d_img = x_T [B,3,S,S].  Out: d_img = unnormalised sample in [0,1] (clamp, final inpaint

@@ -115,6 +115,13 @@ size_t gca_scratch_floats(int B, int HW, int C);
 // time embedding: out[b][0]=t, [1..h]=sin(t*w*2pi), [h+1..2h]=cos
 int launch_sinu_emb(const float* t, const float* w, float* out, int B, int half, hipStream_t s);
 
+// ---- text conditioning helpers (kernels_text.hip)
+int launch_text_select(const float* tok, const float* mask, const float* null_embed, float* out, int B, int L, int P,
+                       int C, int drop, hipStream_t s);
+int launch_add_rows_bcast(const float* x, const float* add, float* y, int B, int R, int C, hipStream_t s);
+int launch_mean_rows(const float* x, float* y, int B, int R, int C, hipStream_t s);
+int launch_cfg_combine(const float* cond, const float* nul, float* out, float scale, int64_t n, hipStream_t s);
+
 // ---- sampler (kernels_sampler.hip)
 struct StepTables {  // device arrays of T floats
   const float *log_snr, *alpha, *sigma, *alpha_next, *sigma_next, *c, *noise_scale, *rn_a, *rn_b;

@@ -137,6 +137,13 @@ struct kd_unet {
   const float *in_x = nullptr, *in_lowres = nullptr, *in_cond = nullptr, *in_log_snr = nullptr,
               *in_lowres_log_snr = nullptr, *in_text_tokens = nullptr, *in_text_hiddens = nullptr;
   float* out = nullptr;
+  // text-conditioning sub-plan (present iff cfg.cond_on_text && cfg.text_tokens > 0)
+  std::vector<std::function<int(hipStream_t)>> text_ops;
+  int text_embed_dim = 0, max_text_len = 0;
+  const float *in_text_embeds = nullptr, *in_text_mask = nullptr;
+  int in_text_len = 0, in_text_drop = 0;
+  float *out_text_tokens = nullptr, *out_text_hiddens = nullptr;
+  float* s_pred_null = nullptr;  // classifier-free guidance: second forward's output
   // sampler scratch (allocated on first use)
   float *s_pred = nullptr, *s_x0 = nullptr, *s_thresh = nullptr, *s_time = nullptr, *s_tables = nullptr;
   int* s_iter = nullptr;
@@ -151,7 +158,7 @@ struct kd_unet {
   ~kd_unet() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
-    void* frees[] = {ws, s_pred, s_x0, s_thresh, s_time, s_tables, s_iter, s_qws};
+    void* frees[] = {ws, s_pred, s_x0, s_thresh, s_time, s_tables, s_iter, s_qws, s_pred_null};
     for (void* p : frees)
       if (p) (void)hipFree(p);
   }
@@ -245,7 +252,13 @@ struct Builder {
       arena.release(t.off);
     }
   }
+  bool to_text = false;  // building the text-conditioning sub-plan: ops go to u->text_ops
+  const float* P_(const std::string& n) { return P(n); }
   void emit(std::function<int(hipStream_t)> f, std::string label = "op", int64_t macs = 0) {
+    if (to_text) {
+      u->text_ops.push_back(std::move(f));
+      return;
+    }
     u->ops.push_back(std::move(f));
     u->op_label.push_back(std::move(label));
     u->op_macs.push_back(macs);
@@ -307,11 +320,13 @@ struct Builder {
     });
     int cin = o.cin_logical > 0 ? o.cin_logical : x.C;
     int64_t m = (int64_t)x.B * Ho * Wo * Cout * cin * K * K;
-    u->op_label.back() = "conv k" + std::to_string(K) + " s" + std::to_string(stride) + " M" +
-                         std::to_string((int64_t)x.B * Ho * Wo) + " Cin" + std::to_string(x.C) + " Cout" +
-                         std::to_string(Cout);
-    u->op_macs.back() = m;
-    u->macs += m;
+    if (!to_text) {
+      u->op_label.back() = "conv k" + std::to_string(K) + " s" + std::to_string(stride) + " M" +
+                           std::to_string((int64_t)x.B * Ho * Wo) + " Cin" + std::to_string(x.C) + " Cout" +
+                           std::to_string(Cout);
+      u->op_macs.back() = m;
+      u->macs += m;
+    }
     return y;
   }
   // token GEMM y[M,N] = x[M,K] @ w[N,K]^T
@@ -337,7 +352,7 @@ struct Builder {
     emit([=](hipStream_t s) {
       return launch_linear_skinny(uu->P(x_off), ldx, w, bias, uu->P(y_off), ldy, M, K, N, in_act, act, s);
     }, "skinny M" + std::to_string(M) + " K" + std::to_string(K) + " N" + std::to_string(N), (int64_t)M * K * N);
-    u->macs += (int64_t)M * K * N;
+    if (!to_text) u->macs += (int64_t)M * K * N;
   }
 
   T layernorm(const T& x, const float* g, const float* beta, const T* res = nullptr) {
@@ -637,10 +652,12 @@ struct Builder {
   }
 
   void build();
+  void build_text();
 };
 
 }  // namespace kd
 
 #include "unet_build.inc"  // Builder::build(): the walk over the module tree
+#include "text_build.inc"  // Builder::build_text(): step-invariant text conditioning
 #include "api.inc"         // sampler loop + extern "C" entry points
 

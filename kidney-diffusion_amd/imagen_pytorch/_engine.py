@@ -80,6 +80,9 @@ class kd_sample_args_t(C.Structure):
         ("d_noise_renoise", C.c_void_p),
         ("seed", C.c_uint64),
         ("use_graph", C.c_int),
+        ("cond_scale", C.c_float),
+        ("d_null_text_tokens", C.c_void_p),
+        ("d_null_text_hiddens", C.c_void_p),
     ]
 
 
@@ -93,6 +96,8 @@ SIGNATURES = {
     "kd_unet_hbm_bytes": (C.c_int64, [C.c_void_p]),
     "kd_unet_macs": (C.c_int64, [C.c_void_p]),
     "kd_unet_num_launches": (C.c_int, [C.c_void_p]),
+    "kd_unet_text_cond": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
     "kd_unet_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_void_p]),
     "kd_unet_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8 + [C.c_void_p]),
     "kd_sample_loop": (C.c_int, [C.c_void_p, C.POINTER(kd_schedule_t), C.POINTER(kd_sample_args_t), C.c_void_p,

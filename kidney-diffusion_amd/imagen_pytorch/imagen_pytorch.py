@@ -422,8 +422,6 @@ class Unet(nn.Module):
         assert not (self.lowres_cond and not exists(lowres_noise_times)), "low resolution conditioning noise time must be present"
         assert not (self.has_cond_image ^ exists(cond_images)), \
             "you either requested to condition on an image on the unet, but the conditioning image is not supplied, or vice versa"
-        if exists(text_embeds) and self.cond_on_text:
-            raise NotImplementedError("text conditioning on the engine is planned (SURVEY §8f); not in this round")
         E.require_gpu()
         b, _, s, _ = x.shape
         f32 = lambda t: None if t is None else t.to(device=x.device, dtype=torch.float32).contiguous()
@@ -433,11 +431,32 @@ class Unet(nn.Module):
         x, lowres_cond_img, cond_images = f32(x), f32(lowres_cond_img), f32(cond_images)
         time, lowres_noise_times = f32(time), f32(lowres_noise_times)
         out = torch.empty_like(x)
+        with_text = exists(text_embeds) and self.cond_on_text
+        assert cond_drop_prob in (0.0, 1.0), "sampling uses keep-all (0) or drop-all (1) conditioning only"
         with torch.cuda.device(x.device):
-            h = self.engine(b, s, x.device, with_text=False)
+            h = self.engine(b, s, x.device, with_text=with_text)
+            tok = hid = None
+            if with_text:
+                tok, hid = self.text_cond(h, text_embeds, text_mask, drop=cond_drop_prob == 1.0, device=x.device)
             E.check(E.load().kd_unet_forward(h, E.ptr(x), E.ptr(lowres_cond_img), E.ptr(cond_images), E.ptr(time),
-                                             E.ptr(lowres_noise_times), None, None, E.ptr(out), E.current_stream()))
+                                             E.ptr(lowres_noise_times), E.ptr(tok), E.ptr(hid), E.ptr(out),
+                                             E.current_stream()))
         return out
+
+    def text_cond(self, handle, text_embeds, text_mask, drop, device):
+        """(text_tokens [B,n,cond_dim], text_hiddens [B,time_cond_dim]) on the engine — the
+        step-invariant text branch of the library's Unet.forward, computed once per sample call."""
+        f32 = lambda t: t.to(device=device, dtype=torch.float32).contiguous()
+        text_embeds = f32(text_embeds)[:, : self.max_text_len].contiguous()
+        b, L, _ = text_embeds.shape
+        mask = torch.ones(b, L, device=device) if text_mask is None else f32(text_mask)[:, : self.max_text_len]
+        mask = mask.contiguous()  # named tensors: they must outlive the asynchronous launches below
+        tok = torch.empty(b, self.n_text_tokens, self.cond_dim, device=device)
+        hid = torch.empty(b, self.time_cond_dim, device=device)
+        E.check(E.load().kd_unet_text_cond(handle, E.ptr(text_embeds), E.ptr(mask), L, int(bool(drop)), E.ptr(tok),
+                                           E.ptr(hid), E.current_stream()))
+        torch.cuda.current_stream().synchronize()  # text_embeds / mask temporaries may be released now
+        return tok, hid
 
     def forward_with_cond_scale(self, *args, cond_scale=1.0, **kwargs):
         if cond_scale != 1:
@@ -624,9 +643,6 @@ class Imagen(nn.Module):
         assert not (exists(text_embeds) and text_embeds.shape[-1] != self.text_embed_dim), \
             f"invalid text embedding dimension being passed in (should be {self.text_embed_dim})"
         assert not (exists(inpaint_images) ^ exists(inpaint_masks)), "inpaint images and masks must be both passed in to do inpainting"
-        if exists(text_embeds):
-            raise NotImplementedError("text conditioning on the engine is planned (SURVEY §8f); not in this round")
-
         lowres_sample_noise_level = default(lowres_sample_noise_level, self.lowres_sample_noise_level)
         n = len(self.unets)
         cond_scale = cast_tuple(cond_scale, n)
@@ -650,11 +666,12 @@ class Imagen(nn.Module):
             if num < start_at_unet_number:
                 continue
             assert not isinstance(unet, NullUnet), "one cannot sample from null / placeholder unets"
-            if cs != 1:
-                raise NotImplementedError("classifier-free guidance (cond_scale != 1) is planned (SURVEY §8f)")
+            assert not (cs != 1.0 and not self.condition_on_text), \
+                "imagen was not trained with conditional dropout, and thus one cannot use classifier free guidance (cond_scale anything other than 1)"
             img = self._p_sample_loop(
                 unet, num, size, sched, obj, dyn, batch_size, device, img, cond_images, inpaint_images,
-                inpaint_masks, inpaint_resample_times, lowres_sample_noise_level, noise_fn, seed, use_graph, trace)
+                inpaint_masks, inpaint_resample_times, lowres_sample_noise_level, noise_fn, seed, use_graph, trace,
+                text_embeds=text_embeds, text_masks=text_masks, cond_scale=float(cs))
             outputs.append(img)
             if exists(stop_at_unet_number) and stop_at_unet_number == num:
                 break
@@ -669,7 +686,7 @@ class Imagen(nn.Module):
 
     def _p_sample_loop(self, unet, stage, size, sched, objective, dynamic_threshold, batch, device, prev_img,
                        cond_images, inpaint_images, inpaint_masks, resample_times, lowres_level, noise_fn, seed,
-                       use_graph, trace):
+                       use_graph, trace, text_embeds=None, text_masks=None, cond_scale=1.0):
         lib = E.load()
         shape = (batch, self.channels, size, size)
         f32 = lambda t: None if t is None else t.to(device=device, dtype=torch.float32).contiguous()
@@ -731,7 +748,17 @@ class Imagen(nn.Module):
                     if R > 1:
                         args.d_noise_renoise = stack("renoise")
             img = gauss(("init", stage), shape, (16 << 32) | 2)
-            h = unet.engine(batch, size, device, with_text=False)
+            with_text = exists(text_embeds) and unet.cond_on_text
+            h = unet.engine(batch, size, device, with_text=with_text)
+            if with_text:  # step-invariant: pooled text tokens + text hiddens, once per stage
+                tok, hid = unet.text_cond(h, text_embeds, text_masks, drop=False, device=device)
+                keep += [tok, hid]
+                args.d_text_tokens, args.d_text_hiddens = E.ptr(tok), E.ptr(hid)
+                args.cond_scale = cond_scale
+                if cond_scale != 1.0:  # classifier-free guidance: null conditioning for the second forward
+                    ntok, nhid = unet.text_cond(h, text_embeds, text_masks, drop=True, device=device)
+                    keep += [ntok, nhid]
+                    args.d_null_text_tokens, args.d_null_text_hiddens = E.ptr(ntok), E.ptr(nhid)
             if exists(trace):
                 for k in range(T):
                     E.check(lib.kd_sample_steps(h, C.byref(sc), C.byref(args), E.ptr(img), k, k + 1, E.current_stream()))

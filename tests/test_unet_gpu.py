@@ -172,3 +172,103 @@ def test_engine_cascade_sampler_matches_golden(device):
                     start_at_unet_number=2, inpaint_images=t("inpaint"), inpaint_masks=t("mask"),
                     inpaint_resample_times=2, device=device)
     assert (sr.cpu() - torch.from_numpy(g["sr"])).abs().max() < SAMPLE_ABS
+
+
+def test_patch_grid_on_engine_matches_oracle_driver(device):
+    """The ultra-res grid driver (ultra_res/) over the HIP engine vs the same driver over the CPU
+    oracle: 2x2 grid, stage-2 only, every patch sampled with the reference's kwargs
+    (sample_ultra_res.py:183-195) and inpainted from its finished neighbours."""
+    from ultra_res import distributed as D
+    from ultra_res import grid as G
+
+    oim, pim = _imagen_pair(device, ["small1", "small2"], (16, 32), (3, 4), ("noise", "v"))
+    pos = [(i, j) for i in range(2) for j in range(2)]
+    g = torch.Generator().manual_seed(4)
+    cond = torch.rand(4, 3, 32, 32, generator=g)
+    low = torch.rand(4, 3, 16, 16, generator=g)
+    old = dict(G.PATCH_SIZES)
+    G.PATCH_SIZES.update({1: 16, 2: 32})
+    try:
+        def oracle_fn(stage, tasks, lows, conds, ips, ims):
+            outs = []
+            for t, lo, c, ip, im in zip(tasks, lows, conds, ips, ims):
+                nf = RS.generator_noise_fn(1000 + 10 * t[1] + t[2])
+                outs.append(oim.sample(noise_fn=nf, batch_size=1, cond_images=c[None], start_image_or_video=lo[None],
+                                       start_at_unet_number=stage, stop_at_unet_number=stage, inpaint_images=ip[None],
+                                       inpaint_masks=im[None], inpaint_resample_times=2)[0])
+            return outs
+
+        def engine_fn(stage, tasks, lows, conds, ips, ims):
+            outs = []
+            for t, lo, c, ip, im in zip(tasks, lows, conds, ips, ims):
+                nf = RS.generator_noise_fn(1000 + 10 * t[1] + t[2])
+                dv = lambda v: v[None].to(device)
+                outs.append(pim.sample(noise_fn=nf, batch_size=1, cond_images=dv(c), start_image_or_video=dv(lo),
+                                       start_at_unet_number=stage, stop_at_unet_number=stage, inpaint_images=dv(ip),
+                                       inpaint_masks=dv(im), inpaint_resample_times=2, device=device)[0].cpu())
+            return outs
+
+        kw = dict(stages=(2,), patch_pos=[pos], cond_images=[cond], overlap=0.25, num_patches_width=[2],
+                  orientations=[-1], lowres=[low])
+        ref = D.sample_grids(oracle_fn, **kw)[0]
+        got = D.sample_grids(engine_fn, **kw)[0]
+    finally:
+        G.PATCH_SIZES.clear()
+        G.PATCH_SIZES.update(old)
+    for a, b in zip(got, ref):
+        assert (a - b).abs().max() < SAMPLE_ABS
+    # the overlap strip of patch (1,1) is exactly the bottom strip of patch (0,1)
+    assert torch.equal(got[3][:, :8, 8:], got[1][:, -8:, 8:])
+
+
+# ------------------------------------------------------------------------------- text conditioning + guidance (seg-cond path)
+SEG_KW = dict(dim=32, dim_mults=(1, 2, 3, 4), cond_dim=64, text_embed_dim=3, num_resnet_blocks=2,
+              layer_attns=(False, True, True, True), layer_cross_attns=(False, True, True, True),
+              cond_images_channels=4)  # train.py:30-39 at reduced dim
+
+
+def _seg_pair(device, seed=17, T=4):
+    import imagen_pytorch as ip
+    from oracle import imagen_ref as R
+
+    ou = H.randomize_(R.Unet(**SEG_KW, cond_on_text=True), seed)
+    oim = RS.Imagen([ou], image_sizes=(16,), timesteps=(T,), pred_objectives=("noise",), text_embed_dim=3)
+    pim = ip.Imagen([ip.Unet(**oim.unets[0]._locals)], image_sizes=(16,), timesteps=(T,), pred_objectives=("noise",),
+                    text_embed_dim=3)
+    pim.load_state_dict(oim.state_dict(), strict=True)
+    return oim, pim.to(device)
+
+
+def test_text_conditioned_unet_forward_matches_oracle(device):
+    """sample_cond.py:36-48 call shape: text_embeds (B,1,3) = [0.0, 0.5, 0.2], 4 one-hot label planes."""
+    oim, pim = _seg_pair(device)
+    ou, pu = oim.unets[0], pim.unets[0]
+    B, S = 3, 16
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, 3, S, S, generator=g)
+    t = torch.randn(B, generator=g)
+    text = torch.tensor([0.0, 0.5, 0.2]).reshape(1, 1, 3).repeat_interleave(B, dim=0)
+    text[1, 0] = torch.tensor([0.3, -0.2, 1.0])  # per-sample text
+    mask = torch.any(text != 0.0, dim=-1)
+    labels = torch.nn.functional.one_hot(torch.randint(0, 4, (B, 2 * S, 2 * S), generator=g), 4).permute(0, 3, 1, 2).float()
+    dv = lambda v: v.to(device)
+    for drop in (0.0, 1.0):
+        with torch.no_grad():
+            ref = ou(x, t, text_embeds=text, text_mask=mask, cond_images=labels, cond_drop_prob=drop)
+        got = pu(dv(x), dv(t), text_embeds=dv(text), text_mask=dv(mask), cond_images=dv(labels), cond_drop_prob=drop)
+        assert H.rel_l2(got, ref) < FWD_REL_L2, (drop, H.rel_l2(got, ref))
+
+
+@pytest.mark.parametrize("cond_scale", [1.0, 2.5])
+def test_text_conditioned_sampling_with_guidance_matches_oracle(device, cond_scale):
+    """BASELINE config 2 shape (seg-cond base UNet) at reduced dim/T; cond_scale as sample.py:55-59."""
+    oim, pim = _seg_pair(device, T=4)
+    B = 2
+    g = torch.Generator().manual_seed(3)
+    text = torch.tensor([0.0, 0.5, 0.2]).reshape(1, 1, 3).repeat_interleave(B, dim=0)
+    labels = torch.nn.functional.one_hot(torch.randint(0, 4, (B, 16, 16), generator=g), 4).permute(0, 3, 1, 2).float()
+    nf = RS.generator_noise_fn(5)
+    ref = oim.sample(noise_fn=nf, text_embeds=text, cond_images=labels, cond_scale=cond_scale)
+    got = pim.sample(noise_fn=nf, text_embeds=text.to(device), cond_images=labels.to(device), cond_scale=cond_scale,
+                     device=device)
+    assert (got.cpu() - ref).abs().max() < SAMPLE_ABS
