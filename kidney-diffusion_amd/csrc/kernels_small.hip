@@ -100,7 +100,12 @@ int launch_linear_skinny(const float* x, int ldx, const float* w, const float* b
 // logits[p] = x[p][:]·wk + bk ; pooled[c] = sum_p softmax_p(logits) x[p][c]   (per batch element)
 // One read of x: every wave keeps a running (max, sum, weighted channel sums) over its rows (online
 // softmax), waves are merged through LDS, blocks through a small partial buffer.
-constexpr int GCA_ROWS = 256;   // pixels per block
+constexpr int GCA_ROWS = 256;   // pixels per block (grows so that an image never has more than 1024 blocks)
+static inline int gca_rows(int HW) {
+  int r = GCA_ROWS;
+  while ((HW + r - 1) / r > 1024) r *= 2;
+  return r;
+}
 constexpr int GCA_MAXT = 8;     // float4 slices per lane: C <= 2048
 constexpr int GCA_U = 4;        // rows in flight per wave
 
@@ -108,7 +113,7 @@ constexpr int GCA_U = 4;        // rows in flight per wave
 template <int T, int RPW>
 __global__ __launch_bounds__(256) void gca_partial_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                           const float* __restrict__ bk, float* __restrict__ part,
-                                                          int HW, int C) {
+                                                          int HW, int C, int rows) {
   extern __shared__ float sm[];  // [4][C] + [4][2]
   const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void gca_partial_kernel(const float* __restric
   const int sub = RPW == 2 ? (lane >> 5) : 0;
   const int li = RPW == 2 ? (lane & 31) : lane;
   const int C4 = C >> 2;
-  const int p0 = chunk * GCA_ROWS, p1 = min(HW, p0 + GCA_ROWS);
+  const int p0 = chunk * rows, p1 = min(HW, p0 + rows);
   f32x4 wv[T], acc[T];
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -206,38 +211,56 @@ __global__ __launch_bounds__(256) void gca_partial_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void gca_combine_kernel(const float* __restrict__ part, float* __restrict__ pooled,
                                                           int nchunks, int C) {
-  const int b = blockIdx.x;
+  // grid (B, ceil(C/64)); 4 waves: lane = channel, wave = chunk subset
+  __shared__ float se[1024];   // exp(m_i - mg) per chunk (nchunks <= 1024)
+  __shared__ float red[8];
+  __shared__ float sacc[4][64];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lane;
   const float* pb = part + (int64_t)b * nchunks * (C + 2);
-  float mg = -INFINITY;
-  for (int i = 0; i < nchunks; ++i) mg = fmaxf(mg, pb[(int64_t)i * (C + 2)]);
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < nchunks; i += 256) m = fmaxf(m, pb[(int64_t)i * (C + 2)]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  const float mg = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float l = 0.f;
-  for (int i = 0; i < nchunks; ++i) l += pb[(int64_t)i * (C + 2) + 1] * expf(pb[(int64_t)i * (C + 2)] - mg);
-  const float inv = 1.0f / l;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f;
-    for (int i = 0; i < nchunks; ++i) s += pb[(int64_t)i * (C + 2) + 2 + c] * expf(pb[(int64_t)i * (C + 2)] - mg);
-    pooled[(int64_t)b * C + c] = s * inv;
+  for (int i = threadIdx.x; i < nchunks; i += 256) {
+    float e = expf(pb[(int64_t)i * (C + 2)] - mg);
+    se[i] = e;
+    l += pb[(int64_t)i * (C + 2) + 1] * e;
   }
+  l = wave_sum(l);
+  if (lane == 0) red[4 + wave] = l;
+  __syncthreads();
+  const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+  float s = 0.f;
+  if (c < C)
+    for (int i = wave; i < nchunks; i += 4) s += pb[(int64_t)i * (C + 2) + 2 + c] * se[i];
+  sacc[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < C) pooled[(int64_t)b * C + c] = ((sacc[0][lane] + sacc[1][lane]) + (sacc[2][lane] + sacc[3][lane])) * inv;
 }
 
 size_t gca_scratch_floats(int B, int HW, int C) {
-  int chunks = (HW + GCA_ROWS - 1) / GCA_ROWS;
+  int rows = gca_rows(HW), chunks = (HW + rows - 1) / rows;
   return (size_t)B * chunks * (C + 2);
 }
 
 int launch_gca_pool(const float* x, const float* wk, const float* bk, float* /*logits (unused)*/, float* pooled,
                     float* scratch, int B, int HW, int C, hipStream_t s) {
   KD_REQUIRE(C % 4 == 0 && C <= 64 * 4 * GCA_MAXT, "gca needs C % 4 == 0 and C <= 2048");
-  int chunks = (HW + GCA_ROWS - 1) / GCA_ROWS;
+  const int rows = gca_rows(HW), chunks = (HW + rows - 1) / rows;
   size_t smem = (size_t)(4 * C + 8) * sizeof(float);
   const int C4 = C / 4;
   dim3 grid(chunks, B), blk(256);
-  if (C4 == 32) hipLaunchKernelGGL((gca_partial_kernel<1, 2>), grid, blk, smem, s, x, wk, bk, scratch, HW, C);
-  else if (C4 <= 64) hipLaunchKernelGGL((gca_partial_kernel<1, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C);
-  else if (C4 <= 128) hipLaunchKernelGGL((gca_partial_kernel<2, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C);
-  else if (C4 <= 256) hipLaunchKernelGGL((gca_partial_kernel<4, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C);
-  else hipLaunchKernelGGL((gca_partial_kernel<8, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C);
-  hipLaunchKernelGGL(gca_combine_kernel, dim3(B), dim3(256), 0, s, scratch, pooled, chunks, C);
+  if (C4 == 32) hipLaunchKernelGGL((gca_partial_kernel<1, 2>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
+  else if (C4 <= 64) hipLaunchKernelGGL((gca_partial_kernel<1, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
+  else if (C4 <= 128) hipLaunchKernelGGL((gca_partial_kernel<2, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
+  else if (C4 <= 256) hipLaunchKernelGGL((gca_partial_kernel<4, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
+  else hipLaunchKernelGGL((gca_partial_kernel<8, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
+  hipLaunchKernelGGL(gca_combine_kernel, dim3(B, (C + 63) / 64), dim3(256), 0, s, scratch, pooled, chunks, C);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
