@@ -705,7 +705,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bufx_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int64_t M = (int64_t)p.B * p.Ho * p.Wo;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  int bid_m = blockIdx.x;
+  if (p.ldgs == 1) {  // EXPERIMENT: consecutive M tiles on the same XCD (blocks are dealt round-robin over 8 XCDs)
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid_m & 7;
+    bid_m = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid_m >> 3);
+  }
+  const int64_t m0 = (int64_t)bid_m * BM;
   const int n0 = blockIdx.y * BN;
   const int lrow = tid >> 3;
   const int gseg = (tid & 7) ^ ((lrow >> 1) & 7);
@@ -749,9 +754,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bufx_kernel(
   uint32_t soffA = 0, soffB = 0;
   const uint32_t tap_stride_b = (uint32_t)p.Cout * p.Cin * 4;
 
+  const bool tapminor = p.ldres == 1;  // EXPERIMENT: K order = channel-chunk major, tap minor (L2 reuse over taps)
+  const int ntaps_ = p.KH * p.KW;
+  int cc_major = 0;
   auto next_tap = [&]() {
     ++cur_tap;
-    cur_cc = 0;
+    if (tapminor) {
+      if (cur_tap == ntaps_) {
+        cur_tap = 0;
+        ++cc_major;
+      }
+    } else {
+      cur_cc = 0;
+    }
     int kh = cur_tap / p.KW, kw = cur_tap - kh * p.KW;
 #pragma unroll
     for (int q = 0; q < A_PASSES; ++q) {
@@ -759,11 +774,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bufx_kernel(
       bool ok = a_img[q] >= 0 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
       voffA[q] = ok ? (uint32_t)(((a_img[q] + iy * p.Wi + ix) * p.ldx + gseg * 4) * 4) : OOB_OFF;
     }
-    soffA = 0;
-    soffB = (uint32_t)cur_tap * tap_stride_b;
+    soffA = tapminor ? (uint32_t)cc_major * XBK * 4 : 0;
+    soffB = (uint32_t)cur_tap * tap_stride_b + (tapminor ? (uint32_t)cc_major * XBK * 4 : 0);
   };
   auto issue = [&](float* stage_base) {  // DMA of the next chunk into the given stage
-    if (cur_cc == chunks_per_tap) next_tap();
+    if (tapminor || cur_cc == chunks_per_tap) next_tap();
     __attribute__((address_space(3))) float* sb =
         (__attribute__((address_space(3))) float*)(stage_base + wave * 8 * XBK);
 #pragma unroll
@@ -772,9 +787,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_bufx_kernel(
 #pragma unroll
     for (int q = 0; q < B_PASSES; ++q)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, sb + BM * XBK + q * ROWS_PER_PASS * XBK, 16, voffB[q], soffB, 0, 0);
-    soffA += XBK * 4;
-    soffB += XBK * 4;
-    ++cur_cc;
+    if (!tapminor) {
+      soffA += XBK * 4;
+      soffB += XBK * 4;
+      ++cur_cc;
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -944,6 +961,10 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
       case 19: launch_pipe<128, 128, 2, 2>(p, zeros, 0); break;        // pipelined, 128x128, 4 waves
       case 20: launch_buf<128, 128, 2, 2, 2>(p, 0); break;             // buffer-DMA, scalar addressing, 2 blocks/CU
       case 21: launch_buf<256, 128, 4, 2, 2>(p, 0); break;             // same, 256x128 / 8 waves
+      case 28: { ConvParams q = p; q.ldres = 1; launch_buf<256, 128, 4, 2, 2>(q, 0); } break;   // tap-minor K order
+      case 29: { ConvParams q = p; q.ldgs = 1; launch_buf<256, 128, 4, 2, 2>(q, 0); } break;    // XCD remap
+      case 30: { ConvParams q = p; q.ldres = 1; q.ldgs = 1; launch_buf<256, 128, 4, 2, 2>(q, 0); } break;  // both
+      case 31: { ConvParams q = p; q.ldres = 1; q.ldgs = 1; launch_buf<128, 128, 2, 2, 2>(q, 0); } break;
       case 25: launch_buf<128, 64, 2, 2, 3>(p, 0); break;              // 128x64 tiles, 3 blocks/CU
       case 26: launch_buf<64, 128, 2, 2, 3>(p, 0); break;              // 64x128 tiles
       case 27: launch_buf<128, 64, 4, 1, 3>(p, 0); break;              // 128x64, waves 4x1
