@@ -107,13 +107,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     distributed = world > 1
-    device = torch.device("cuda", local_rank)
+    # one process per GPU; KD_BENCH_BACKEND=gloo lets several ranks share one card for a rehearsal
+    backend = os.environ.get("KD_BENCH_BACKEND", "nccl")
+    device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank)
     torch.cuda.set_device(device)
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # RCCL; used for the barrier / max-reduce only
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # RCCL; used for the barrier / max-reduce only
+        else:
+            dist.init_process_group(backend)
 
     from imagen_pytorch import _engine as E
     from imagen_pytorch.imagen_pytorch import GaussianDiffusionContinuousTimes, log_snr_to_alpha_sigma, \
@@ -169,7 +174,7 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the graph is launched on
     assert torch.isfinite(x).all(), "sampler state went non-finite"
     if distributed:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

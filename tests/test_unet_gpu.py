@@ -272,3 +272,45 @@ def test_text_conditioned_sampling_with_guidance_matches_oracle(device, cond_sca
     got = pim.sample(noise_fn=nf, text_embeds=text.to(device), cond_images=labels.to(device), cond_scale=cond_scale,
                      device=device)
     assert (got.cpu() - ref).abs().max() < SAMPLE_ABS
+
+
+# ------------------------------------------------------------------------------- full-size properties (BASELINE config 3)
+def test_full_size_sr_unet_is_deterministic_and_batch_independent(device):
+    """At the benchmark's real size (dim 128, 256x256, train_ultra_res.py:39-48) the CPU oracle is too
+    slow to run in a test, so the forward is pinned through size-independent properties: repeated
+    calls are bit-identical, every sample of a batch equals the same sample run alone (different
+    tile mapping, so to fp32 rounding), and the output responds to the conditioning inputs."""
+    import imagen_pytorch as ip
+
+    with torch.device("meta"):
+        u = ip.Unet(dim=128, dim_mults=(1, 2, 4, 8), num_resnet_blocks=2, memory_efficient=True,
+                    layer_attns=(False, False, False, True), layer_cross_attns=(False, False, True, True),
+                    init_conv_to_final_conv_residual=True, cond_images_channels=3, lowres_cond=True,
+                    cond_on_text=False, text_embed_dim=None)
+    u = u.to_empty(device=device)
+    g = torch.Generator(device=device).manual_seed(0)
+    with torch.no_grad():
+        for name, p in u.named_parameters():
+            if name.endswith(".g") or name.endswith("norm.weight") or name.endswith("groupnorm.weight") \
+                    or name.endswith("norm_cond.weight"):
+                p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g, device=device))
+            elif p.dim() == 1:
+                p.copy_(0.05 * torch.randn(p.shape, generator=g, device=device))
+            else:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g, device=device) * fan_in ** -0.5)
+    S = 256
+    x = torch.randn(3, 3, S, S, generator=g, device=device)
+    lr = torch.randn(3, 3, S, S, generator=g, device=device)
+    cond = torch.rand(3, 3, S, S, generator=g, device=device)
+    t = torch.tensor([0.3, -2.0, 4.0], device=device)
+    tl = torch.full((3,), -1.1, device=device)
+    run = lambda sl: u(x[sl], t[sl], lowres_cond_img=lr[sl], lowres_noise_times=tl[sl], cond_images=cond[sl])
+    full = run(slice(0, 3))
+    assert torch.isfinite(full).all() and full.std() > 1e-3
+    assert torch.equal(full, run(slice(0, 3)))
+    for i in range(3):
+        single = run(slice(i, i + 1))
+        assert H.rel_l2(single, full[i:i + 1]) < 1e-5, i
+    other = u(x[:1], t[:1], lowres_cond_img=lr[:1], lowres_noise_times=tl[:1], cond_images=1 - cond[:1])
+    assert H.rel_l2(other, full[:1]) > 1e-3
