@@ -59,6 +59,9 @@ int64_t conv_macs(const ConvParams& p);
 int launch_pack_oihw(const float* w_oihw, float* w_packed, int O, int I, int Ipad, int KH, int KW, hipStream_t s);
 // OIHW -> row-run layout [KH][O][KW*Ipad] (zero for i >= I)
 int launch_pack_oihw_rowrun(const float* w_oihw, float* w_packed, int O, int I, int Ipad, int KH, int KW, hipStream_t s);
+// same, for the input-channel subset [a0,a0+na) U [b0,b0+nb) of an OIHW tensor with Itot input channels
+int launch_pack_oihw_rowrun_sub(const float* w_oihw, float* w_packed, int O, int Itot, int a0, int na, int b0, int nb,
+                                int Ipad, int KH, int KW, hipStream_t s);
 // Downsample conv1x1 over pixel-unshuffled input ([O][4C], k = c*4+s1*2+s2) -> [tap=s1*2+s2][O][C]
 int launch_pack_unshuffle(const float* w, float* w_packed, int O, int C, hipStream_t s);
 // PixelShuffle conv1x1 ([4Co][I], n = c*4+i*2+j) -> rows n' = (i*2+j)*Co + c ; same for bias
@@ -114,6 +117,13 @@ int launch_gca_pool(const float* x, const float* wk, const float* bk, float* log
 size_t gca_scratch_floats(int B, int HW, int C);
 // time embedding: out[b][0]=t, [1..h]=sin(t*w*2pi), [h+1..2h]=cos
 int launch_sinu_emb(const float* t, const float* w, float* out, int B, int half, hipStream_t s);
+
+// ---- final conv to 3 channels (kernels_final.hip)
+int launch_pack_final(const float* w_oihw, float* w_packed, int Ctot, int C, hipStream_t s);
+int launch_final_static(const float* lowres, const float* w_oihw, const float* bias, float* stat, int Ctot, int c0,
+                        int B, int H, int W, hipStream_t s);
+int launch_final_gather(const float* P, const float* stat, const float* bias, float* out, int B, int H, int W,
+                        hipStream_t s);
 
 // ---- text conditioning helpers (kernels_text.hip)
 int launch_text_select(const float* tok, const float* mask, const float* null_embed, float* out, int B, int L, int P,

@@ -139,6 +139,9 @@ struct kd_unet {
   float* out = nullptr;
   // text-conditioning sub-plan (present iff cfg.cond_on_text && cfg.text_tokens > 0)
   std::vector<std::function<int(hipStream_t)>> text_ops;
+  // step-invariant part of the forward (init conv over the cond / low-res planes): run once per
+  // sampling call, before the captured per-step graph
+  std::vector<std::function<int(hipStream_t)>> static_ops;
   int text_embed_dim = 0, max_text_len = 0;
   const float *in_text_embeds = nullptr, *in_text_mask = nullptr;
   int in_text_len = 0, in_text_drop = 0;
@@ -182,6 +185,7 @@ struct Builder {
   T t_ss;  // [B, tmlp_total] scale|shift rows for all blocks
   // shared scratch
   T gn_stats_t, gn_partial_t;
+  T init_x_;  // output of the init conv (set inside a nested scope of build())
   size_t gn_partial_max = 0;
 
   Builder(kd_unet* u_) : u(u_), cfg(u_->cfg), B(u_->cfg.batch) {}
@@ -225,6 +229,14 @@ struct Builder {
     return dst;
   }
 
+  const float* pack_conv_rowrun_sub(const std::string& n, int O, int Itot, int a0, int na, int b0, int nb, int Ipad,
+                                    int K) {
+    const float* src = raw(n, (int64_t)O * Itot * K * K);
+    float* dst = u->wpool.alloc((size_t)O * Ipad * K * K);
+    KD_THROW_IF(launch_pack_oihw_rowrun_sub(src, dst, O, Itot, a0, na, b0, nb, Ipad, K, K, 0));
+    return dst;
+  }
+
   // ---- activations
   T alloc(int b, int h, int w, int c) {
     T t;
@@ -252,11 +264,16 @@ struct Builder {
       arena.release(t.off);
     }
   }
-  bool to_text = false;  // building the text-conditioning sub-plan: ops go to u->text_ops
+  bool to_text = false;    // building the text-conditioning sub-plan: ops go to u->text_ops
+  bool to_static = false;  // emitting step-invariant work (run once per sampling call): u->static_ops
   const float* P_(const std::string& n) { return P(n); }
   void emit(std::function<int(hipStream_t)> f, std::string label = "op", int64_t macs = 0) {
     if (to_text) {
       u->text_ops.push_back(std::move(f));
+      return;
+    }
+    if (to_static) {
+      u->static_ops.push_back(std::move(f));
       return;
     }
     u->ops.push_back(std::move(f));
@@ -276,6 +293,8 @@ struct Builder {
     int cin_logical = -1;
     bool out_external = false;  // OUT_NCHW into u->out
     bool rowrun = false;        // small-Cin wide-window conv: weights from pack_conv_rowrun
+    int res_coff = 0;           // channel offset into res (res row stride stays res->C)
+    int64_t macs_override = -1; // algorithmic MACs when the launch computes padded / re-associated work
   };
   T conv(const T& x, const float* w, const float* bias, int Cout, int K, int stride, int pad, const ConvOpt& o) {
     int Ho = (x.H + 2 * pad - K) / stride + 1, Wo = (x.W + 2 * pad - K) / stride + 1;
@@ -309,24 +328,27 @@ struct Builder {
     bool has_res = o.res != nullptr, has_gs = o.gate_src != nullptr, ext = o.out_external;
     size_t ro = has_res ? o.res->off : 0, gso = has_gs ? o.gate_src->off : 0, go = has_gs ? o.gate->off : 0;
     kd_unet* uu = u;
+    const int res_coff = o.res_coff;
     emit([=](hipStream_t s) {
       ConvParams q = p;
       q.x = uu->P(xo);
       q.y = ext ? uu->out : uu->P(yo);
-      q.res = has_res ? uu->P(ro) : nullptr;
+      q.res = has_res ? uu->P(ro) + res_coff : nullptr;
       q.gate_src = has_gs ? uu->P(gso) : nullptr;
       q.gate = has_gs ? uu->P(go) : nullptr;
       return launch_conv_igemm(q, s);
     });
     int cin = o.cin_logical > 0 ? o.cin_logical : x.C;
-    int64_t m = (int64_t)x.B * Ho * Wo * Cout * cin * K * K;
-    if (!to_text) {
+    int64_t m = o.macs_override >= 0 ? o.macs_override : (int64_t)x.B * Ho * Wo * Cout * cin * K * K;
+    if (!to_text && !to_static) {
       u->op_label.back() = "conv k" + std::to_string(K) + " s" + std::to_string(stride) + " M" +
                            std::to_string((int64_t)x.B * Ho * Wo) + " Cin" + std::to_string(x.C) + " Cout" +
                            std::to_string(Cout);
       u->op_macs.back() = m;
-      u->macs += m;
     }
+    // algorithmic MACs of one forward as the reference computes it: the step-invariant part of the
+    // init conv is counted even though the engine runs it once per sampling call instead of per step
+    if (!to_text) u->macs += m;
     return y;
   }
   // token GEMM y[M,N] = x[M,K] @ w[N,K]^T

@@ -518,6 +518,33 @@ int launch_pack_oihw_rowrun(const float* w, float* out, int O, int Ireal, int I,
   return 0;
 }
 
+// Row-run packing of a SUBSET of the input channels: packed channel i comes from source channel
+// a0+i (i < na) or b0+(i-na) (i < na+nb), zero above; Itot = channels of the OIHW source.
+__global__ void pack_oihw_rowrun_sub_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int Itot,
+                                            int a0, int na, int b0, int nb, int I, int KH, int KW) {
+  int64_t total = (int64_t)O * I * KH * KW;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int i = (int)(idx % I);
+    int64_t t = idx / I;
+    int kw = (int)(t % KW);
+    t /= KW;
+    int o = (int)(t % O);
+    int kh = (int)(t / O);
+    int src = i < na ? a0 + i : (i < na + nb ? b0 + (i - na) : -1);
+    out[idx] = src >= 0 ? w[(((int64_t)o * Itot + src) * KH + kh) * KW + kw] : 0.f;
+  }
+}
+int launch_pack_oihw_rowrun_sub(const float* w, float* out, int O, int Itot, int a0, int na, int b0, int nb, int I,
+                                int KH, int KW, hipStream_t s) {
+  int64_t total = (int64_t)O * I * KH * KW;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_oihw_rowrun_sub_kernel, dim3(blocks), dim3(256), 0, s, w, out, O, Itot, a0, na, b0, nb, I,
+                     KH, KW);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 __global__ void pack_unshuffle_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int C) {
   int64_t total = (int64_t)O * C * 4;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;

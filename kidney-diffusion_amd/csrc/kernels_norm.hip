@@ -311,7 +311,8 @@ __global__ void pack_init_kernel(const float* __restrict__ cond, int Cc, const f
     float* o = y + pix * Cpad;
     int c = 0;
     for (int i = 0; i < Cc; ++i) o[c++] = cond[(b * Cc + i) * HW + p];
-    for (int i = 0; i < 3; ++i) o[c++] = x[(b * 3 + i) * HW + p];
+    if (x)  // x == nullptr: only the step-invariant planes (cond | lowres) are packed
+      for (int i = 0; i < 3; ++i) o[c++] = x[(b * 3 + i) * HW + p];
     for (int i = 0; i < Cl; ++i) o[c++] = lowres[(b * Cl + i) * HW + p];
     for (; c < Cpad; ++c) o[c] = 0.f;
   }
