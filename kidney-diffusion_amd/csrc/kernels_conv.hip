@@ -446,7 +446,11 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
                     span * img_bytes < 0x7fffffff && (((uintptr_t)p.x | (uintptr_t)p.w) & 15) == 0;
   if (fast) {
     const int64_t tiles256 = ((M + 255) / 256) * ((p.Cout + 127) / 128);
-    if (tiles256 >= 512) {  // enough 256x128 tiles for two rounds of the 256 CUs
+    // 256x128 (one 8-wave workgroup per CU) needs a K loop long enough to amortise its serial
+    // prologue/epilogue; short-K 1x1 convs run as two 128x128 workgroups per CU, which overlap one
+    // tile's epilogue with the other's loop (measured in the step: 3x3 Cin=128 layers still prefer 256x128)
+    const int k_chunks = p.KH * p.KW * (p.Cin / BK);
+    if (tiles256 >= 512 && (p.KH * p.KW > 1 || k_chunks >= 64)) {
       dim3 grid((unsigned)((M + 255) / 256), (p.Cout + 127) / 128);
       hipLaunchKernelGGL((conv_buf_kernel<256, 128, 4, 2, 2>), grid, dim3(512), 0, s, p);
     } else if (((M + 127) / 128) * ((p.Cout + 127) / 128) >= 512) {

@@ -1,0 +1,15 @@
+import sys, ctypes as C
+sys.path.insert(0,'kidney-diffusion_amd')
+from imagen_pytorch import _engine as E
+import torch; torch.zeros(1,device='cuda')
+lib=E.load(); f=lib.kd_conv_bench; f.restype=C.c_int
+shapes=[(16,256,256,256,128,1),(16,128,128,256,128,1),(16,128,128,128,512,1),(16,64,64,512,256,1),(16,128,128,128,128,3),(16,256,256,128,128,3)]
+variants=[int(v) for v in sys.argv[1].split(',')]
+for rep in range(2):
+  for (B,H,W,Ci,Co,K) in shapes:
+    flop=2.0*B*H*W*Ci*Co*K*K; res=[]
+    for v in variants:
+        us=C.c_float(); cs=C.c_float()
+        rc=f(B,H,W,Ci,Co,K,1,K//2,v,5,C.byref(us),C.byref(cs))
+        res.append(f"v{v}:{flop/us.value/1e6:6.1f}TF {us.value:7.1f}us" if rc==0 else f"v{v}:ERR")
+    print((B,H,W,Ci,Co,K), ' '.join(res), flush=True)
