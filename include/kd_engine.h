@@ -60,6 +60,10 @@ typedef struct kd_unet_config {
   /* static shape of the plan */
   int batch;
   int image_size;             /* S: x is [batch, channels, S, S] */
+  /* 0 = auto: Winograd F(2x2,3x3) for the ResnetBlock 3x3 convs with Cin >= 256, direct implicit
+   * GEMM elsewhere; 1 = direct implicit GEMM everywhere (bitwise the k-ordered fmaf chain);
+   * n >= 32 = Winograd from Cin >= n (experiments / tests) */
+  int conv_algo;
 } kd_unet_config_t;
 
 /* One named parameter tensor of the UNet's state_dict (key WITHOUT the `unets.N.` prefix,
@@ -186,6 +190,11 @@ int kd_sample_finalize(kd_unet_t* u, const kd_sample_args_t* args, float* d_img,
 int kd_conv2d_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias, float* d_y,
                    int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad,
                    int act, void* stream);
+/* The same 3x3 / stride-1 / pad-1 convolution through the plan's Winograd F(2x2,3x3) path (used for
+ * the deep ResnetBlock convs): fp32, differs from kd_conv2d_nhwc by re-association
+ * only.  Needs even H, W; B*H*W/4 % 256 == 0; Cin % 32 == 0; Cout > 32. */
+int kd_conv3x3_winograd_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias, float* d_y,
+                             int B, int H, int W, int Cin, int Cout, void* stream);
 /* GroupNorm(G) + optional FiLM (scale+1, shift: [B,2C] = [scale | shift]) + SiLU, NHWC. */
 int kd_groupnorm_silu_nhwc(const float* d_x, const float* d_gamma, const float* d_beta,
                            const float* d_scale_shift, float* d_y, int B, int HW, int C, int G,

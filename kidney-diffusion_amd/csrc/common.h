@@ -49,6 +49,9 @@ struct ConvParams {
   int ldgs;
   int out_mode;
   int ldy, yoff;          // OUT_NHWC: y[m*ldy + yoff + n]
+  // batched 1x1 GEMM (Winograd positions): rows [z*wz_rows, (z+1)*wz_rows) use weight slab z of
+  // wz_count slabs [Cout][Cin]; 0 = one weight tensor.  wz_rows must be a multiple of 256.
+  int wz_rows, wz_count;
 };
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s);
@@ -67,6 +70,17 @@ int launch_pack_unshuffle(const float* w, float* w_packed, int O, int C, hipStre
 // PixelShuffle conv1x1 ([4Co][I], n = c*4+i*2+j) -> rows n' = (i*2+j)*Co + c ; same for bias
 int launch_pack_shuffle(const float* w, const float* b, float* w_packed, float* b_packed, int Co, int I,
                         hipStream_t s);
+
+// ---- Winograd F(2x2,3x3) transforms (kernels_wino.hip)
+// OIHW 3x3 weights -> U [16][O][I]
+int launch_wino_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s);
+// V[p][t][c] = (B^T d B)[p] of the 4x4 input tile of output tile t, d = SiLU(GroupNorm/FiLM(x)) when
+// stats != nullptr (same arguments as launch_gn_apply_silu), d = x otherwise; zero padding outside
+int launch_wino_in(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
+                   const float* scale_shift, int ld_ss, float* V, int B, int H, int W, int C, int G, hipStream_t s);
+// y[b][2ty+i][2tx+j][n] = (A^T D A)[i][j] + bias[n] (+ res)
+int launch_wino_out(const float* D, const float* bias, const float* res, int ldres, float* y, int B, int H, int W,
+                    int C, hipStream_t s);
 
 // ---- norms / elementwise (kernels_norm.hip)
 int launch_gn_stats(const float* x, int ldx, float* stats /*[B][G][2] mean,rstd*/, double* partial,

@@ -295,6 +295,7 @@ struct Builder {
     bool rowrun = false;        // small-Cin wide-window conv: weights from pack_conv_rowrun
     int res_coff = 0;           // channel offset into res (res row stride stays res->C)
     int64_t macs_override = -1; // algorithmic MACs when the launch computes padded / re-associated work
+    int wz_rows = 0;            // batched 1x1 GEMM over 16 Winograd positions (ConvParams::wz_rows)
   };
   T conv(const T& x, const float* w, const float* bias, int Cout, int K, int stride, int pad, const ConvOpt& o) {
     int Ho = (x.H + 2 * pad - K) / stride + 1, Wo = (x.W + 2 * pad - K) / stride + 1;
@@ -319,6 +320,8 @@ struct Builder {
       p.Cin = K * x.C;
       p.rr_cin = x.C;
     }
+    p.wz_rows = o.wz_rows;
+    p.wz_count = o.wz_rows > 0 ? 16 : 0;
     p.act = o.act; p.out_mode = o.out_mode;
     p.ldy = (o.out_mode == OUT_NHWC || o.out_mode == OUT_PIXSHUF) ? y.C : 0;
     p.yoff = o.yoff;
@@ -518,15 +521,74 @@ struct Builder {
     return gate;
   }
 
+  // ---- Winograd F(2x2,3x3) for the `Block` = GroupNorm -> [FiLM] -> SiLU -> conv3x3 of deep layers
+  // (kernels_wino.hip).  Worth it where the 2.25x smaller GEMM outweighs moving 4x the map through
+  // the transforms: measured on MI355X, Cin >= 256 wins and Cin = 128 loses (profiles/README.md).
+  // cfg.conv_algo: 0 auto, 1 never, >= 32 explicit Cin threshold (experiments, tests).
+  bool wino_ok(const T& x, int cout) const {
+    if (cfg.conv_algo == 1) return false;
+    const int min_cin = cfg.conv_algo >= 32 ? cfg.conv_algo : 256;
+    if ((x.H & 1) || (x.W & 1) || x.C < min_cin || x.C % 32 || cout <= 32 || cout % 4) return false;
+    const int64_t Mt = (int64_t)x.B * (x.H / 2) * (x.W / 2);
+    return Mt % 256 == 0 && 16 * Mt < 0x7fffffff && (int64_t)16 * cout * x.C * 4 < 0x7fffffff;
+  }
+  T wino_block(const T& x, const std::string& gn_prefix, int ss_col, const std::string& conv_prefix, int Cout,
+               const T* res) {
+    const int Cin = x.C, G = cfg.resnet_groups, Bx = x.B, H = x.H, W = x.W, HW = x.HW();
+    const int64_t Mt = (int64_t)Bx * (H / 2) * (W / 2);
+    const float* gamma = P(gn_prefix + ".weight", Cin);
+    const float* beta = P(gn_prefix + ".bias", Cin);
+    const float* bias = P(conv_prefix + ".bias", Cout);
+    float* U = u->wpool.alloc((size_t)16 * Cout * Cin);
+    KD_THROW_IF(launch_wino_pack(raw(conv_prefix + ".weight", (int64_t)Cout * Cin * 9), U, Cout, Cin, 0));
+    if (gn_partial_bytes(Bx, HW, Cin, G) > gn_partial_max) throw std::runtime_error("gn partial scratch too small");
+    T V = alloc(1, 1, (int)(16 * Mt), Cin);
+    {
+      size_t xo = x.off, vo = V.off, so = gn_stats_t.off, po = gn_partial_t.off, sso = t_ss.off;
+      int ld = tmlp_total;
+      kd_unet* uu = u;
+      emit([=](hipStream_t s) {
+        if (launch_gn_stats(uu->P(xo), Cin, uu->P(so), (double*)uu->P(po), Bx, HW, Cin, G, 1e-5f, s)) return 1;
+        const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
+        return launch_wino_in(uu->P(xo), Cin, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s);
+      }, "gn+wino_in HW" + std::to_string(HW) + " C" + std::to_string(Cin));
+    }
+    ConvOpt o;
+    o.wz_rows = (int)Mt;
+    o.macs_override = (int64_t)Bx * HW * Cout * Cin * 9;  // algorithmic MACs of the 3x3 conv it replaces
+    T D = conv(V, U, nullptr, Cout, 1, 1, 0, o);
+    if (!to_text && !to_static)
+      u->op_label.back() = "wino gemm M" + std::to_string((int64_t)Bx * HW) + " Cin" + std::to_string(Cin) + " Cout" +
+                           std::to_string(Cout);
+    free(V);
+    T y = alloc(Bx, H, W, Cout);
+    {
+      size_t d_o = D.off, yo = y.off, ro = res ? res->off : 0;
+      bool hr = res != nullptr;
+      int ldres = res ? res->C : 0;
+      kd_unet* uu = u;
+      emit([=](hipStream_t s) {
+        return launch_wino_out(uu->P(d_o), bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W, Cout, s);
+      }, "wino_out HW" + std::to_string(HW) + " C" + std::to_string(Cout));
+    }
+    free(D);
+    return y;
+  }
+
   // ResnetBlock.  Does NOT free x.
   T resnet(const T& x, const std::string& pre, int dim_out, const T* ctx, bool use_gca) {
     bool has_cross = has(pre + ".cross_attn.to_q.weight");
     if (has_cross && !ctx) throw std::runtime_error("cross-attention block without conditioning tokens: " + pre);
     int dim_in = x.C;
-    T y1 = gn_silu(x, pre + ".block1.groupnorm", nullptr, 0);
-    T h = conv(y1, pack_conv(pre + ".block1.project.weight", dim_out, dim_in, dim_in, 3),
+    T h;
+    if (wino_ok(x, dim_out)) {
+      h = wino_block(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
+    } else {
+      T y1 = gn_silu(x, pre + ".block1.groupnorm", nullptr, 0);
+      h = conv(y1, pack_conv(pre + ".block1.project.weight", dim_out, dim_in, dim_in, 3),
                P(pre + ".block1.project.bias", dim_out), dim_out, 3, 1, 1, ConvOpt());
-    free(y1);
+      free(y1);
+    }
     if (has_cross) {
       T h2 = cross_attn(h, pre + ".cross_attn", *ctx);
       free(h);
@@ -534,8 +596,14 @@ struct Builder {
     }
     auto it = tmlp_off.find(pre);
     int ss_col = it != tmlp_off.end() ? it->second : -1;
-    T y2;
-    {
+    bool has_res_conv = has(pre + ".res_conv.weight");
+    T h2;
+    if (wino_ok(h, dim_out)) {
+      h2 = wino_block(h, pre + ".block2.groupnorm", ss_col, pre + ".block2.project", dim_out,
+                      (!use_gca && !has_res_conv) ? &x : nullptr);
+      free(h);
+    } else {
+      T y2;
       // scale/shift rows live in t_ss at column ss_col (row stride tmlp_total)
       const float* gamma = P(pre + ".block2.groupnorm.weight", dim_out);
       const float* beta = P(pre + ".block2.groupnorm.bias", dim_out);
@@ -549,14 +617,13 @@ struct Builder {
         const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
         return launch_gn_apply_silu(uu->P(xo), C, uu->P(so), gamma, beta, ssp, ld, uu->P(yo), Bx, HW, C, G, s);
       }, "gn HW" + std::to_string(HW) + " C" + std::to_string(C));
-    }
-    bool has_res_conv = has(pre + ".res_conv.weight");
-    ConvOpt o2;
-    if (!use_gca && !has_res_conv) o2.res = &x;  // h2 + x folded into the conv epilogue
-    free(h);
-    T h2 = conv(y2, pack_conv(pre + ".block2.project.weight", dim_out, dim_out, dim_out, 3),
+      ConvOpt o2;
+      if (!use_gca && !has_res_conv) o2.res = &x;  // h2 + x folded into the conv epilogue
+      free(h);
+      h2 = conv(y2, pack_conv(pre + ".block2.project.weight", dim_out, dim_out, dim_out, 3),
                 P(pre + ".block2.project.bias", dim_out), dim_out, 3, 1, 1, o2);
-    free(y2);
+      free(y2);
+    }
     if (!use_gca && !has_res_conv) return h2;
     T out;
     if (use_gca) {

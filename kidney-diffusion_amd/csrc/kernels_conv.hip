@@ -294,22 +294,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
   const int lrow = tid >> 3;
   const int gseg = (tid & 7) ^ ((lrow >> 1) & 7);
 
-  // activations: buffer based at the image of the tile's first pixel (keeps offsets < 2^31)
+  // activations: buffer based at the image of the tile's first pixel (keeps offsets < 2^31); a pure
+  // GEMM (1x1, stride 1, no padding) has contiguous rows and is based at the tile's first row
+  // instead, so tensors of any size work (the Winograd V/D matrices exceed 2 GiB)
+  const bool gemm = p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0;
   const int hw = p.Ho * p.Wo;
-  const int img0 = (int)(m0 / hw);
+  const int img0 = gemm ? 0 : (int)(m0 / hw);
   const int64_t img_elems = (int64_t)p.Hi * p.Wi * p.ldx;
-  const int64_t a_total = ((int64_t)p.B - img0) * img_elems * 4;
+  const int64_t a_total = gemm ? (M - m0 < BM ? M - m0 : (int64_t)BM) * p.ldx * 4 : ((int64_t)p.B - img0) * img_elems * 4;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.x + (int64_t)img0 * img_elems), 0, (int)(a_total > 0x7fffffff ? 0x7fffffff : a_total), 0x00020000);
+      (void*)(p.x + (gemm ? m0 * p.ldx : (int64_t)img0 * img_elems)), 0,
+      (int)(a_total > 0x7fffffff ? 0x7fffffff : a_total), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.w, 0, (int)((int64_t)p.KH * p.KW * p.Cout * p.Cin * 4), 0x00020000);
+      (void*)p.w, 0, (int)((int64_t)(p.wz_rows > 0 ? p.wz_count : p.KH * p.KW) * p.Cout * p.Cin * 4), 0x00020000);
+  // batched GEMM: the whole tile lies in one weight slab (wz_rows % BM == 0)
+  const uint32_t wz_off = p.wz_rows > 0 ? (uint32_t)(m0 / p.wz_rows) * (uint32_t)(p.Cout * p.Cin * 4) : 0u;
 
   int a_iy0[A_PASSES], a_ix0[A_PASSES];
   int a_img[A_PASSES];  // pixel offset of the row's image relative to img0, or -1 past the edge
 #pragma unroll
   for (int q = 0; q < A_PASSES; ++q) {
     int64_t m = m0 + lrow + q * ROWS_PER_PASS;
-    if (m < M) {
+    if (m < M && gemm) {
+      a_iy0[q] = 0;
+      a_ix0[q] = 0;
+      a_img[q] = lrow + q * ROWS_PER_PASS;
+    } else if (m < M) {
       int b = (int)(m / hw);
       int rem = (int)(m - (int64_t)b * hw);
       int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -342,11 +352,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
 #pragma unroll
     for (int q = 0; q < A_PASSES; ++q) {
       int iy = a_iy0[q] + kh, ix = a_ix0[q] + kw;
-      bool ok = a_img[q] >= 0 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-      voffA[q] = ok ? (uint32_t)(((a_img[q] + iy * p.Wi + ix) * p.ldx + gseg * 4) * 4) : OOB_OFF;
+      bool ok = a_img[q] >= 0 && (gemm || (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi));
+      int pix = gemm ? a_img[q] : a_img[q] + iy * p.Wi + ix;
+      voffA[q] = ok ? (uint32_t)((pix * p.ldx + gseg * 4) * 4) : OOB_OFF;
     }
     soffA = 0;
-    soffB = (uint32_t)cur_tap * tap_stride_b;
+    soffB = (uint32_t)cur_tap * tap_stride_b + wz_off;
   };
   auto issue = [&](float* stage_base) {  // DMA of the next K-chunk into the given stage
     if (cur_cc == chunks_per_tap) next_tap();
@@ -436,14 +447,18 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
   if (p.out_mode == OUT_PIXSHUF) KD_REQUIRE(p.Cout % 4 == 0, "pixel-shuffle needs Cout % 4 == 0");
   int64_t M = (int64_t)p.B * p.Ho * p.Wo;
   KD_REQUIRE(M > 0 && p.Cout > 0, "empty conv");
-  const int64_t w_bytes = (int64_t)p.KH * p.KW * p.Cout * p.Cin * 4;
+  const int64_t w_bytes = (int64_t)(p.wz_rows > 0 ? p.wz_count : p.KH * p.KW) * p.Cout * p.Cin * 4;
+  if (p.wz_rows > 0)
+    KD_REQUIRE(p.KH * p.KW == 1 && p.wz_rows % 256 == 0 && M == (int64_t)p.wz_rows * p.wz_count,
+               "batched GEMM: 1x1 only, slab rows a multiple of 256, M = rows x slabs");
   // the fast kernel addresses the activations with 32-bit byte offsets relative to the image of the
   // tile's first pixel: every image a 256-row tile can touch must lie within 2^31 bytes of it
   const int64_t img_bytes = (int64_t)p.Hi * p.Wi * p.ldx * 4;
   const int64_t hw_o = (int64_t)p.Ho * p.Wo;
   const int64_t span = (hw_o % 256 == 0) ? 1 : 255 / hw_o + 2;
+  const bool gemm = p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0;  // based per tile: no size limit
   const bool fast = p.rr_cin == 0 && (p.Cin % BK) == 0 && p.Cout > 32 && M > 64 && w_bytes < 0x7fffffff &&
-                    span * img_bytes < 0x7fffffff && (((uintptr_t)p.x | (uintptr_t)p.w) & 15) == 0;
+                    (gemm || span * img_bytes < 0x7fffffff) && (((uintptr_t)p.x | (uintptr_t)p.w) & 15) == 0;
   if (fast) {
     const int64_t tiles256 = ((M + 255) / 256) * ((p.Cout + 127) / 128);
     // 256x128 (one 8-wave workgroup per CU) needs a K loop long enough to amortise its serial
@@ -460,6 +475,8 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
       dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 63) / 64);
       hipLaunchKernelGGL((conv_buf_kernel<128, 64, 2, 2, 3>), grid, dim3(256), 0, s, p);
     }
+  } else if (p.wz_rows > 0) {
+    KD_REQUIRE(false, "batched GEMM needs the buffer-load fast path (Cin % 32 == 0, Cout > 32)");
   } else if (p.Cout <= 32) {
     dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 31) / 32);
     hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, p);

@@ -1,0 +1,202 @@
+// Winograd F(2x2,3x3) transforms for the deep 3x3 convolutions of the ResnetBlocks.
+//
+//   y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A          (Lavin & Gray; the same identity cuDNN /
+//                                                          MIOpen select for fp32 3x3 stride-1 convs)
+//
+// A 3x3 / stride 1 / pad 1 conv over [B,H,W,Cin] becomes 16 independent GEMMs
+// D_p[t][n] = sum_c V_p[t][c] * U_p[n][c], one per position p of the 4x4 transformed tile, over the
+// Mt = B*(H/2)*(W/2) output tiles: 16*Mt*Cin*Cout MACs instead of 36*Mt*Cin*Cout (2.25x fewer MFMA
+// issues).  The GEMMs run on the fast implicit-GEMM kernel (kernels_conv.hip, weight slab selected
+// by tile row: ConvParams::wz_rows); this file holds the three HBM-bound transform kernels:
+//
+//   wino_pack  (plan build)  OIHW weights            -> U [16][Cout][Cin]
+//   wino_in    (per step)    GroupNorm+FiLM+SiLU(x)  -> V [16][Mt][Cin]   (replaces gn_apply: the
+//                                                       normalised map is never materialised)
+//   wino_out   (per step)    D [16][Mt][Cout]        -> y NHWC, + bias (+ residual)
+//
+// The transforms move 4x the feature map, so the plan uses this path only where the GEMM saving
+// outweighs that traffic (measured: Cin >= 256 wins, Cin = 128 loses); everything is fp32, the
+// result differs from the direct conv by re-association only (tests: <= 4e-6 relative L2).
+#include "common.h"
+
+namespace kd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wino_silu(float v) { return v / (1.0f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int O,
+                                                        int I) {
+  const int64_t total = (int64_t)O * I;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const float* g = w + idx * 9;
+    float t[4][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float g0 = g[k], g1 = g[3 + k], g2 = g[6 + k];
+      t[0][k] = g0;
+      t[1][k] = 0.5f * (g0 + g1 + g2);
+      t[2][k] = 0.5f * (g0 - g1 + g2);
+      t[3][k] = g2;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float u[4] = {t[r][0], 0.5f * (t[r][0] + t[r][1] + t[r][2]), 0.5f * (t[r][0] - t[r][1] + t[r][2]), t[r][2]};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) U[(int64_t)(r * 4 + s) * total + idx] = u[s];
+    }
+  }
+}
+
+int launch_wino_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s) {
+  int64_t total = (int64_t)O * I;
+  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, U, O, I);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// One thread: one output tile x 4 channels.  Threads run along channels first (16-B coalesced).
+__global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ x, int ldx,
+                                                      const float* __restrict__ stats,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      const float* __restrict__ scale_shift, int ld_ss,
+                                                      float* __restrict__ V, int B, int H, int W, int C, int G) {
+  const int C4 = C >> 2;
+  const int Ht = H >> 1, Wt = W >> 1;
+  const int64_t Mt = (int64_t)B * Ht * Wt;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Mt * C4) return;
+  const int c4 = (int)(idx % C4);
+  const int64_t t = idx / C4;
+  const int tx = (int)(t % Wt);
+  const int ty = (int)((t / Wt) % Ht);
+  const int b = (int)(t / ((int64_t)Wt * Ht));
+
+  float A[4], Bc[4];
+  const bool norm = stats != nullptr;
+  if (norm) {
+    const int Cg = C / G;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // same folding as gn_apply_silu_kernel (kernels_norm.hip)
+      int c = c4 * 4 + e;
+      int g = c / Cg;
+      float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+      float a = rstd * gamma[c];
+      float bb = beta[c] - mean * a;
+      if (scale_shift) {
+        float sc = scale_shift[(int64_t)b * ld_ss + c] + 1.0f;
+        float sh = scale_shift[(int64_t)b * ld_ss + C + c];
+        a *= sc;
+        bb = bb * sc + sh;
+      }
+      A[e] = a;
+      Bc[e] = bb;
+    }
+  }
+
+  f32x4 d[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int iy = 2 * ty - 1 + r;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int ix = 2 * tx - 1 + s;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        v = *(const f32x4*)(x + (((int64_t)b * H + iy) * W + ix) * ldx + c4 * 4);
+        if (norm) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = wino_silu(v[e] * A[e] + Bc[e]);
+        }
+      }
+      d[r][s] = v;
+    }
+  }
+  // B^T d
+  f32x4 u[4][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    u[0][s] = d[0][s] - d[2][s];
+    u[1][s] = d[1][s] + d[2][s];
+    u[2][s] = d[2][s] - d[1][s];
+    u[3][s] = d[1][s] - d[3][s];
+  }
+  // (B^T d) B
+  float* out = V + t * C + c4 * 4;
+  const int64_t pstride = Mt * C;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    *(f32x4*)(out + (int64_t)(r * 4 + 0) * pstride) = u[r][0] - u[r][2];
+    *(f32x4*)(out + (int64_t)(r * 4 + 1) * pstride) = u[r][1] + u[r][2];
+    *(f32x4*)(out + (int64_t)(r * 4 + 2) * pstride) = u[r][2] - u[r][1];
+    *(f32x4*)(out + (int64_t)(r * 4 + 3) * pstride) = u[r][1] - u[r][3];
+  }
+}
+
+int launch_wino_in(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
+                   const float* scale_shift, int ld_ss, float* V, int B, int H, int W, int C, int G,
+                   hipStream_t s) {
+  KD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && H % 2 == 0 && W % 2 == 0, "Winograd input transform needs even H, W and C % 4 == 0");
+  int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, stats, gamma,
+                     beta, scale_shift, ld_ss, V, B, H, W, C, G);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ D, const float* __restrict__ bias,
+                                                       const float* __restrict__ res, int ldres,
+                                                       float* __restrict__ y, int B, int H, int W, int C) {
+  const int C4 = C >> 2;
+  const int Ht = H >> 1, Wt = W >> 1;
+  const int64_t Mt = (int64_t)B * Ht * Wt;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Mt * C4) return;
+  const int c4 = (int)(idx % C4);
+  const int64_t t = idx / C4;
+  const int tx = (int)(t % Wt);
+  const int ty = (int)((t / Wt) % Ht);
+  const int b = (int)(t / ((int64_t)Wt * Ht));
+  const float* in = D + t * C + c4 * 4;
+  const int64_t pstride = Mt * C;
+  f32x4 m[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) m[r][s] = *(const f32x4*)(in + (int64_t)(r * 4 + s) * pstride);
+  f32x4 u[2][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    u[0][s] = m[0][s] + m[1][s] + m[2][s];
+    u[1][s] = m[1][s] - m[2][s] - m[3][s];
+  }
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = *(const f32x4*)(bias + c4 * 4);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    f32x4 o0 = u[i][0] + u[i][1] + u[i][2] + bv;
+    f32x4 o1 = u[i][1] - u[i][2] - u[i][3] + bv;
+    const int64_t pix = ((int64_t)b * H + 2 * ty + i) * W + 2 * tx;
+    if (res) {
+      o0 += *(const f32x4*)(res + pix * ldres + c4 * 4);
+      o1 += *(const f32x4*)(res + (pix + 1) * ldres + c4 * 4);
+    }
+    *(f32x4*)(y + pix * C + c4 * 4) = o0;
+    *(f32x4*)(y + (pix + 1) * C + c4 * 4) = o1;
+  }
+}
+
+int launch_wino_out(const float* D, const float* bias, const float* res, int ldres, float* y, int B, int H, int W,
+                    int C, hipStream_t s) {
+  KD_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "Winograd output transform needs even H, W and C % 4 == 0");
+  int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(wino_out_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, D, bias, res, ldres, y,
+                     B, H, W, C);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace kd

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Callable, Optional
 
 import torch
@@ -367,7 +368,9 @@ class Unet(nn.Module):
         E.require_gpu()
         lib = E.load()
         device = torch.device(device)
-        key = (batch, image_size, device.index, bool(with_text))
+        # engine extension (not a library kwarg): 0 = auto (Winograd for the deep 3x3 convs), 1 = direct only
+        conv_algo = int(getattr(self, "conv_algo", os.environ.get("KD_CONV_ALGO", "0")))
+        key = (batch, image_size, device.index, bool(with_text), conv_algo)
         if key in self._engines:
             return self._engines[key]
         p = self._plan
@@ -395,6 +398,7 @@ class Unet(nn.Module):
         cfg.resnet_groups = p["groups"]
         cfg.attend_at_middle, cfg.use_gca = int(p["attend_at_middle"]), int(p["use_gca"])
         cfg.batch, cfg.image_size = batch, image_size
+        cfg.conv_algo = conv_algo
 
         with torch.cuda.device(device):
             sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous()

@@ -76,6 +76,45 @@ def test_conv_igemm(lib, device, B, H, W, Cin, Cout, K, stride, pad, act):
     assert err <= max(3 * err_cpu, CONV_REL), (err, err_cpu)
 
 
+# Winograd F(2x2,3x3) re-associates the sum (4x4 tile transforms): fp32 error a few x the direct conv's
+WINO_REL = 4e-6
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (16, 16, 16, 512, 512),    # Mt = 1024: the SR UNet's deepest level
+    (4, 32, 32, 64, 96),       # ragged N tile, several images per weight slab
+    (1, 64, 32, 32, 40),       # Mt = 512, one image
+    (4, 16, 16, 1024, 128),    # long K, Mt = 256 (one 256-row tile per slab)
+])
+def test_conv3x3_winograd_matches_direct(lib, device, B, H, W, Cin, Cout):
+    E = _E()
+    x = torch.randn(B, Cin, H, W, generator=g(1))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g(2)) * (Cin * 9) ** -0.5
+    b = torch.randn(Cout, generator=g(3))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(device)
+    wd, bd = w.to(device), b.to(device)
+    y = torch.full((B, H, W, Cout), float("nan"), device=device)
+    yd = torch.full((B, H, W, Cout), float("nan"), device=device)
+    E.check(lib.kd_conv3x3_winograd_nhwc(E.ptr(xd), E.ptr(wd), E.ptr(bd), E.ptr(y), B, H, W, Cin, Cout,
+                                         E.current_stream()))
+    E.check(lib.kd_conv2d_nhwc(E.ptr(xd), E.ptr(wd), E.ptr(bd), E.ptr(yd), B, H, W, Cin, Cout, 3, 3, 1, 1, 0,
+                                E.current_stream()))
+    got, direct = y.permute(0, 3, 1, 2).cpu().double(), yd.permute(0, 3, 1, 2).cpu().double()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).norm() / ref.norm())
+    err_direct = float((direct - ref).norm() / ref.norm())
+    assert err <= WINO_REL, (err, err_direct)
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), "element-wise outlier"
+
+
+def test_conv3x3_winograd_rejects_unsupported_shapes(lib, device):
+    E = _E()
+    t = torch.zeros(16, device=device)
+    rc = lib.kd_conv3x3_winograd_nhwc(E.ptr(t), E.ptr(t), None, E.ptr(t), 1, 15, 16, 32, 64, E.current_stream())
+    assert rc != 0 and b"even" in lib.kd_last_error()
+
+
 @pytest.mark.parametrize("B,HW,C,G,film", [(2, 64, 32, 8, False), (3, 100, 96, 8, True), (1, 4096, 128, 8, True),
                                            (2, 16, 1024, 8, True), (2, 300, 384, 8, False)])
 def test_groupnorm_film_silu(lib, device, B, HW, C, G, film):

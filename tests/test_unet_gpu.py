@@ -49,6 +49,35 @@ def test_unet_forward_matches_oracle(device, name, lowres, B, S):
     assert torch.equal(got, got2)
 
 
+def test_unet_forward_with_winograd_levels_matches_oracle(device):
+    """The plan's Winograd F(2x2,3x3) path (deep ResnetBlock convs; GroupNorm+FiLM+SiLU fused into the
+    input transform).  conv_algo=32 lowers the Cin threshold so the small test UNet exercises it on
+    its 16x16 and 8x8 levels; conv_algo=1 (direct only) must agree to the same tolerance."""
+    import ctypes as C
+    from imagen_pytorch import _engine as E
+
+    B, S = 16, 64
+    ou = H.oracle_unet("ultra2", lowres_cond=True, seed=13).eval()
+    x, lr, cond, t, tl = _inputs("ultra2", B, S, True, seed=8)
+    with torch.no_grad():
+        ref = ou(x, t, lowres_cond_img=lr, lowres_noise_times=tl, cond_images=cond)
+    dv = lambda v: None if v is None else v.to(device)
+    outs = {}
+    for algo in (32, 1):
+        pu = H.product_unet_like(ou).to(device)
+        pu.conv_algo = algo
+        got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
+        err = H.rel_l2(got, ref)
+        assert err < FWD_REL_L2, f"conv_algo={algo}: rel-L2 {err:.3e}"
+        buf = C.create_string_buffer(1 << 20)
+        E.check(E.load().kd_unet_profile(pu.engine(B, S, device, with_text=False), 1, buf, len(buf),
+                                         E.current_stream()))
+        n_wino = buf.value.decode().count("wino gemm")
+        assert (n_wino > 0) == (algo == 32), f"conv_algo={algo}: {n_wino} Winograd GEMMs in the plan"
+        outs[algo] = got
+    assert H.rel_l2(outs[32], outs[1]) < FWD_REL_L2
+
+
 def test_engine_mac_count_matches_survey_appendix_b(device):
     """unet2 64->256 (train_ultra_res.py:39-48, 3 cond channels) = 229.2 GMAC/sample."""
     import imagen_pytorch as ip
