@@ -84,6 +84,10 @@ void kd_unet_destroy(kd_unet_t* u);
 /* bytes of HBM held (weights + workspace) and algorithmic MACs of one forward (whole batch) */
 int64_t kd_unet_hbm_bytes(const kd_unet_t* u);
 int64_t kd_unet_macs(const kd_unet_t* u);
+/* MACs the conv / GEMM launches of one step actually issue on the matrix cores: smaller than
+ * kd_unet_macs where a 3x3 conv runs as Winograd F(2x2,3x3) (16/36 of its MACs) and by the
+ * step-invariant share of the init / final conv that is hoisted out of the step */
+int64_t kd_unet_mfma_macs(const kd_unet_t* u);
 int kd_unet_num_launches(const kd_unet_t* u);
 
 /* Step-invariant text conditioning (the text branch of Unet.forward; reached by the

@@ -131,7 +131,8 @@ struct kd_unet {
   WeightPool wpool;
   char* ws = nullptr;
   size_t ws_bytes = 0;
-  int64_t macs = 0;
+  int64_t macs = 0;       // algorithmic MACs of one forward as the reference computes it
+  int64_t mfma_macs = 0;  // MACs the per-step conv / GEMM launches issue on the matrix cores
   int time_cond_dim = 0;
   // per-call I/O (read by the ops at run time)
   const float *in_x = nullptr, *in_lowres = nullptr, *in_cond = nullptr, *in_log_snr = nullptr,
@@ -352,6 +353,7 @@ struct Builder {
     // algorithmic MACs of one forward as the reference computes it: the step-invariant part of the
     // init conv is counted even though the engine runs it once per sampling call instead of per step
     if (!to_text) u->macs += m;
+    if (!to_text && !to_static) u->mfma_macs += (int64_t)x.B * Ho * Wo * Cout * p.Cin * p.KH * p.KW;
     return y;
   }
   // token GEMM y[M,N] = x[M,K] @ w[N,K]^T

@@ -96,6 +96,7 @@ SIGNATURES = {
     "kd_unet_destroy": (None, [C.c_void_p]),
     "kd_unet_hbm_bytes": (C.c_int64, [C.c_void_p]),
     "kd_unet_macs": (C.c_int64, [C.c_void_p]),
+    "kd_unet_mfma_macs": (C.c_int64, [C.c_void_p]),
     "kd_unet_num_launches": (C.c_int, [C.c_void_p]),
     "kd_unet_text_cond": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
