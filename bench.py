@@ -93,14 +93,140 @@ def cpu_baseline(unet_product, device_tables):
                       f"({dts[-1]:.2f} s), scaled x{BATCH // b} to batch 16; torch {torch.__version__} oneDNN fp32"}
 
 
+F_, T_ = False, True
+ULTRA_UNETS = {  # train_ultra_res.py:29-60 (magnification level > 0: 3 conditioning channels)
+    1: dict(dim=256, dim_mults=(1, 2, 4, 8), num_resnet_blocks=3, layer_attns=(F_, T_, T_, T_),
+            layer_cross_attns=(F_, T_, T_, T_), cond_images_channels=3),
+    2: SR_UNET_KW,
+    3: dict(dim=128, dim_mults=(1, 2, 4, 8), num_resnet_blocks=(2, 4, 6, 8), memory_efficient=True, layer_attns=False,
+            layer_cross_attns=(F_, F_, F_, T_), init_conv_to_final_conv_residual=True, cond_images_channels=3),
+}
+
+
+def grid_workload(args, world, rank, device, distributed, barrier):
+    """BASELINE configs[4]: the 8x8 ultra-res outpainting grid of 1024-px patches through the 3-stage
+    cascade (sample_ultra_res.py:264-448), sharded over the ranks by anti-diagonal waves with one
+    all-gather per wave (ultra_res/distributed.py).  One "step" = one full set of --canvases grids.
+    Strong scaling: the same 64 x canvases patches whatever N is."""
+    import imagen_pytorch as ip
+    from ultra_res import distributed as D
+    from ultra_res import grid as G
+
+    class FixedNullUnet(ip.NullUnet):  # train_ultra_res.py:65-75
+        def __init__(self, lowres_cond=False, *a, **k):
+            super().__init__()
+            self.lowres_cond = lowres_cond
+            self.dummy_parameter = torch.nn.Parameter(torch.tensor([0.0]))
+
+        def cast_model_parameters(self, *a, **k):
+            return self
+
+        def forward(self, x, *a, **k):
+            return x
+
+    T = args.grid_steps
+    imagens = {}
+
+    def load_imagen(stage):  # train_ultra_res.py:79-90 with one real UNet resident per Imagen
+        torch.manual_seed(100 + stage)
+        unets = tuple(ip.Unet(**ULTRA_UNETS[i]) if i == stage else FixedNullUnet(lowres_cond=i > 1) for i in (1, 2, 3))
+        with torch.no_grad():
+            fc = unets[stage - 1].final_conv
+            fc.weight.normal_(0, 0.02)
+            fc.bias.normal_(0, 0.02)
+        im = ip.Imagen(unets=unets, image_sizes=(64, 256, 1024), timesteps=(T, T, T),
+                       pred_objectives=("noise", "noise", "noise"), random_crop_sizes=(None, None, 256),
+                       condition_on_text=False)
+        imagens[stage] = im
+        return im
+
+    geom = G.grid_geometry(1024, 1, 0.25)  # sample_ultra_res.py:280,307,311: 8x8 patches, canvas 6400
+    assert geom.num_patches_width == 8 and geom.canvas_width == 6400
+    n = args.grid_n
+    pos = [(i, j) for i in range(n) for j in range(n)]
+    g = torch.Generator().manual_seed(1234)
+    zoomed = torch.rand(1, 3, 1024, 1024, generator=g)
+    cond = G.cond_images_for_grid(zoomed, geom, pos)
+    sample_fn = D.imagen_sample_fn(load_imagen, args.grid_resample, device, use_graph=not args.no_graph, seed=1234)
+    ncan = args.canvases
+    # finished patches live where the all-gather runs: HBM under RCCL, host memory in a gloo rehearsal
+    # (gloo has no CUDA all_gather)
+    import torch.distributed as dist
+
+    slab_dev = device if (not distributed or dist.get_backend() == "nccl") else torch.device("cpu")
+
+    def run(positions, cond_images, canvases):
+        out = D.sample_grids(sample_fn, (1, 2, 3), [positions] * canvases, [cond_images] * canvases, 0.25,
+                             [n] * canvases, patch_width=geom.patch_width, device=slab_dev)
+        sub = G.GridGeometry(geom.patch_width, geom.patch_dist, n, geom.out_patch_dist,
+                             1024 + (n - 1) * geom.out_patch_dist)
+        return [G.stitch_canvas(o, positions, sub, background=zoomed.to(device)) for o in out]
+
+    for _ in range(max(1, args.warmup)):  # builds the three plans (batch 1) and their step graphs
+        run(pos[:1], cond[:1], 1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        canv = run(pos, cond, ncan)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert all(torch.isfinite(c).all() for c in canv)
+    if distributed:
+        import torch.distributed as dist
+
+        tmax = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank != 0:
+        return
+    from imagen_pytorch import _engine as E
+
+    lib = E.load()
+    R = args.grid_resample
+    flop_patch = 0.0
+    for stage, size in ((1, 64), (2, 256), (3, 1024)):
+        h = imagens[stage].unets[stage - 1].engine(1, size, device, with_text=False)
+        flop_patch += 2.0 * lib.kd_unet_macs(h) * T * R
+    patches = len(pos) * ncan * args.steps
+    waves = D.merged_waves([pos] * ncan, [G.choose_orientation(pos)] * ncan)
+    achieved = patches * flop_patch / elapsed / 1e12 / world
+    print(json.dumps({
+        "metric": "patches/sec (ultra-res outpainting grid, 1024-px patches, 3-stage cascade)",
+        "value": patches / elapsed, "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[4]: {n}x{n} grid x {ncan} canvas(es), overlap 0.25, stages 64->256->1024 "
+                               f"(train_ultra_res.py:27-92), batch 1 per patch as the reference samples them, "
+                               f"timesteps ({T},{T},{T}) [reference default (1024,256,256)], inpaint_resample {R}, "
+                               "random-init weights",
+                   "patches": len(pos) * ncan, "schedule_slots": D.schedule_length(waves, world),
+                   "parallelism": f"{world} rank(s): anti-diagonal waves dealt round-robin, one all-gather per wave"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                     "kernel": f"whole patch pipeline per GPU: {flop_patch / 1e12:.2f} TFLOP algorithmic per patch "
+                               "(wall clock, includes host-side inpaint-tensor assembly, all-gathers and idle wave slots)"},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--workload", choices=("sr", "grid"), default="sr",
+                    help="sr: the headline metric (default); grid: ultra-res patch grid, patches/s")
+    ap.add_argument("--grid-n", type=int, default=8)
+    ap.add_argument("--canvases", type=int, default=1)
+    ap.add_argument("--grid-steps", type=int, default=8, help="timesteps per stage for --workload grid")
+    ap.add_argument("--grid-resample", type=int, default=1, help="inpaint_resample_times for --workload grid")
     args = ap.parse_args()
+    grid = args.workload == "grid"
+    if args.steps is None:
+        args.steps = 1 if grid else 20
+    if args.warmup is None:
+        args.warmup = 1 if grid else 3
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -119,6 +245,18 @@ def main():
             dist.init_process_group("nccl", device_id=device)  # RCCL; used for the barrier / max-reduce only
         else:
             dist.init_process_group(backend)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if grid:
+        grid_workload(args, world, rank, device, distributed, barrier)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from imagen_pytorch import _engine as E
     from imagen_pytorch.imagen_pytorch import GaussianDiffusionContinuousTimes, log_snr_to_alpha_sigma, \
@@ -157,11 +295,6 @@ def main():
             E.check(lib.kd_sample_steps(handle, C.byref(sc), C.byref(sa), E.ptr(x), k0, k0 + m, E.current_stream()))
             k0 += m
             n -= m
-
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     run_steps(0, args.warmup)
     barrier()

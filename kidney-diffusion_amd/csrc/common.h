@@ -75,12 +75,15 @@ int launch_pack_shuffle(const float* w, const float* b, float* w_packed, float* 
 // OIHW 3x3 weights -> U [16][O][I]
 int launch_wino_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s);
 // V[p][t][c] = (B^T d B)[p] of the 4x4 input tile of output tile t, d = SiLU(GroupNorm/FiLM(x)) when
-// stats != nullptr (same arguments as launch_gn_apply_silu), d = x otherwise; zero padding outside
+// stats != nullptr (same arguments as launch_gn_apply_silu), d = x otherwise; zero padding outside.
+// Both transforms work on a slice [t0, t0+nt) of the B*(H/2)*(W/2) output tiles; V and D are
+// [16][nt][C] for that slice (the plan walks a map in slices that stay in the 256 MB Infinity Cache).
 int launch_wino_in(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
-                   const float* scale_shift, int ld_ss, float* V, int B, int H, int W, int C, int G, hipStream_t s);
+                   const float* scale_shift, int ld_ss, float* V, int B, int H, int W, int C, int G, int64_t t0,
+                   int64_t nt, hipStream_t s);
 // y[b][2ty+i][2tx+j][n] = (A^T D A)[i][j] + bias[n] (+ res)
 int launch_wino_out(const float* D, const float* bias, const float* res, int ldres, float* y, int B, int H, int W,
-                    int C, hipStream_t s);
+                    int C, int64_t t0, int64_t nt, hipStream_t s);
 
 // ---- norms / elementwise (kernels_norm.hip)
 int launch_gn_stats(const float* x, int ldx, float* stats /*[B][G][2] mean,rstd*/, double* partial,

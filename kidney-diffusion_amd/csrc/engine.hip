@@ -4,6 +4,7 @@
 //  and emits a flat list of kernel launches with static shapes and
 // static workspace offsets, so one denoising iteration can be captured into a hipGraph and
 // replayed.  Feature maps are NHWC fp32; token tensors [B,N,C] are the same memory.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -544,35 +545,61 @@ struct Builder {
     float* U = u->wpool.alloc((size_t)16 * Cout * Cin);
     KD_THROW_IF(launch_wino_pack(raw(conv_prefix + ".weight", (int64_t)Cout * Cin * 9), U, Cout, Cin, 0));
     if (gn_partial_bytes(Bx, HW, Cin, G) > gn_partial_max) throw std::runtime_error("gn partial scratch too small");
-    T V = alloc(1, 1, (int)(16 * Mt), Cin);
+    // The map can be walked in slices of tiles (V and D are 4x the slice each) to bound the workspace:
+    // KD_WINO_SLICE_MB caps V+D per slice.  Default: one slice - slices small enough to stay in the
+    // 256 MB Infinity Cache were measured and are slower (56.5 ms/step unsliced, 59.3 at 96 MB,
+    // 57.5 at 192 MB): the cache does not turn the V/D round trip into hits.
+    const int64_t slice_mb = getenv("KD_WINO_SLICE_MB") ? atoll(getenv("KD_WINO_SLICE_MB")) : 0;  // read per plan
+    int64_t nt_slice = Mt;
+    if (slice_mb > 0) {
+      nt_slice = (slice_mb << 20) / (64 * (int64_t)(Cin + Cout)) / 256 * 256;
+      nt_slice = std::min(Mt, std::max<int64_t>(nt_slice, 256));
+    }
     {
-      size_t xo = x.off, vo = V.off, so = gn_stats_t.off, po = gn_partial_t.off, sso = t_ss.off;
-      int ld = tmlp_total;
+      size_t xo = x.off, so = gn_stats_t.off, po = gn_partial_t.off;
       kd_unet* uu = u;
       emit([=](hipStream_t s) {
-        if (launch_gn_stats(uu->P(xo), Cin, uu->P(so), (double*)uu->P(po), Bx, HW, Cin, G, 1e-5f, s)) return 1;
-        const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
-        return launch_wino_in(uu->P(xo), Cin, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s);
-      }, "gn+wino_in HW" + std::to_string(HW) + " C" + std::to_string(Cin));
+        return launch_gn_stats(uu->P(xo), Cin, uu->P(so), (double*)uu->P(po), Bx, HW, Cin, G, 1e-5f, s);
+      }, "gn stats HW" + std::to_string(HW) + " C" + std::to_string(Cin));
     }
-    ConvOpt o;
-    o.wz_rows = (int)Mt;
-    o.macs_override = (int64_t)Bx * HW * Cout * Cin * 9;  // algorithmic MACs of the 3x3 conv it replaces
-    T D = conv(V, U, nullptr, Cout, 1, 1, 0, o);
-    if (!to_text && !to_static)
-      u->op_label.back() = "wino gemm M" + std::to_string((int64_t)Bx * HW) + " Cin" + std::to_string(Cin) + " Cout" +
-                           std::to_string(Cout);
-    free(V);
+    T V = alloc(1, 1, (int)(16 * nt_slice), Cin);
+    T D = alloc(1, 1, (int)(16 * nt_slice), Cout);
     T y = alloc(Bx, H, W, Cout);
-    {
-      size_t d_o = D.off, yo = y.off, ro = res ? res->off : 0;
-      bool hr = res != nullptr;
-      int ldres = res ? res->C : 0;
-      kd_unet* uu = u;
-      emit([=](hipStream_t s) {
-        return launch_wino_out(uu->P(d_o), bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W, Cout, s);
-      }, "wino_out HW" + std::to_string(HW) + " C" + std::to_string(Cout));
+    const std::string shape = " M" + std::to_string((int64_t)Bx * HW) + " Cin" + std::to_string(Cin) + " Cout" +
+                              std::to_string(Cout);
+    for (int64_t t0 = 0; t0 < Mt; t0 += nt_slice) {
+      const int64_t nt = std::min(nt_slice, Mt - t0);
+      {
+        size_t xo = x.off, vo = V.off, so = gn_stats_t.off, sso = t_ss.off;
+        int ld = tmlp_total;
+        kd_unet* uu = u;
+        emit([=](hipStream_t s) {
+          const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
+          return launch_wino_in(uu->P(xo), Cin, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, t0, nt,
+                                s);
+        }, "wino_in" + shape);
+      }
+      T Vs = V, Ds = D;
+      Vs.W = (int)(16 * nt);
+      Ds.W = (int)(16 * nt);
+      ConvOpt o;
+      o.wz_rows = (int)nt;
+      o.dst = &Ds;
+      o.macs_override = nt * 4 * Cout * Cin * 9;  // algorithmic MACs of the share of the 3x3 conv it replaces
+      conv(Vs, U, nullptr, Cout, 1, 1, 0, o);
+      if (!to_text && !to_static) u->op_label.back() = "wino gemm" + shape;
+      {
+        size_t d_o = D.off, yo = y.off, ro = res ? res->off : 0;
+        bool hr = res != nullptr;
+        int ldres = res ? res->C : 0;
+        kd_unet* uu = u;
+        emit([=](hipStream_t s) {
+          return launch_wino_out(uu->P(d_o), bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W, Cout, t0, nt,
+                                 s);
+        }, "wino_out" + shape);
+      }
     }
+    free(V);
     free(D);
     return y;
   }

@@ -63,14 +63,16 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta,
                                                       const float* __restrict__ scale_shift, int ld_ss,
-                                                      float* __restrict__ V, int B, int H, int W, int C, int G) {
+                                                      float* __restrict__ V, int B, int H, int W, int C, int G,
+                                                      int64_t t0, int64_t nt) {
   const int C4 = C >> 2;
   const int Ht = H >> 1, Wt = W >> 1;
-  const int64_t Mt = (int64_t)B * Ht * Wt;
+  const int64_t Mt = nt;  // tiles of this slice: V is [16][nt][C]
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= Mt * C4) return;
   const int c4 = (int)(idx % C4);
-  const int64_t t = idx / C4;
+  const int64_t tl = idx / C4;
+  const int64_t t = t0 + tl;
   const int tx = (int)(t % Wt);
   const int ty = (int)((t / Wt) % Ht);
   const int b = (int)(t / ((int64_t)Wt * Ht));
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
     u[3][s] = d[1][s] - d[3][s];
   }
   // (B^T d) B
-  float* out = V + t * C + c4 * 4;
+  float* out = V + tl * C + c4 * 4;
   const int64_t pstride = Mt * C;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -137,30 +139,33 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 }
 
 int launch_wino_in(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
-                   const float* scale_shift, int ld_ss, float* V, int B, int H, int W, int C, int G,
-                   hipStream_t s) {
+                   const float* scale_shift, int ld_ss, float* V, int B, int H, int W, int C, int G, int64_t t0,
+                   int64_t nt, hipStream_t s) {
   KD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && H % 2 == 0 && W % 2 == 0, "Winograd input transform needs even H, W and C % 4 == 0");
-  int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / 4);
+  KD_REQUIRE(t0 >= 0 && nt > 0 && t0 + nt <= (int64_t)B * (H / 2) * (W / 2), "tile slice out of range");
+  int64_t total = nt * (C / 4);
   hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, stats, gamma,
-                     beta, scale_shift, ld_ss, V, B, H, W, C, G);
+                     beta, scale_shift, ld_ss, V, B, H, W, C, G, t0, nt);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ D, const float* __restrict__ bias,
                                                        const float* __restrict__ res, int ldres,
-                                                       float* __restrict__ y, int B, int H, int W, int C) {
+                                                       float* __restrict__ y, int B, int H, int W, int C,
+                                                       int64_t t0, int64_t nt) {
   const int C4 = C >> 2;
   const int Ht = H >> 1, Wt = W >> 1;
-  const int64_t Mt = (int64_t)B * Ht * Wt;
+  const int64_t Mt = nt;  // tiles of this slice: D is [16][nt][C]
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= Mt * C4) return;
   const int c4 = (int)(idx % C4);
-  const int64_t t = idx / C4;
+  const int64_t tl = idx / C4;
+  const int64_t t = t0 + tl;
   const int tx = (int)(t % Wt);
   const int ty = (int)((t / Wt) % Ht);
   const int b = (int)(t / ((int64_t)Wt * Ht));
-  const float* in = D + t * C + c4 * 4;
+  const float* in = D + tl * C + c4 * 4;
   const int64_t pstride = Mt * C;
   f32x4 m[4][4];
 #pragma unroll
@@ -190,11 +195,12 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 }
 
 int launch_wino_out(const float* D, const float* bias, const float* res, int ldres, float* y, int B, int H, int W,
-                    int C, hipStream_t s) {
+                    int C, int64_t t0, int64_t nt, hipStream_t s) {
   KD_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "Winograd output transform needs even H, W and C % 4 == 0");
-  int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / 4);
+  KD_REQUIRE(t0 >= 0 && nt > 0 && t0 + nt <= (int64_t)B * (H / 2) * (W / 2), "tile slice out of range");
+  int64_t total = nt * (C / 4);
   hipLaunchKernelGGL(wino_out_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, D, bias, res, ldres, y,
-                     B, H, W, C);
+                     B, H, W, C, t0, nt);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

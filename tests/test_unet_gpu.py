@@ -62,20 +62,30 @@ def test_unet_forward_with_winograd_levels_matches_oracle(device):
     with torch.no_grad():
         ref = ou(x, t, lowres_cond_img=lr, lowres_noise_times=tl, cond_images=cond)
     dv = lambda v: None if v is None else v.to(device)
-    outs = {}
-    for algo in (32, 1):
+    import os
+
+    outs, n_gemm = {}, {}
+    # (conv_algo, KD_WINO_SLICE_MB): the last variant walks every Winograd layer in 256-tile slices
+    for algo, slice_mb in ((32, None), (1, None), (32, "1")):
         pu = H.product_unet_like(ou).to(device)
         pu.conv_algo = algo
-        got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
+        if slice_mb is not None:
+            os.environ["KD_WINO_SLICE_MB"] = slice_mb
+        try:
+            got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
+        finally:
+            os.environ.pop("KD_WINO_SLICE_MB", None)
         err = H.rel_l2(got, ref)
-        assert err < FWD_REL_L2, f"conv_algo={algo}: rel-L2 {err:.3e}"
+        assert err < FWD_REL_L2, f"conv_algo={algo} slice={slice_mb}: rel-L2 {err:.3e}"
         buf = C.create_string_buffer(1 << 20)
         E.check(E.load().kd_unet_profile(pu.engine(B, S, device, with_text=False), 1, buf, len(buf),
                                          E.current_stream()))
         n_wino = buf.value.decode().count("wino gemm")
         assert (n_wino > 0) == (algo == 32), f"conv_algo={algo}: {n_wino} Winograd GEMMs in the plan"
-        outs[algo] = got
-    assert H.rel_l2(outs[32], outs[1]) < FWD_REL_L2
+        outs[(algo, slice_mb)], n_gemm[(algo, slice_mb)] = got, n_wino
+    assert H.rel_l2(outs[(32, None)], outs[(1, None)]) < FWD_REL_L2
+    assert n_gemm[(32, "1")] > n_gemm[(32, None)], "slicing did not split the Winograd layers"
+    assert torch.equal(outs[(32, "1")], outs[(32, None)]), "sliced and unsliced Winograd must be bit-identical"
 
 
 def test_engine_mac_count_matches_survey_appendix_b(device):
