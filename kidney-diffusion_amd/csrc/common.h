@@ -52,9 +52,15 @@ struct ConvParams {
   // batched 1x1 GEMM (Winograd positions): rows [z*wz_rows, (z+1)*wz_rows) use weight slab z of
   // wz_count slabs [Cout][Cin]; 0 = one weight tensor.  wz_rows must be a multiple of 256.
   int wz_rows, wz_count;
+  // split-K for small-M layers: scratch [conv_ksplit(p)][M][Cout] floats, or nullptr (never split);
+  // ksplit is filled in by launch_conv_igemm
+  float* partial;
+  int ksplit;
 };
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s);
+// number of K splits launch_conv_igemm uses for this shape when `partial` is provided (1 = none)
+int conv_ksplit(const ConvParams& p);
 int64_t conv_macs(const ConvParams& p);
 
 // weight re-packing (device→device)
@@ -159,12 +165,14 @@ int launch_x0(const float* x, const float* pred, float* x0, const StepTables& tb
 int launch_quantile_abs(const float* x, float* out, int B, int64_t n, float q, void* ws, hipStream_t s);
 size_t quantile_ws_bytes(int B);
 int launch_ddpm_update(float* x, const float* x0, const float* s_thresh, const float* noise, int64_t noise_stride,
-                       uint64_t seed, const StepTables& tb, const int* d_iter, int R, int dynamic_threshold,
+                       const uint64_t* d_seed, const StepTables& tb, const int* d_iter, int R, int dynamic_threshold,
                        int B, int64_t per, hipStream_t s);
 int launch_inpaint_mix(float* x, const float* inp, const float* mask, const float* noise, int64_t noise_stride,
-                       uint64_t seed, const StepTables& tb, const int* d_iter, int R, int B, int C, int64_t hw,
+                       const uint64_t* d_seed, const StepTables& tb, const int* d_iter, int R, int B, int C, int64_t hw,
                        hipStream_t s);
-int launch_renoise(float* x, const float* noise, int64_t noise_stride, uint64_t seed, const StepTables& tb,
+// the Philox key lives in device memory (d_seed) so that one captured step graph serves every seed
+int launch_seed_set(uint64_t* d_seed, uint64_t value, hipStream_t s);
+int launch_renoise(float* x, const float* noise, int64_t noise_stride, const uint64_t* d_seed, const StepTables& tb,
                    const int* d_iter, int R, int T, int B, int64_t per, hipStream_t s);
 int launch_iter_set(int* d_iter, int value, hipStream_t s);
 int launch_finalize(float* x, const float* inp, const float* mask, int B, int C, int64_t hw, hipStream_t s);

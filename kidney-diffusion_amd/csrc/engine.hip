@@ -152,6 +152,7 @@ struct kd_unet {
   // sampler scratch (allocated on first use)
   float *s_pred = nullptr, *s_x0 = nullptr, *s_thresh = nullptr, *s_time = nullptr, *s_tables = nullptr;
   int* s_iter = nullptr;
+  uint64_t* s_seed = nullptr;  // Philox key, device-resident so the step graph does not depend on it
   void* s_qws = nullptr;
   int s_tables_cap = 0;
   // cached graph of one iteration
@@ -163,7 +164,7 @@ struct kd_unet {
   ~kd_unet() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
-    void* frees[] = {ws, s_pred, s_x0, s_thresh, s_time, s_tables, s_iter, s_qws, s_pred_null};
+    void* frees[] = {ws, s_pred, s_x0, s_thresh, s_time, s_tables, s_iter, s_seed, s_qws, s_pred_null};
     for (void* p : frees)
       if (p) (void)hipFree(p);
   }
@@ -334,6 +335,12 @@ struct Builder {
     size_t ro = has_res ? o.res->off : 0, gso = has_gs ? o.gate_src->off : 0, go = has_gs ? o.gate->off : 0;
     kd_unet* uu = u;
     const int res_coff = o.res_coff;
+    // small-M layers (batch-1 patches): split-K scratch, released right after the launch is recorded
+    // (one in-order stream: the next op that reuses the block runs after the reduction)
+    const int ks = conv_ksplit(p);
+    T part;
+    if (ks > 1) part = alloc_bytes((size_t)ks * x.B * Ho * Wo * Cout * sizeof(float));
+    const size_t parto = part.off;
     emit([=](hipStream_t s) {
       ConvParams q = p;
       q.x = uu->P(xo);
@@ -341,8 +348,10 @@ struct Builder {
       q.res = has_res ? uu->P(ro) + res_coff : nullptr;
       q.gate_src = has_gs ? uu->P(gso) : nullptr;
       q.gate = has_gs ? uu->P(go) : nullptr;
+      q.partial = ks > 1 ? uu->P(parto) : nullptr;
       return launch_conv_igemm(q, s);
     });
+    if (ks > 1) free(part);
     int cin = o.cin_logical > 0 ? o.cin_logical : x.C;
     int64_t m = o.macs_override >= 0 ? o.macs_override : (int64_t)x.B * Ho * Wo * Cout * cin * K * K;
     if (!to_text && !to_static) {

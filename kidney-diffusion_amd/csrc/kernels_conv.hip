@@ -341,7 +341,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
   uint32_t voffA[A_PASSES];
   const int chunks_per_tap = p.Cin / BK;
   const int nchunks = p.KH * p.KW * chunks_per_tap;
-  int cur_tap = -1, cur_cc = chunks_per_tap;
+  // split-K (small-M layers that cannot fill the chip with tiles): workgroup z sums the chunks
+  // [c_begin, c_end) and writes a raw partial tile; conv_splitk_reduce_kernel adds the partials in a
+  // fixed order and applies the epilogue
+  int c_begin = 0, c_end = nchunks;
+  if (p.ksplit > 1) {
+    const int per = (nchunks + p.ksplit - 1) / p.ksplit;
+    c_begin = (int)blockIdx.z * per;
+    c_end = c_begin + per < nchunks ? c_begin + per : nchunks;
+  }
+  int cur_tap = c_begin / chunks_per_tap - 1, cur_cc = chunks_per_tap;
   uint32_t soffA = 0, soffB = 0;
   const uint32_t tap_stride_b = (uint32_t)p.Cout * p.Cin * 4;
 
@@ -408,9 +417,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
 
   float* const s0 = lds;
   float* const s1 = lds + STAGE;
+  if (c_begin > 0) {  // start in the middle of a tap
+    next_tap();
+    cur_cc = c_begin - cur_tap * chunks_per_tap;
+    soffA = (uint32_t)cur_cc * BK * 4;
+    soffB += (uint32_t)cur_cc * BK * 4;
+  }
   issue(s0);
-  for (int c = 0; c < nchunks; c += 2) {
-    if (c + 1 < nchunks) {
+  for (int c = c_begin; c < c_end; c += 2) {
+    if (c + 1 < c_end) {
       issue(s1);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
     } else {
@@ -420,8 +435,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
     compute(s0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (c + 1 >= nchunks) break;
-    if (c + 2 < nchunks) {
+    if (c + 1 >= c_end) break;
+    if (c + 2 < c_end) {
       issue(s0);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
     } else {
@@ -433,12 +448,74 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
     __builtin_amdgcn_s_barrier();
   }
   __syncthreads();
-  store_tile<BM, BN, WAVES_M, WAVES_N>(p, lds, acc, m0, n0, M);
+  if (p.ksplit > 1) {  // raw partial sums [z][M][Cout]
+    ConvParams q = p;
+    q.bias = nullptr; q.act = ACT_NONE; q.res = nullptr; q.gate_src = nullptr; q.gate = nullptr;
+    q.out_mode = OUT_NHWC; q.ldy = p.Cout; q.yoff = 0;
+    q.y = p.partial + (int64_t)blockIdx.z * M * p.Cout;
+    store_tile<BM, BN, WAVES_M, WAVES_N>(q, lds, acc, m0, n0, M);
+  } else {
+    store_tile<BM, BN, WAVES_M, WAVES_N>(p, lds, acc, m0, n0, M);
+  }
 #endif
+}
+
+// y[m][n..n+3] = epilogue( sum_z partial[z][m][n..n+3] ), z ascending (deterministic)
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvParams p, int64_t M) {
+  const int C4 = p.Cout >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * C4) return;
+  const int64_t m = idx / C4;
+  const int n = (int)(idx - m * C4) * 4;
+  const int64_t zstride = M * p.Cout;
+  const float* src = p.partial + m * p.Cout + n;
+  f32x4 s = *(const f32x4*)src;
+  for (int z = 1; z < p.ksplit; ++z) s += *(const f32x4*)(src + z * zstride);
+  const bool vec_ok = p.out_mode != OUT_NCHW && (p.ldy & 3) == 0 && (p.yoff & 3) == 0 && (((uintptr_t)p.y) & 15) == 0 &&
+                      (!p.res || ((p.ldres & 3) == 0 && (((uintptr_t)p.res) & 15) == 0)) &&
+                      (!p.gate_src || (p.ldgs & 3) == 0) && (p.out_mode != OUT_PIXSHUF || (p.Cout & 15) == 0);
+  if (vec_ok) {
+    float v[4] = {s[0], s[1], s[2], s[3]};
+    epilogue_store<4>(p, m, n, v);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v[1] = {s[e]};
+      epilogue_store<1>(p, m, n + e, v);
+    }
+  }
 }
 
 int64_t conv_macs(const ConvParams& p) {
   return (int64_t)p.B * p.Ho * p.Wo * p.Cout * p.Cin * p.KH * p.KW;
+}
+
+// Shape conditions of the buffer-DMA fast path (pointer alignment is checked at launch).
+static bool fast_shape_ok(const ConvParams& p) {
+  const int64_t w_bytes = (int64_t)(p.wz_rows > 0 ? p.wz_count : p.KH * p.KW) * p.Cout * p.Cin * 4;
+  // the fast kernel addresses the activations with 32-bit byte offsets relative to the image of the
+  // tile's first pixel: every image a 256-row tile can touch must lie within 2^31 bytes of it
+  const int64_t img_bytes = (int64_t)p.Hi * p.Wi * p.ldx * 4;
+  const int64_t hw_o = (int64_t)p.Ho * p.Wo;
+  const int64_t span = (hw_o % 256 == 0) ? 1 : 255 / hw_o + 2;
+  const bool gemm = p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0;  // based per tile: no size limit
+  return p.rr_cin == 0 && (p.Cin % BK) == 0 && p.Cout > 32 && w_bytes < 0x7fffffff &&
+         (gemm || span * img_bytes < 0x7fffffff);
+}
+
+// Number of K splits for a conv whose M x Cout tiles cannot fill the chip (batch-1 patches of the
+// ultra-res grid: M = 64 .. 1024 pixels against K = 9 x 2048): enough workgroups for ~3 per CU, at
+// least 4 chunks each.  1 = no split.  The caller provides ConvParams::partial [ksplit][M][Cout].
+int conv_ksplit(const ConvParams& p) {
+  if (!fast_shape_ok(p) || p.wz_rows > 0 || p.Cout < 64 || (p.Cout & 3)) return 1;
+  const int64_t M = (int64_t)p.B * p.Ho * p.Wo;
+  const int64_t tiles = ((M + 127) / 128) * ((p.Cout + 63) / 64);
+  const int nchunks = p.KH * p.KW * (p.Cin / BK);
+  if (tiles >= 256 || nchunks < 16) return 1;
+  const int want = (int)((768 + tiles - 1) / tiles);
+  int per = (nchunks + want - 1) / want;
+  if (per < 4) per = 4;
+  return (nchunks + per - 1) / per;
 }
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
@@ -447,18 +524,22 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
   if (p.out_mode == OUT_PIXSHUF) KD_REQUIRE(p.Cout % 4 == 0, "pixel-shuffle needs Cout % 4 == 0");
   int64_t M = (int64_t)p.B * p.Ho * p.Wo;
   KD_REQUIRE(M > 0 && p.Cout > 0, "empty conv");
-  const int64_t w_bytes = (int64_t)(p.wz_rows > 0 ? p.wz_count : p.KH * p.KW) * p.Cout * p.Cin * 4;
   if (p.wz_rows > 0)
     KD_REQUIRE(p.KH * p.KW == 1 && p.wz_rows % 256 == 0 && M == (int64_t)p.wz_rows * p.wz_count,
                "batched GEMM: 1x1 only, slab rows a multiple of 256, M = rows x slabs");
-  // the fast kernel addresses the activations with 32-bit byte offsets relative to the image of the
-  // tile's first pixel: every image a 256-row tile can touch must lie within 2^31 bytes of it
-  const int64_t img_bytes = (int64_t)p.Hi * p.Wi * p.ldx * 4;
-  const int64_t hw_o = (int64_t)p.Ho * p.Wo;
-  const int64_t span = (hw_o % 256 == 0) ? 1 : 255 / hw_o + 2;
-  const bool gemm = p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0;  // based per tile: no size limit
-  const bool fast = p.rr_cin == 0 && (p.Cin % BK) == 0 && p.Cout > 32 && M > 64 && w_bytes < 0x7fffffff &&
-                    (gemm || span * img_bytes < 0x7fffffff) && (((uintptr_t)p.x | (uintptr_t)p.w) & 15) == 0;
+  const int ks = p.partial ? conv_ksplit(p) : 1;
+  if (ks > 1) {
+    KD_REQUIRE(((uintptr_t)p.partial & 15) == 0, "split-K partial buffer must be 16-B aligned");
+    ConvParams q = p;
+    q.ksplit = ks;
+    dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 63) / 64, ks);
+    hipLaunchKernelGGL((conv_buf_kernel<128, 64, 2, 2, 3>), grid, dim3(256), 0, s, q);
+    const int64_t total = M * (p.Cout / 4);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, q, M);
+    KD_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  const bool fast = fast_shape_ok(p) && M > 64;
   if (fast) {
     const int64_t tiles256 = ((M + 255) / 256) * ((p.Cout + 127) / 128);
     // 256x128 (one 8-wave workgroup per CU) needs a K loop long enough to amortise its serial

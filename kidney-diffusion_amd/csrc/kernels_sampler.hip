@@ -93,6 +93,12 @@ int launch_fill_time(const float* table, const int* d_iter, int R, float* out, i
 
 __global__ void iter_inc_kernel(int* d_iter) { *d_iter += 1; }
 __global__ void iter_set_kernel(int* d_iter, int v) { *d_iter = v; }
+__global__ void seed_set_kernel(uint64_t* d_seed, uint64_t v) { *d_seed = v; }
+int launch_seed_set(uint64_t* d_seed, uint64_t value, hipStream_t s) {
+  hipLaunchKernelGGL(seed_set_kernel, dim3(1), dim3(1), 0, s, d_seed, value);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
 int launch_iter_set(int* d_iter, int value, hipStream_t s) {
   hipLaunchKernelGGL(iter_set_kernel, dim3(1), dim3(1), 0, s, d_iter, value);
   KD_HIP_CHECK(hipGetLastError());
@@ -250,9 +256,10 @@ int launch_quantile_abs(const float* x, float* out, int B, int64_t n, float q, v
 // x0c = clamp(x0,-s,s)/s ; mean = alpha_next*(x*(1-c)/alpha + c*x0c) ; x = mean + noise_scale*N(0,1)
 __global__ void ddpm_update_kernel(float* __restrict__ x, const float* __restrict__ x0,
                                    const float* __restrict__ s_thresh, const float* __restrict__ noise,
-                                   int64_t noise_stride, uint64_t seed, StepTables tb,
+                                   int64_t noise_stride, const uint64_t* __restrict__ d_seed, StepTables tb,
                                    const int* __restrict__ d_iter, int R, int dynamic_threshold, int64_t per4,
                                    int64_t total4) {
+  const uint64_t seed = *d_seed;  // device-resident: the captured step graph is seed-independent
   const int it = *d_iter;
   const int k = it / R;
   const float alpha = tb.alpha[k], alpha_next = tb.alpha_next[k], c = tb.c[k], ns = tb.noise_scale[k];
@@ -274,12 +281,12 @@ __global__ void ddpm_update_kernel(float* __restrict__ x, const float* __restric
   }
 }
 int launch_ddpm_update(float* x, const float* x0, const float* s_thresh, const float* noise, int64_t noise_stride,
-                       uint64_t seed, const StepTables& tb, const int* d_iter, int R, int dynamic_threshold, int B,
+                       const uint64_t* d_seed, const StepTables& tb, const int* d_iter, int R, int dynamic_threshold, int B,
                        int64_t per, hipStream_t s) {
   KD_REQUIRE(per % 4 == 0, "per-sample element count must be a multiple of 4");
   int64_t total4 = (int64_t)B * per / 4;
   hipLaunchKernelGGL(ddpm_update_kernel, dim3(grid_for(total4)), dim3(256), 0, s, x, x0, s_thresh, noise,
-                     noise_stride, seed, tb, d_iter, R, dynamic_threshold, per / 4, total4);
+                     noise_stride, d_seed, tb, d_iter, R, dynamic_threshold, per / 4, total4);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -288,8 +295,9 @@ int launch_ddpm_update(float* x, const float* x0, const float* s_thresh, const f
 // x = x*(1-m) + (alpha_t*inp + sigma_t*noise)*m        (mask [B,1,HW], image [B,C,HW])
 __global__ void inpaint_mix_kernel(float* __restrict__ x, const float* __restrict__ inp,
                                    const float* __restrict__ mask, const float* __restrict__ noise,
-                                   int64_t noise_stride, uint64_t seed, StepTables tb,
+                                   int64_t noise_stride, const uint64_t* __restrict__ d_seed, StepTables tb,
                                    const int* __restrict__ d_iter, int R, int C, int64_t hw4, int64_t total4) {
+  const uint64_t seed = *d_seed;
   const int it = *d_iter;
   const int k = it / R;
   const float alpha = tb.alpha[k], sigma = tb.sigma[k];
@@ -309,20 +317,21 @@ __global__ void inpaint_mix_kernel(float* __restrict__ x, const float* __restric
   }
 }
 int launch_inpaint_mix(float* x, const float* inp, const float* mask, const float* noise, int64_t noise_stride,
-                       uint64_t seed, const StepTables& tb, const int* d_iter, int R, int B, int C, int64_t hw,
+                       const uint64_t* d_seed, const StepTables& tb, const int* d_iter, int R, int B, int C, int64_t hw,
                        hipStream_t s) {
   KD_REQUIRE(hw % 4 == 0, "H*W must be a multiple of 4");
   int64_t total4 = (int64_t)B * C * hw / 4;
   hipLaunchKernelGGL(inpaint_mix_kernel, dim3(grid_for(total4)), dim3(256), 0, s, x, inp, mask, noise,
-                     noise_stride, seed, tb, d_iter, R, C, hw / 4, total4);
+                     noise_stride, d_seed, tb, d_iter, R, C, hw / 4, total4);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 // re-noise t_next -> t after a non-final resample:  x = x*rn_a + noise*rn_b   (skipped when r == 0 or last k)
 __global__ void renoise_kernel(float* __restrict__ x, const float* __restrict__ noise, int64_t noise_stride,
-                               uint64_t seed, StepTables tb, const int* __restrict__ d_iter, int R, int T,
-                               int64_t total4) {
+                               const uint64_t* __restrict__ d_seed, StepTables tb,
+                               const int* __restrict__ d_iter, int R, int T, int64_t total4) {
+  const uint64_t seed = *d_seed;
   const int it = *d_iter;
   const int k = it / R, ri = it - k * R;
   if (ri == R - 1 || k == T - 1) return;
@@ -336,10 +345,10 @@ __global__ void renoise_kernel(float* __restrict__ x, const float* __restrict__ 
     *(f32x4*)(x + i * 4) = o;
   }
 }
-int launch_renoise(float* x, const float* noise, int64_t noise_stride, uint64_t seed, const StepTables& tb,
+int launch_renoise(float* x, const float* noise, int64_t noise_stride, const uint64_t* d_seed, const StepTables& tb,
                    const int* d_iter, int R, int T, int B, int64_t per, hipStream_t s) {
   int64_t total4 = (int64_t)B * per / 4;
-  hipLaunchKernelGGL(renoise_kernel, dim3(grid_for(total4)), dim3(256), 0, s, x, noise, noise_stride, seed, tb,
+  hipLaunchKernelGGL(renoise_kernel, dim3(grid_for(total4)), dim3(256), 0, s, x, noise, noise_stride, d_seed, tb,
                      d_iter, R, T, total4);
   KD_HIP_CHECK(hipGetLastError());
   return 0;

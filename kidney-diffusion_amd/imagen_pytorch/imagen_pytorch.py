@@ -330,6 +330,7 @@ class Unet(nn.Module):
         nn.init.zeros_(self.final_conv.bias)
 
         self._engines = {}
+        self._io_buffers = {}  # per (batch, size, device): sampler inputs at stable addresses (step graph reuse)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_engine())
 
     # ---- library API used by Imagen
@@ -348,6 +349,7 @@ class Unet(nn.Module):
             if lib is not None:
                 lib.kd_unet_destroy(h)
         self._engines = {}
+        self._io_buffers = {}
 
     def _apply(self, fn, *a, **k):  # .to()/.cuda()/.float() move parameters: packed copies are stale
         self.invalidate_engine()
@@ -703,6 +705,21 @@ class Imagen(nn.Module):
             E.check(lib.kd_philox_normal(E.ptr(out), out.numel(), stage_seed, sid, E.current_stream()))
             return out
 
+        # The engine caches the captured step graph keyed on the device addresses it was captured with.
+        # Per-call tensors are therefore copied into per-(batch, size) buffers that keep their address,
+        # so that e.g. the 64 patches of an ultra-res grid replay one graph per stage instead of
+        # re-capturing it for every patch.
+        io = unet._io_buffers.setdefault((batch, size, device.index), {})
+
+        def stable(name, t):
+            if t is None:
+                return None
+            buf = io.get(name)
+            if buf is None or buf.shape != t.shape:
+                buf = io[name] = torch.empty_like(t)
+            buf.copy_(t)
+            return buf
+
         with torch.cuda.device(device):
             lowres = lowres_log_snr = None
             if unet.lowres_cond:
@@ -712,18 +729,18 @@ class Imagen(nn.Module):
                 lowres = resize_image_to(prev_img, size) * 2 - 1
                 lowres = (a.to(device)[:, None, None, None] * lowres
                           + s.to(device)[:, None, None, None] * gauss(("lowres", stage), lowres.shape, (16 << 32) | 1))
-                lowres = lowres.contiguous()
-                lowres_log_snr = ls.to(device)
+                lowres = stable("lowres", lowres.contiguous())
+                lowres_log_snr = stable("lowres_log_snr", ls.to(device))
             cond = None
             if exists(cond_images):
                 assert cond_images.shape[1] == unet.cond_images_channels, "invalid number of channels in conditioning image"
-                cond = f32(resize_image_to(f32(cond_images), size))
+                cond = stable("cond", f32(resize_image_to(f32(cond_images), size)))
             has_inpaint = exists(inpaint_images) and exists(inpaint_masks)
             R = resample_times if has_inpaint else 1
             inp = msk = None
             if has_inpaint:
-                inp = f32(resize_image_to(f32(inpaint_images) * 2 - 1, size))
-                msk = f32(resize_image_to(f32(inpaint_masks)[:, None], size).bool().float())
+                inp = stable("inpaint", f32(resize_image_to(f32(inpaint_images) * 2 - 1, size)))
+                msk = stable("mask", f32(resize_image_to(f32(inpaint_masks)[:, None], size).bool().float()))
             T = sched.num_timesteps
             tables = sched.step_tables()
             sc = E.kd_schedule_t()
@@ -751,16 +768,18 @@ class Imagen(nn.Module):
                     args.d_noise_inpaint = stack("inpaint")
                     if R > 1:
                         args.d_noise_renoise = stack("renoise")
-            img = gauss(("init", stage), shape, (16 << 32) | 2)
+            img = stable("img", gauss(("init", stage), shape, (16 << 32) | 2))
             with_text = exists(text_embeds) and unet.cond_on_text
             h = unet.engine(batch, size, device, with_text=with_text)
             if with_text:  # step-invariant: pooled text tokens + text hiddens, once per stage
                 tok, hid = unet.text_cond(h, text_embeds, text_masks, drop=False, device=device)
+                tok, hid = stable("text_tokens", tok), stable("text_hiddens", hid)
                 keep += [tok, hid]
                 args.d_text_tokens, args.d_text_hiddens = E.ptr(tok), E.ptr(hid)
                 args.cond_scale = cond_scale
                 if cond_scale != 1.0:  # classifier-free guidance: null conditioning for the second forward
                     ntok, nhid = unet.text_cond(h, text_embeds, text_masks, drop=True, device=device)
+                    ntok, nhid = stable("null_text_tokens", ntok), stable("null_text_hiddens", nhid)
                     keep += [ntok, nhid]
                     args.d_null_text_tokens, args.d_null_text_hiddens = E.ptr(ntok), E.ptr(nhid)
             if exists(trace):
@@ -772,4 +791,5 @@ class Imagen(nn.Module):
                 E.check(lib.kd_sample_loop(h, C.byref(sc), C.byref(args), E.ptr(img), E.current_stream()))
             torch.cuda.current_stream().synchronize()  # host tables / noise buffers must outlive the launches
             del keep
+            img = img.clone()  # the stable buffer is overwritten by the next call
         return img

@@ -50,6 +50,10 @@ CONV_REL = 2e-6
     (2, 20, 24, 12, 32, 15, 1, 7, 0x100),  # row-run K layout (init conv k=15 over 12 padded channels)
     (1, 33, 17, 12, 16, 7, 1, 3, 0x100),   # row-run, k=7, ragged image
     (3, 16, 16, 8, 64, 3, 1, 1, 0x101),    # row-run, k=3, SiLU
+    (1, 8, 8, 1024, 1024, 3, 1, 1, 0),     # split-K: one batch-1 patch at the 8x8 level (M = 64, 288 K-chunks)
+    (1, 9, 7, 512, 200, 3, 1, 1, 1),       # split-K, ragged M = 63 and Cout = 200, SiLU after the reduction
+    (1, 16, 16, 512, 320, 1, 1, 0, 2),     # split-K of a 1x1 conv (16 chunks), GELU
+    (2, 8, 8, 96, 128, 2, 2, 0, 0),        # M = 32, K too short to split: generic small-M kernel
 ])
 def test_conv_igemm(lib, device, B, H, W, Cin, Cout, K, stride, pad, act):
     E = _E()
