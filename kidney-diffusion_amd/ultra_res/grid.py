@@ -7,9 +7,12 @@ Reference being mirrored (jameshball/kidney-diffusion):
   dependency rule     sample_ultra_res.py:92-107, :141-143 and get_next_patches :403-412
   orientation         sample_ultra_res.py:423-426
   inpaint patch/mask  sample_ultra_res.py:147-170 (+ fallback crops :128-140)
+  tissue filter       sample_ultra_res.py:317-352 (mag 2: HSV threshold, 5x5 erode, 51x51 dilate, any-pixel test)
   cond images         sample_ultra_res.py:356-400 (roll / fill / centre crop)
   stitch              sample_ultra_res.py:434-446, outpainting.py:232-243
-Everything here is integer geometry or tensor slicing; no model arithmetic.
+Everything here is integer geometry, tensor slicing or pooling; no model arithmetic.  The functions
+run on whatever device their tensors live on: with the zoomed image in HBM the conditioning images
+and the tissue mask never touch the host (the reference builds them with numpy / skimage / cv2).
 """
 from __future__ import annotations
 
@@ -139,6 +142,50 @@ def assemble_inpaint(pos: Pos, patch_pos: Sequence[Pos], done: Dict[Pos, torch.T
         else:
             patch[:, :ov, -ov:] = an[:, -ov:, :ov]
     return patch, mask
+
+
+def rgb_to_hsv(img: torch.Tensor) -> torch.Tensor:
+    """(3,H,W) RGB in [0,1] -> (3,H,W) HSV with skimage.color.rgb2hsv's conventions (the reference
+    calls it at sample_ultra_res.py:321): v = max, s = (max-min)/max (0 where max-min == 0), h from the
+    channel that attains the max with blue taking precedence over green over red on ties, h in [0,1)."""
+    r, g, b = img[0], img[1], img[2]
+    v = img.max(0).values
+    delta = v - img.min(0).values
+    safe = torch.where(delta == 0, torch.ones_like(delta), delta)
+    h = torch.zeros_like(v)
+    h = torch.where(r == v, (g - b) / safe, h)
+    h = torch.where(g == v, 2.0 + (b - r) / safe, h)
+    h = torch.where(b == v, 4.0 + (r - g) / safe, h)
+    h = torch.remainder(h / 6.0, 1.0)
+    h = torch.where(delta == 0, torch.zeros_like(h), h)
+    s = torch.where(delta == 0, torch.zeros_like(v), delta / torch.where(v == 0, torch.ones_like(v), v))
+    return torch.stack((h, s, v))
+
+
+def tissue_mask(zoomed_image: torch.Tensor, version: str = "ultra", erode: int = 5, dilate: int = 51) -> torch.Tensor:
+    """(H,W) bool mask of tissue in the mag-1 canvas (sample_ultra_res.py:317-333): HSV threshold
+    (hue > 0.5 and saturation > 0.02; value > 0.1 for 'airs'), 5x5 erosion to drop small objects, 51x51
+    dilation to grow the mask.  cv2's default border (erode ignores, dilate ignores pixels outside the
+    image) is what max-pooling's implicit -inf padding gives.  Runs on the tensor's device."""
+    hsv = rgb_to_hsv(zoomed_image[0].float())
+    m = (hsv[2] > 0.1) if version == "airs" else ((hsv[0] > 0.5) & (hsv[1] > 0.02))
+    m = m.float()[None, None]
+    m = -F.max_pool2d(-m, erode, stride=1, padding=erode // 2)
+    m = F.max_pool2d(m, dilate, stride=1, padding=dilate // 2)
+    return m[0, 0] > 0.5
+
+
+def tissue_patch_positions(mask: torch.Tensor, geom: GridGeometry) -> List[Pos]:
+    """Grid positions whose footprint in the zoomed image touches the mask (sample_ultra_res.py:343-352)."""
+    # any() over every footprint at once: a max-pool with the patch as the window, evaluated at the stride
+    pw, dist, n = geom.patch_width, geom.patch_dist, geom.num_patches_width
+    H, W = mask.shape
+    need = (n - 1) * dist + pw
+    m = mask.float()
+    if need > H or need > W:  # footprints that hang over the edge see only the part inside, as numpy slicing does
+        m = F.pad(m, (0, max(0, need - W), 0, max(0, need - H)))
+    hit = F.max_pool2d(m[None, None], pw, stride=dist)[0, 0]
+    return [(i, j) for i in range(n) for j in range(n) if bool(hit[i, j] > 0.5)]
 
 
 def cond_images_for_grid(zoomed_image: torch.Tensor, geom: GridGeometry, patch_pos: Sequence[Pos],

@@ -137,3 +137,72 @@ def test_two_rank_gloo_schedule_equals_single_process():
     assert torch.equal(out[0], single) and torch.equal(out[1], single)
     # stage 2 really consumed stage 1 and the neighbours: overlaps were pasted from finished patches
     assert single.shape == (2, 9, 3, 256, 256)
+
+
+def _np_rgb2hsv(arr):
+    """skimage.color.rgb2hsv restated in numpy ((H,W,3) floats), the function the reference calls at
+    sample_ultra_res.py:321."""
+    import numpy as np
+
+    out = np.empty_like(arr)
+    v = arr.max(-1)
+    delta = np.ptp(arr, -1)
+    old = np.seterr(invalid="ignore", divide="ignore")
+    s = delta / v
+    s[delta == 0.0] = 0.0
+    idx = arr[..., 0] == v
+    out[idx, 0] = (arr[idx, 1] - arr[idx, 2]) / delta[idx]
+    idx = arr[..., 1] == v
+    out[idx, 0] = 2.0 + (arr[idx, 2] - arr[idx, 0]) / delta[idx]
+    idx = arr[..., 2] == v
+    out[idx, 0] = 4.0 + (arr[idx, 0] - arr[idx, 1]) / delta[idx]
+    h = (out[..., 0] / 6.0) % 1.0
+    h[delta == 0.0] = 0.0
+    np.seterr(**old)
+    return np.stack((h, np.nan_to_num(s), v), -1)
+
+
+def _np_morph(m, k, op):
+    """cv2.erode / cv2.dilate with a k x k ones kernel and the default border (outside pixels ignored)."""
+    import numpy as np
+
+    H, W = m.shape
+    r = k // 2
+    out = np.empty_like(m)
+    for y in range(H):
+        for x in range(W):
+            win = m[max(0, y - r):y + r + 1, max(0, x - r):x + r + 1]
+            out[y, x] = win.min() if op == "erode" else win.max()
+    return out
+
+
+@pytest.mark.parametrize("version", ["ultra", "airs"])
+def test_tissue_mask_and_patch_filter_match_the_reference_recipe(version):
+    import numpy as np
+
+    g = torch.Generator().manual_seed(21)
+    S = 96
+    img = torch.rand(1, 3, S, S, generator=g) * 0.08 + 0.9          # near-white background
+    img[0, :, 20:40, 30:70] = torch.tensor([0.75, 0.35, 0.8])[:, None, None]   # a purple (hue 0.8) tissue blob
+    img[0, :, 70:72, 5:7] = torch.tensor([0.7, 0.3, 0.8])[:, None, None]       # 2x2 speck: removed by the 5x5 erosion
+    img[0, :, 50:60, 50:60] = 0.5                                              # grey square: delta == 0 -> hue 0
+    img[0, :, 0, 0] = 0.0                                                      # black pixel: v == 0
+    hsv = G.rgb_to_hsv(img[0])
+    ref_hsv = _np_rgb2hsv(img[0].permute(1, 2, 0).numpy().astype(np.float32))
+    assert np.allclose(hsv.permute(1, 2, 0).numpy(), ref_hsv, atol=1e-6)
+
+    erode, dilate = 5, 11
+    mask = G.tissue_mask(img, version=version, erode=erode, dilate=dilate)
+    ref = ref_hsv[..., 2] > 0.1 if version == "airs" else np.logical_and(ref_hsv[..., 0] > 0.5, ref_hsv[..., 1] > 0.02)
+    ref = _np_morph(_np_morph(ref.astype(np.uint8), erode, "erode"), dilate, "dilate")
+    assert np.array_equal(mask.numpy(), ref > 0.5)
+    if version == "ultra":
+        assert mask[30, 50] and not mask[71, 6] and not mask[55, 55]
+
+    geom = G.GridGeometry(patch_width=20, patch_dist=15, num_patches_width=7, out_patch_dist=768, canvas_width=0)
+    got = G.tissue_patch_positions(mask, geom)
+    want = [(i, j) for i in range(7) for j in range(7)
+            if np.any(ref[i * 15:i * 15 + 20, j * 15:j * 15 + 20] > 0.5)]   # sample_ultra_res.py:343-352
+    assert got == want
+    if version == "ultra":
+        assert 0 < len(got) < 49
