@@ -83,7 +83,7 @@ int launch_wino_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s)
 // V[p][t][c] = (B^T d B)[p] of the 4x4 input tile of output tile t, d = SiLU(GroupNorm/FiLM(x)) when
 // stats != nullptr (same arguments as launch_gn_apply_silu), d = x otherwise; zero padding outside.
 // Both transforms work on a slice [t0, t0+nt) of the B*(H/2)*(W/2) output tiles; V and D are
-// [16][nt][C] for that slice (the plan walks a map in slices that stay in the 256 MB Infinity Cache).
+// [16][nt][C] for that slice (KD_WINO_SLICE_MB bounds the workspace; one slice by default).
 int launch_wino_in(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
                    const float* scale_shift, int ld_ss, float* V, int B, int H, int W, int C, int G, int64_t t0,
                    int64_t nt, hipStream_t s);

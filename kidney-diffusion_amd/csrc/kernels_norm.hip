@@ -25,7 +25,8 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 constexpr int GN_ROWS_PER_BLOCK = 256;
 
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int ldx,
-                                                         double* __restrict__ partial, int HW, int C, int G) {
+                                                         double* __restrict__ partial, float* __restrict__ stats,
+                                                         int HW, int C, int G, double count, float eps) {
   const int g = blockIdx.y, b = blockIdx.z, chunk = blockIdx.x;
   const int Cg = C / G;
   const int Cg4 = Cg >> 2;
@@ -56,6 +57,14 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
   if (threadIdx.x == 0) {
     double ts = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     double tss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (gridDim.x == 1) {  // small map: this workgroup saw the whole group, no finalize launch needed
+      double mean = ts / count;
+      double var = tss / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      stats[(b * G + g) * 2] = (float)mean;
+      stats[(b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+      return;
+    }
     int64_t o = (((int64_t)b * G + g) * gridDim.x + chunk) * 2;
     partial[o] = ts;
     partial[o + 1] = tss;
@@ -87,10 +96,16 @@ int launch_gn_stats(const float* x, int ldx, float* stats, double* partial, int 
                     float eps, hipStream_t s) {
   KD_REQUIRE(C % G == 0 && (C / G) % 4 == 0 && ldx % 4 == 0, "GroupNorm needs (C/G) % 4 == 0");
   int chunks = (HW + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, G, B), dim3(256), 0, s, x, ldx, partial, HW, C, G);
-  int BG = B * G;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((BG + 63) / 64), dim3(64), 0, s, partial, stats, chunks, BG,
-                     (double)HW * (C / G), eps);
+  const double count = (double)HW * (C / G);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, G, B), dim3(256), 0, s, x, ldx, partial, stats, HW, C, G, count,
+                     eps);
+  // (a single-launch version in which the last workgroup to arrive reduces the partials was measured:
+  //  its per-workgroup __threadfence - an L2 write-back on this multi-XCD part - cost 12 ms per step)
+  if (chunks > 1) {
+    int BG = B * G;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((BG + 63) / 64), dim3(64), 0, s, partial, stats, chunks, BG, count,
+                       eps);
+  }
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
