@@ -372,12 +372,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
     if (cur_cc == chunks_per_tap) next_tap();
     __attribute__((address_space(3))) float* sb =
         (__attribute__((address_space(3))) float*)(stage_base + wave * 8 * BK);
+    // the scalar offsets are wave-uniform, but hipcc keeps them in VGPRs and would wrap every load in a
+    // readfirstlane waterfall loop (10 instructions + exec juggling per load): pin them to SGPRs
+    const uint32_t sa = __builtin_amdgcn_readfirstlane(soffA), sbo = __builtin_amdgcn_readfirstlane(soffB);
 #pragma unroll
     for (int q = 0; q < A_PASSES; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, sb + q * ROWS_PER_PASS * BK, 16, voffA[q], soffA, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, sb + q * ROWS_PER_PASS * BK, 16, voffA[q], sa, 0, 0);
 #pragma unroll
     for (int q = 0; q < B_PASSES; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, sb + BM * BK + q * ROWS_PER_PASS * BK, 16, voffB[q], soffB, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, sb + BM * BK + q * ROWS_PER_PASS * BK, 16, voffB[q], sbo, 0, 0);
     soffA += BK * 4;
     soffB += BK * 4;
     ++cur_cc;
