@@ -399,6 +399,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
   const int khalf = lane >> 5;
   const int a_row = (wm * TM * 32 + frow) * BK;
   const int b_row = BM * BK + (wn * TN * 32 + frow) * BK;
+  // (reading the fragments of k-group kk+1 ahead of the MFMAs of group kk - two register sets and a
+  //  sched_barrier so that hipcc does not sink the ds_reads - was measured: no change, the partner wave
+  //  of the SIMD already covers the LDS latency)
   auto compute = [&](const float* base) {
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
@@ -427,18 +430,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
     soffB += (uint32_t)cur_cc * BK * 4;
   }
   issue(s0);
-  for (int c = c_begin; c < c_end; c += 2) {
-    if (c + 1 < c_end) {
-      issue(s1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+  // Two chunks per trip with static stage addresses and ONE loop exit: with a `break` between the two
+  // halves hipcc kept two copies of the 64 accumulator registers and moved one onto the other on every
+  // trip (32 v_mov_b64 behind a drained MFMA pipe).  An odd last chunk is handled after the loop.
+  int c = c_begin;
+  for (; c + 1 < c_end; c += 2) {
+    issue(s1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
     __builtin_amdgcn_s_barrier();
     compute(s0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (c + 1 >= c_end) break;
     if (c + 2 < c_end) {
       issue(s0);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
@@ -447,6 +449,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
     }
     __builtin_amdgcn_s_barrier();
     compute(s1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (c < c_end) {  // odd chunk count: the last chunk is in stage 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    compute(s0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
