@@ -319,7 +319,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
     __syncthreads();
   }
 
-  store_tile<BM, BN, WAVES_M, WAVES_N>(p, lds, acc, m0, n0, M);
+  if (p.out_mode == OUT_NHWC && (!p.gate_src || (((p.Ho * p.Wo) & 31) == 0 && !p.res && p.act == ACT_NONE)))
+    store_tile_regs<BM, BN, WAVES_M, WAVES_N>(p, acc, m0, n0, M);
+  else
+    store_tile<BM, BN, WAVES_M, WAVES_N>(p, lds, acc, m0, n0, M);
 }
 
 // ------------------------------------------------------------------------------------------------
