@@ -898,6 +898,174 @@ static void launch_buf(const ConvParams& p, hipStream_t s) {
   if (e != hipSuccess) fprintf(stderr, "conv_buf launch: %s\n", hipGetErrorString(e));
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3-stage ring: BK = 16 (64-B LDS rows, 4 x 16-B slots XOR-swizzled by (row>>2)&3), prefetch distance
+// 2, ONE barrier per chunk, 16 KB per stage -> 48 KB per workgroup -> 3 workgroups (3 waves/SIMD) per
+// CU with the 133-VGPR budget of the v6 loop.  128x128 tile, 4 waves, register epilogue (bias only).
+constexpr int RK = 16;
+
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void conv_ring_kernel(ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WAVES_N = 2, NLOADS = 4;
+  constexpr int STAGE = (BM + BN) * RK;  // floats
+  __shared__ __attribute__((aligned(1024))) float lds[3 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int64_t M = (int64_t)p.B * p.Ho * p.Wo;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int lrow = tid >> 2;                       // 0..63: 16 rows per wave-instruction
+  const int gseg = (tid & 3) ^ ((lrow >> 2) & 3);  // LDS slot s of row r holds logical 16-B segment s ^ ((r>>2)&3)
+
+  const bool gemm = p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0;
+  const int hw = p.Ho * p.Wo;
+  const int img0 = gemm ? 0 : (int)(m0 / hw);
+  const int64_t img_elems = (int64_t)p.Hi * p.Wi * p.ldx;
+  const int64_t a_total = gemm ? (M - m0 < BM ? M - m0 : (int64_t)BM) * p.ldx * 4 : ((int64_t)p.B - img0) * img_elems * 4;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.x + (gemm ? m0 * p.ldx : (int64_t)img0 * img_elems)), 0,
+      (int)(a_total > 0x7fffffff ? 0x7fffffff : a_total), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.w, 0, (int)((int64_t)p.KH * p.KW * p.Cout * p.Cin * 4), 0x00020000);
+
+  int a_iy0[2], a_ix0[2], a_img[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int64_t m = m0 + lrow + q * 64;
+    if (m < M && gemm) {
+      a_iy0[q] = 0; a_ix0[q] = 0; a_img[q] = lrow + q * 64;
+    } else if (m < M) {
+      int b = (int)(m / hw);
+      int rem = (int)(m - (int64_t)b * hw);
+      int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_iy0[q] = oy * p.stride - p.pad;
+      a_ix0[q] = ox * p.stride - p.pad;
+      a_img[q] = (b - img0) * p.Hi * p.Wi;
+    } else {
+      a_iy0[q] = 0; a_ix0[q] = 0; a_img[q] = -1;
+    }
+  }
+  uint32_t voffA[2], voffB[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int n = n0 + lrow + q * 64;
+    voffB[q] = n < p.Cout ? (uint32_t)((n * p.Cin + gseg * 4) * 4) : OOB_OFF;
+  }
+  const int chunks_per_tap = p.Cin / RK;
+  const int nchunks = p.KH * p.KW * chunks_per_tap;
+  int cur_tap = -1, cur_cc = chunks_per_tap;
+  uint32_t soffA = 0, soffB = 0;
+  const uint32_t tap_stride_b = (uint32_t)p.Cout * p.Cin * 4;
+
+  auto next_tap = [&]() {
+    ++cur_tap;
+    cur_cc = 0;
+    int kh = cur_tap / p.KW, kw = cur_tap - kh * p.KW;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int iy = a_iy0[q] + kh, ix = a_ix0[q] + kw;
+      bool ok = a_img[q] >= 0 && (gemm || (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi));
+      int pix = gemm ? a_img[q] : a_img[q] + iy * p.Wi + ix;
+      voffA[q] = ok ? (uint32_t)((pix * p.ldx + gseg * 4) * 4) : OOB_OFF;
+    }
+    soffA = 0;
+    soffB = (uint32_t)cur_tap * tap_stride_b;
+  };
+  auto issue = [&](int st) {
+    if (cur_cc == chunks_per_tap) next_tap();
+    __attribute__((address_space(3))) float* sb =
+        (__attribute__((address_space(3))) float*)(lds + st * STAGE + wave * 16 * RK);
+    const uint32_t sa = __builtin_amdgcn_readfirstlane(soffA), sbo = __builtin_amdgcn_readfirstlane(soffB);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, sb + q * 64 * RK, 16, voffA[q], sa, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, sb + BM * RK + q * 64 * RK, 16, voffB[q], sbo, 0, 0);
+    soffA += RK * 4;
+    soffB += RK * 4;
+    ++cur_cc;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31;
+  const int fsw = (frow >> 2) & 3;
+  const int khalf = lane >> 5;
+  const int a_row = (wm * TM * 32 + frow) * RK;
+  const int b_row = BM * RK + (wn * TN * 32 + frow) * RK;
+  auto compute = [&](int st) {
+    const float* base = lds + st * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < RK / 8; ++kk) {
+      const int slot = ((2 * kk + khalf) ^ fsw) * 4;
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(base + a_row + i * 32 * RK + slot);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(base + b_row + j * 32 * RK + slot);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  issue(0);
+  if (nchunks > 1) issue(1);
+  int st = 0, st2 = 2;
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // chunk c visible to all waves; everyone is done with chunk c-1's stage
+    if (c + 2 < nchunks) issue(st2);
+    compute(st);
+    st = st == 2 ? 0 : st + 1;
+    st2 = st2 == 2 ? 0 : st2 + 1;
+  }
+
+  // register epilogue (bias only), as store_tile_regs in kernels_conv.hip
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+    if (n >= p.Cout) continue;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int64_t mb = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+      float* yp = p.y + mb * p.ldy + n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (mb + dr < M) yp[(int64_t)dr * p.ldy] = acc[i][j][r] + bias;
+      }
+    }
+  }
+#endif
+}
+
+template <int MINW>
+static void launch_ring(const ConvParams& p, hipStream_t s) {
+  int64_t M = (int64_t)p.B * p.Ho * p.Wo;
+  dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 127) / 128);
+  hipLaunchKernelGGL((conv_ring_kernel<MINW>), grid, dim3(256), 0, s, p);
+}
+
 __global__ void fill_rand_kernel(float* p, int64_t n, uint32_t seed) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t x = (uint32_t)i * 747796405u + seed;
@@ -971,6 +1139,8 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
       case 22: { ConvParams q = p; q.act = 1; launch_buf<128, 128, 2, 2, 2>(q, 0); } break;  // stagger 1k cycles
       case 23: { ConvParams q = p; q.act = 2; launch_buf<128, 128, 2, 2, 2>(q, 0); } break;  // stagger 2k
       case 24: { ConvParams q = p; q.act = 4; launch_buf<128, 128, 2, 2, 2>(q, 0); } break;  // stagger 4k
+      case 40: launch_ring<3>(p, 0); break;   // BK=16 3-stage ring, 1 barrier/chunk, 3 workgroups per CU
+      case 41: launch_ring<2>(p, 0); break;   // same, 2 workgroups per CU
       default: break;
     }
   };
