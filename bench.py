@@ -58,6 +58,56 @@ def synthetic_inputs(batch, device=None, seed=1234):
     return mv(x), mv(lowres), mv(lowres_noise), mv(cond)
 
 
+def kernel_classes(lib, handle, iters=3):
+    """Per-kernel-class rates of one UNet forward, measured live with HIP events around every launch
+    (`kd_unet_profile`, include/kd_engine.h): algorithmic FLOPs (or bytes) of the launches of a class
+    divided by their summed device time.  The step graph replays exactly these launches."""
+    import re
+
+    from imagen_pytorch import _engine as E
+
+    buf = C.create_string_buffer(1 << 20)
+    E.check(lib.kd_unet_profile(handle, iters, buf, len(buf), E.current_stream()))
+    rows = [l.split(",") for l in buf.value.decode().strip().split("\n")[1:]]
+    cls = {}
+
+    def add(key, us, flop=0.0, nbytes=0.0):
+        c = cls.setdefault(key, [0, 0.0, 0.0, 0.0])
+        c[0] += 1
+        c[1] += us
+        c[2] += flop
+        c[3] += nbytes
+
+    total_us = 0.0
+    for _, label, macs, us in rows:
+        us, macs = float(us), int(macs)
+        total_us += us
+        m = re.match(r"(wino_in|wino_out|wino gemm) M(\d+) Cin(\d+) Cout(\d+)", label)
+        if label.startswith("conv k3"):
+            add("conv_buf_kernel: direct 3x3 convs", us, flop=2.0 * macs)
+        elif m and m.group(1) == "wino gemm":
+            add("conv_buf_kernel: Winograd position GEMMs", us, flop=2.0 * macs)
+        elif m:  # transforms move 5x the map: read 1x / write 4x (in), read 4x / write 1x (out)
+            ch = int(m.group(3)) if m.group(1) == "wino_in" else int(m.group(4))
+            add("wino_in_kernel + wino_out_kernel (Winograd transforms)", us, nbytes=20.0 * int(m.group(2)) * ch)
+        elif label.startswith("conv") or label.startswith("skinny"):
+            add("other conv / GEMM launches (1x1, 2x2-s2, init, final, skinny)", us, flop=2.0 * macs)
+        else:
+            add("GroupNorm, LayerNorm, attention core, GlobalContext, concat, gate (HBM-bound)", us)
+    out = []
+    for key, (n, us, flop, nbytes) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
+        e = {"kernel": key, "launches": n, "ms": us / 1e3, "share": us / total_us}
+        if flop:
+            e.update(bound="mfma", achieved=flop / us / 1e6, unit="TFLOP/s", frac=flop / us / 1e6 / FP32_PEAK_TFLOPS)
+            if "Winograd position" in key:
+                e["issued"] = e["achieved"] * 16.0 / 36.0  # what the matrix pipe executes for those FLOPs
+                e["frac_issued"] = e["issued"] / FP32_PEAK_TFLOPS
+        elif nbytes:
+            e.update(bound="hbm", achieved=nbytes / us / 1e3, unit="GB/s", frac=nbytes / us / 1e3 / 8000.0)
+        out.append(e)
+    return out
+
+
 def cpu_baseline(unet_product, device_tables):
     """The oracle (CPU fp32 torch restatement) timed on this host, bounded sample: batch 2 (1/8 of the
     headline batch), one warm-up step + one timed step.  steps/s is scaled to batch 16."""
@@ -316,6 +366,7 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         dev_ms_per_step = dev_ms / args.steps
         achieved = flop_per_step / (dev_ms_per_step * 1e-3) / 1e12
+        kernels = kernel_classes(lib, handle) if world == 1 else None
         traffic = None
         tf = ROOT / "profiles" / "hbm_traffic.json"
         if tf.exists():
@@ -343,7 +394,8 @@ def main():
                                    f"MFMA peak.  'issued' = the {2.0 * mfma_macs / 1e12:.3f} TFLOP the conv/GEMM "
                                    "launches actually put on the matrix cores: ResnetBlock 3x3 convs with Cin >= 256 "
                                    "run as Winograd F(2x2,3x3) in fp32 (2.25x fewer MACs), so 'achieved' can exceed "
-                                   "what the MFMA pipe executes"},
+                                   "what the MFMA pipe executes",
+                         "kernels": kernels},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(unet, tables)
