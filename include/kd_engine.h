@@ -80,9 +80,16 @@ typedef struct kd_unet kd_unet_t;
  * caller may free its tensors afterwards) and allocates the activation workspace. */
 int kd_unet_create(const kd_unet_config_t* cfg, const kd_param_t* params, int n_params,
                    kd_unet_t** out);
+/* Same, for another (batch, image_size[, conv_algo]) plan of the SAME UNet: the new plan shares the
+ * packed weights of `share_with` (and packs only the forms that plan does not have yet), so a UNet
+ * sampled at several batch sizes keeps one copy of its weights in HBM.  `params` must hold the same
+ * values as when `share_with` was created.  The store lives until the last plan is destroyed. */
+int kd_unet_create_shared(const kd_unet_config_t* cfg, const kd_param_t* params, int n_params,
+                          const kd_unet_t* share_with, kd_unet_t** out);
 void kd_unet_destroy(kd_unet_t* u);
 /* bytes of HBM held (weights + workspace) and algorithmic MACs of one forward (whole batch) */
 int64_t kd_unet_hbm_bytes(const kd_unet_t* u);
+int64_t kd_unet_weight_bytes(const kd_unet_t* u);  /* the (possibly shared) packed-weight store alone */
 int64_t kd_unet_macs(const kd_unet_t* u);
 /* MACs the conv / GEMM launches of one step actually issue on the matrix cores: smaller than
  * kd_unet_macs where a 3x3 conv runs as Winograd F(2x2,3x3) (16/36 of its MACs) and by the

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <functional>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -58,6 +59,13 @@ struct WeightPool {  // engine-owned HBM for weights, bump-allocated from 256 Mi
   ~WeightPool() {
     for (void* p : slabs) (void)hipFree(p);
   }
+};
+
+// Packed weights of ONE UNet, shared by all its plans (batch / image-size variants made with
+// kd_unet_create_shared): a packed form is produced the first time a plan asks for it.
+struct WeightStore {
+  WeightPool pool;
+  std::unordered_map<std::string, float*> cache;
 };
 
 struct Arena {  // plan-time activation allocator with reuse (single in-order stream => safe)
@@ -129,7 +137,7 @@ struct kd_unet {
   std::vector<std::function<int(hipStream_t)>> ops;
   std::vector<std::string> op_label;  // per-op description + algorithmic MACs (kd_unet_profile)
   std::vector<int64_t> op_macs;
-  WeightPool wpool;
+  std::shared_ptr<WeightStore> wstore;
   char* ws = nullptr;
   size_t ws_bytes = 0;
   int64_t macs = 0;       // algorithmic MACs of one forward as the reference computes it
@@ -177,7 +185,6 @@ struct Builder {
   kd_unet* u;
   Arena arena;
   std::unordered_map<std::string, std::pair<const float*, int64_t>> params;
-  std::unordered_map<std::string, const float*> owned;  // engine-owned copies of raw params
   const kd_unet_config_t& cfg;
   int B;
   // batched time-MLP: every ResnetBlock's Linear(time_cond_dim, 2*dim_out) in one skinny GEMM
@@ -208,36 +215,45 @@ struct Builder {
                                " elements, plan expects " + std::to_string(expect));
     return it->second.first;
   }
+  // Engine-owned weight buffer `key` of this UNet: allocated and filled by `make(dst)` the first time any
+  // plan of the UNet asks for it (the store is shared between plans, see kd_unet_create_shared).
+  template <class F>
+  float* cached(const std::string& key, size_t n_floats, F make) {
+    auto& c = u->wstore->cache;
+    auto it = c.find(key);
+    if (it != c.end()) return it->second;
+    float* dst = u->wstore->pool.alloc(n_floats);
+    make(dst);
+    c[key] = dst;
+    return dst;
+  }
   const float* P(const std::string& n, int64_t expect = -1) {  // engine-owned copy, torch layout
-    auto it = owned.find(n);
-    if (it != owned.end()) return it->second;
     const float* src = raw(n, expect);
     int64_t ne = numel(n);
-    float* dst = u->wpool.alloc((size_t)ne);
-    KD_HIP_THROW(hipMemcpyAsync(dst, src, (size_t)ne * sizeof(float), hipMemcpyDeviceToDevice, 0));
-    owned[n] = dst;
-    return dst;
+    return cached("raw:" + n, (size_t)ne, [&](float* dst) {
+      KD_HIP_THROW(hipMemcpyAsync(dst, src, (size_t)ne * sizeof(float), hipMemcpyDeviceToDevice, 0));
+    });
   }
   const float* pack_conv(const std::string& n, int O, int I, int Ipad, int K) {
     const float* src = raw(n, (int64_t)O * I * K * K);
-    float* dst = u->wpool.alloc((size_t)O * Ipad * K * K);
-    KD_THROW_IF(launch_pack_oihw(src, dst, O, I, Ipad, K, K, 0));
-    return dst;
+    return cached("tap:" + n + ":" + std::to_string(Ipad), (size_t)O * Ipad * K * K,
+                  [&](float* dst) { KD_THROW_IF(launch_pack_oihw(src, dst, O, I, Ipad, K, K, 0)); });
   }
 
   const float* pack_conv_rowrun(const std::string& n, int O, int I, int Ipad, int K) {
     const float* src = raw(n, (int64_t)O * I * K * K);
-    float* dst = u->wpool.alloc((size_t)O * Ipad * K * K);
-    KD_THROW_IF(launch_pack_oihw_rowrun(src, dst, O, I, Ipad, K, K, 0));
-    return dst;
+    return cached("rowrun:" + n + ":" + std::to_string(Ipad), (size_t)O * Ipad * K * K,
+                  [&](float* dst) { KD_THROW_IF(launch_pack_oihw_rowrun(src, dst, O, I, Ipad, K, K, 0)); });
   }
 
   const float* pack_conv_rowrun_sub(const std::string& n, int O, int Itot, int a0, int na, int b0, int nb, int Ipad,
                                     int K) {
     const float* src = raw(n, (int64_t)O * Itot * K * K);
-    float* dst = u->wpool.alloc((size_t)O * Ipad * K * K);
-    KD_THROW_IF(launch_pack_oihw_rowrun_sub(src, dst, O, Itot, a0, na, b0, nb, Ipad, K, K, 0));
-    return dst;
+    const std::string key = "rowrun_sub:" + n + ":" + std::to_string(a0) + "," + std::to_string(na) + "," +
+                            std::to_string(b0) + "," + std::to_string(nb) + "," + std::to_string(Ipad);
+    return cached(key, (size_t)O * Ipad * K * K, [&](float* dst) {
+      KD_THROW_IF(launch_pack_oihw_rowrun_sub(src, dst, O, Itot, a0, na, b0, nb, Ipad, K, K, 0));
+    });
   }
 
   // ---- activations
@@ -551,8 +567,9 @@ struct Builder {
     const float* gamma = P(gn_prefix + ".weight", Cin);
     const float* beta = P(gn_prefix + ".bias", Cin);
     const float* bias = P(conv_prefix + ".bias", Cout);
-    float* U = u->wpool.alloc((size_t)16 * Cout * Cin);
-    KD_THROW_IF(launch_wino_pack(raw(conv_prefix + ".weight", (int64_t)Cout * Cin * 9), U, Cout, Cin, 0));
+    const float* wsrc = raw(conv_prefix + ".weight", (int64_t)Cout * Cin * 9);
+    float* U = cached("wino:" + conv_prefix, (size_t)16 * Cout * Cin,
+                      [&](float* dst) { KD_THROW_IF(launch_wino_pack(wsrc, dst, Cout, Cin, 0)); });
     if (gn_partial_bytes(Bx, HW, Cin, G) > gn_partial_max) throw std::runtime_error("gn partial scratch too small");
     // The map can be walked in slices of tiles (V and D are 4x the slice each) to bound the workspace:
     // KD_WINO_SLICE_MB caps V+D per slice.  Default: one slice - slices small enough to stay in the
@@ -694,16 +711,21 @@ struct Builder {
 
   T downsample(const T& x, const std::string& pre, int dim_out) {  // pixel-unshuffle + conv1x1 == 2x2/s2 conv
     const float* src = raw(pre + ".1.weight", (int64_t)dim_out * 4 * x.C);
-    float* w = u->wpool.alloc((size_t)dim_out * 4 * x.C);
-    KD_THROW_IF(launch_pack_unshuffle(src, w, dim_out, x.C, 0));
+    const int C = x.C;
+    float* w = cached("unshuffle:" + pre, (size_t)dim_out * 4 * C,
+                      [&](float* dst) { KD_THROW_IF(launch_pack_unshuffle(src, dst, dim_out, C, 0)); });
     return conv(x, w, P(pre + ".1.bias", dim_out), dim_out, 2, 2, 0, ConvOpt());
   }
   T upsample(const T& x, const std::string& pre, int dim_out) {  // conv1x1 -> SiLU -> PixelShuffle(2)
     const float* wsrc = raw(pre + ".net.0.weight", (int64_t)4 * dim_out * x.C);
     const float* bsrc = raw(pre + ".net.0.bias", 4 * dim_out);
-    float* w = u->wpool.alloc((size_t)4 * dim_out * x.C);
-    float* b = u->wpool.alloc((size_t)4 * dim_out);
-    KD_THROW_IF(launch_pack_shuffle(wsrc, bsrc, w, b, dim_out, x.C, 0));
+    const int C = x.C;
+    float* b = nullptr;  // weight and bias are permuted together: the bias buffer is cached under its own key
+    float* w = cached("shuffle_w:" + pre, (size_t)4 * dim_out * C, [&](float* dst) {
+      b = cached("shuffle_b:" + pre, (size_t)4 * dim_out, [](float*) {});
+      KD_THROW_IF(launch_pack_shuffle(wsrc, bsrc, dst, b, dim_out, C, 0));
+    });
+    if (!b) b = cached("shuffle_b:" + pre, (size_t)4 * dim_out, [](float*) {});
     ConvOpt o;
     o.act = ACT_SILU;
     o.out_mode = OUT_PIXSHUF;
@@ -740,16 +762,20 @@ struct Builder {
     tmlp_total = total;
     tmlp_prefixes = names;
     if (total == 0) return;
-    tmlp_w = u->wpool.alloc((size_t)total * tcd);
-    tmlp_b = u->wpool.alloc((size_t)total);
-    for (auto& pre : names) {
-      int off = tmlp_off[pre];
-      int64_t ne = numel(pre + suffix);
-      KD_HIP_THROW(hipMemcpyAsync(tmlp_w + (size_t)off * tcd, raw(pre + suffix), (size_t)ne * 4,
-                                  hipMemcpyDeviceToDevice, 0));
-      KD_HIP_THROW(hipMemcpyAsync(tmlp_b + off, raw(pre + ".time_mlp.1.bias", ne / tcd), (size_t)(ne / tcd) * 4,
-                                  hipMemcpyDeviceToDevice, 0));
-    }
+    tmlp_w = cached("time_mlps_w", (size_t)total * tcd, [&](float* dst) {
+      for (auto& pre : names) {
+        int64_t ne = numel(pre + suffix);
+        KD_HIP_THROW(hipMemcpyAsync(dst + (size_t)tmlp_off[pre] * tcd, raw(pre + suffix), (size_t)ne * 4,
+                                    hipMemcpyDeviceToDevice, 0));
+      }
+    });
+    tmlp_b = cached("time_mlps_b", (size_t)total, [&](float* dst) {
+      for (auto& pre : names) {
+        int64_t ne = numel(pre + suffix);
+        KD_HIP_THROW(hipMemcpyAsync(dst + tmlp_off[pre], raw(pre + ".time_mlp.1.bias", ne / tcd),
+                                    (size_t)(ne / tcd) * 4, hipMemcpyDeviceToDevice, 0));
+      }
+    });
   }
 
   // one time-conditioning trio: log_snr[B] -> (t [B,tcd] written/accumulated, tokens into c rows)

@@ -95,6 +95,9 @@ SIGNATURES = {
                                  C.POINTER(C.c_void_p)]),
     "kd_unet_destroy": (None, [C.c_void_p]),
     "kd_unet_hbm_bytes": (C.c_int64, [C.c_void_p]),
+    "kd_unet_create_shared": (C.c_int, [C.POINTER(kd_unet_config_t), C.POINTER(kd_param_t), C.c_int, C.c_void_p,
+                                        C.POINTER(C.c_void_p)]),
+    "kd_unet_weight_bytes": (C.c_int64, [C.c_void_p]),
     "kd_unet_macs": (C.c_int64, [C.c_void_p]),
     "kd_unet_mfma_macs": (C.c_int64, [C.c_void_p]),
     "kd_unet_num_launches": (C.c_int, [C.c_void_p]),

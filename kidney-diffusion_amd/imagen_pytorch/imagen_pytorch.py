@@ -416,7 +416,9 @@ class Unet(nn.Module):
                 arr[i].d_data = sd[n].data_ptr()
                 arr[i].numel = sd[n].numel()
             handle = C.c_void_p()
-            E.check(lib.kd_unet_create(C.byref(cfg), arr, len(names), C.byref(handle)))
+            # further plans of this UNet on the same device (other batch / image size) share its packed weights
+            share = next((h for k, h in self._engines.items() if k[2] == device.index), None)
+            E.check(lib.kd_unet_create_shared(C.byref(cfg), arr, len(names), share, C.byref(handle)))
             del sd
         self._engines[key] = handle
         return handle

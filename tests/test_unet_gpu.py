@@ -88,6 +88,30 @@ def test_unet_forward_with_winograd_levels_matches_oracle(device):
     assert torch.equal(outs[(32, "1")], outs[(32, None)]), "sliced and unsliced Winograd must be bit-identical"
 
 
+def test_plans_of_one_unet_share_their_packed_weights(device):
+    """A UNet sampled at several batch / image sizes keeps ONE copy of its packed weights
+    (kd_unet_create_shared): the second plan must not grow the weight store, and both plans must
+    still match the oracle."""
+    from imagen_pytorch import _engine as E
+
+    lib = E.load()
+    ou = H.oracle_unet("ultra2", lowres_cond=True, seed=17).eval()
+    pu = H.product_unet_like(ou).to(device)
+    dv = lambda v: None if v is None else v.to(device)
+    sizes = {}
+    for B, S in ((2, 32), (3, 32), (1, 64)):
+        x, lr, cond, t, tl = _inputs("ultra2", B, S, True, seed=B)
+        with torch.no_grad():
+            ref = ou(x, t, lowres_cond_img=lr, lowres_noise_times=tl, cond_images=cond)
+        got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
+        assert H.rel_l2(got, ref) < FWD_REL_L2
+        h = pu.engine(B, S, device, with_text=False)
+        sizes[(B, S)] = (lib.kd_unet_weight_bytes(h), lib.kd_unet_hbm_bytes(h))
+    w = [v[0] for v in sizes.values()]
+    assert w[0] == w[1] == w[2] > 0, f"weight store grew with the number of plans: {sizes}"
+    assert len(pu._engines) == 3
+
+
 def test_engine_mac_count_matches_survey_appendix_b(device):
     """unet2 64->256 (train_ultra_res.py:39-48, 3 cond channels) = 229.2 GMAC/sample."""
     import imagen_pytorch as ip
