@@ -197,7 +197,11 @@ def grid_workload(args, world, rank, device, distributed, barrier):
     g = torch.Generator().manual_seed(1234)
     zoomed = torch.rand(1, 3, 1024, 1024, generator=g).to(device)
     cond = G.cond_images_for_grid(zoomed, geom, pos)  # built in HBM: no per-patch host-to-device copy
-    sample_fn = D.imagen_sample_fn(load_imagen, args.grid_resample, device, use_graph=not args.no_graph, seed=1234)
+    # --grid-batch N: same-wave patches of a rank share one sample() call in stages 1 and 2 (stage 3 is
+    # already at 141 TFLOP/s per batch-1 patch and its workspace is 10 GB per sample)
+    gb = {1: args.grid_batch, 2: args.grid_batch, 3: 1}
+    sample_fn = D.imagen_sample_fn(load_imagen, args.grid_resample, device, use_graph=not args.no_graph, seed=1234,
+                                   max_batch=gb)
     ncan = args.canvases
     # finished patches live where the all-gather runs: HBM under RCCL, host memory in a gloo rehearsal
     # (gloo has no CUDA all_gather)
@@ -248,7 +252,7 @@ def grid_workload(args, world, rank, device, distributed, barrier):
         "config": {"workload": f"BASELINE configs[4]: {n}x{n} grid x {ncan} canvas(es), overlap 0.25, stages 64->256->1024 "
                                f"(train_ultra_res.py:27-92), batch 1 per patch as the reference samples them, "
                                f"timesteps ({T},{T},{T}) [reference default (1024,256,256)], inpaint_resample {R}, "
-                               "random-init weights",
+                               f"stage-1/2 patches per sample() call <= {args.grid_batch}, random-init weights",
                    "patches": len(pos) * ncan, "schedule_slots": D.schedule_length(waves, world),
                    "parallelism": f"{world} rank(s): anti-diagonal waves dealt round-robin, one all-gather per wave"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -271,6 +275,8 @@ def main():
     ap.add_argument("--canvases", type=int, default=1)
     ap.add_argument("--grid-steps", type=int, default=8, help="timesteps per stage for --workload grid")
     ap.add_argument("--grid-resample", type=int, default=1, help="inpaint_resample_times for --workload grid")
+    ap.add_argument("--grid-batch", type=int, default=1,
+                    help="--workload grid: patches of a wave per sample() call in stages 1-2 (1 = the reference's way)")
     args = ap.parse_args()
     grid = args.workload == "grid"
     if args.steps is None:

@@ -120,30 +120,45 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
 
 
 def imagen_sample_fn(load_imagen: Callable, inpaint_resample: int, device: torch.device, use_graph: bool = True,
-                     seed: Optional[int] = None):
+                     seed: Optional[int] = None, max_batch=1):
     """sample_fn over the drop-in `imagen_pytorch.Imagen` (HIP engine).  `load_imagen(stage)` returns
     the Imagen holding the real unet of that stage (the reference re-loads one stage at a time,
-    sample_ultra_res.py:79; a cache keeps all three resident here).  Each patch is one
-    `imagen.sample(batch_size=1, ...)` call with exactly the reference's kwargs (:183-195)."""
+    sample_ultra_res.py:79; a cache keeps all three resident here).  With `max_batch` = 1 each patch
+    is one `imagen.sample(batch_size=1, ...)` call with exactly the reference's kwargs (:183-195).
+
+    `max_batch` (int, or {stage: int}) lets the patches of one wave that landed on this rank share a
+    `sample()` call: they are independent (a wave holds no two neighbours), every patch keeps its own
+    conditioning / low-res / inpaint tensors, and a batch-1 pass of the 64-px and 256-px UNets is
+    weight-bandwidth bound, so a batch of 8 costs about as much as two single patches.  The plans of
+    the different batch sizes share one packed-weight store (kd_unet_create_shared)."""
     cache = {}
+
+    def cap(stage):
+        m = max_batch.get(stage, 1) if isinstance(max_batch, dict) else max_batch
+        return max(1, int(m))
+
+    def stack(ts):
+        return None if ts[0] is None else torch.stack([t.to(device) for t in ts])
 
     def fn(stage, tasks, lows, conds, ips, ims):
         if stage not in cache:
             cache[stage] = load_imagen(stage).to(device)
         imagen = cache[stage]
         outs = []
-        for n, (low, cond, ip, im) in enumerate(zip(lows, conds, ips, ims)):
-            kw = dict(batch_size=1, return_pil_images=False,
-                      cond_images=None if cond is None else cond.unsqueeze(0).to(device),
-                      start_image_or_video=None if low is None else low.unsqueeze(0).to(device),
-                      start_at_unet_number=stage, stop_at_unet_number=stage, use_tqdm=False, device=device,
-                      use_graph=use_graph)
+        step = cap(stage)
+        for n0 in range(0, len(tasks), step):
+            sl = slice(n0, n0 + step)
+            b = len(tasks[sl])
+            kw = dict(batch_size=b, return_pil_images=False, cond_images=stack(conds[sl]),
+                      start_image_or_video=stack(lows[sl]), start_at_unet_number=stage, stop_at_unet_number=stage,
+                      use_tqdm=False, device=device, use_graph=use_graph)
             if seed is not None:
-                kw["seed"] = seed + 7919 * stage + 104729 * hash(tasks[n]) % (2 ** 31)
+                kw["seed"] = seed + 7919 * stage + 104729 * hash(tasks[n0]) % (2 ** 31)
             # the reference passes the (possibly all-zero) inpaint tensors for every grid patch (:149-174)
-            kw.update(inpaint_images=ip.unsqueeze(0).to(device), inpaint_masks=im.unsqueeze(0).to(device),
+            kw.update(inpaint_images=stack(ips[sl]), inpaint_masks=stack(ims[sl]),
                       inpaint_resample_times=inpaint_resample)
-            outs.append(imagen.sample(**kw)[0])
+            out = imagen.sample(**kw)
+            outs.extend(out[i] for i in range(b))
         return outs
 
     return fn

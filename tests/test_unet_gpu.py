@@ -284,6 +284,47 @@ def test_patch_grid_on_engine_matches_oracle_driver(device):
     assert torch.equal(got[3][:, :8, 8:], got[1][:, -8:, 8:])
 
 
+def test_patch_grid_with_batched_waves_keeps_the_inpaint_contract(device):
+    """imagen_sample_fn(max_batch=4): the patches of a wave share one sample() call (one plan per batch
+    size, shared weights).  Noise differs from the one-by-one run, so the check is the contract of the
+    grid: every patch's known overlap strip equals its finished neighbour bit for bit, images in [0,1]."""
+    from ultra_res import distributed as D
+    from ultra_res import grid as G
+
+    _, pim = _imagen_pair(device, ["small1", "small2"], (16, 32), (3, 4), ("noise", "v"))
+    n = 3
+    pos = [(i, j) for i in range(n) for j in range(n)]
+    g = torch.Generator().manual_seed(9)
+    cond = torch.rand(n * n, 3, 32, 32, generator=g).to(device)
+    low = torch.rand(n * n, 3, 16, 16, generator=g).to(device)
+    old = dict(G.PATCH_SIZES)
+    G.PATCH_SIZES.update({1: 16, 2: 32})
+    calls = []
+    orig = pim.sample
+
+    def counting_sample(*a, **k):
+        calls.append(k["batch_size"])
+        return orig(*a, **k)
+
+    pim.sample = counting_sample
+    try:
+        fn = D.imagen_sample_fn(lambda stage: pim, 2, device, seed=5, max_batch={2: 4})
+        out = D.sample_grids(fn, stages=(2,), patch_pos=[pos], cond_images=[cond], overlap=0.25,
+                             num_patches_width=[n], orientations=[-1], lowres=[low], device=device)[0]
+    finally:
+        G.PATCH_SIZES.clear()
+        G.PATCH_SIZES.update(old)
+    assert sorted(calls) == [1, 1, 2, 2, 3], calls      # anti-diagonal waves of a 3x3 grid: 1,2,3,2,1 patches
+    idx = {p: k for k, p in enumerate(pos)}
+    for (i, j) in pos:
+        p = out[idx[(i, j)]]
+        assert torch.isfinite(p).all() and p.min() >= 0 and p.max() <= 1
+        if i > 0:   # top strip == bottom strip of the patch above
+            assert torch.equal(p[:, :8, :], out[idx[(i - 1, j)]][:, -8:, :])
+        if j > 0:   # orientation -1: left strip == right strip of the left neighbour
+            assert torch.equal(p[:, 8:, :8], out[idx[(i, j - 1)]][:, 8:, -8:])
+
+
 # ------------------------------------------------------------------------------- text conditioning + guidance (seg-cond path)
 SEG_KW = dict(dim=32, dim_mults=(1, 2, 3, 4), cond_dim=64, text_embed_dim=3, num_resnet_blocks=2,
               layer_attns=(False, True, True, True), layer_cross_attns=(False, True, True, True),
