@@ -31,18 +31,24 @@ __device__ __forceinline__ float act_f(float v, int act) {
 
 // ------------------------------------------------------------------------- attention (D = 64)
 constexpr int AT_D = 64;
-constexpr int AT_KT = 64;  // keys per LDS tile
+constexpr int AT_KT = 64;      // keys per LDS tile
+constexpr int AT_LD = AT_D + 4;  // padded K/V rows: the KS lanes of a query read KS different rows without bank conflicts
 
+// KS = 1: one lane per query.  KS = 4 (small grids, e.g. one batch-1 patch of the ultra-res grid: 8 heads x
+// 1024 queries would fill 32 workgroups): 4 adjacent lanes share a query and take every 4th key each, with
+// their own online-softmax state; the states are merged with shuffles at the end.
+template <int KS>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, int ldq,
                                                         const float* __restrict__ null_k,
                                                         const float* __restrict__ null_v, KVSeg s0, KVSeg s1,
                                                         float* __restrict__ out, int ldo, int Nq, int Hkv,
                                                         float scale) {
-  __shared__ __attribute__((aligned(16))) float Ks[AT_KT * AT_D];
-  __shared__ __attribute__((aligned(16))) float Vs[AT_KT * AT_D];
+  __shared__ __attribute__((aligned(16))) float Ks[AT_KT * AT_LD];
+  __shared__ __attribute__((aligned(16))) float Vs[AT_KT * AT_LD];
   const int h = blockIdx.y, b = blockIdx.z;
   const int hk = Hkv == 1 ? 0 : h;
-  const int qi = blockIdx.x * 256 + threadIdx.x;
+  const int ks = threadIdx.x % KS;  // key split of this lane
+  const int qi = blockIdx.x * (256 / KS) + threadIdx.x / KS;
   const bool active = qi < Nq;
 
   float qr[AT_D], o[AT_D];
@@ -83,15 +89,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         kp = s1.k + r * s1.ld + hk * AT_D;
         vp = s1.v + r * s1.ld + hk * AT_D;
       }
-      *(f32x4*)(Ks + j * AT_D + d4 * 4) = *(const f32x4*)(kp + d4 * 4);
-      *(f32x4*)(Vs + j * AT_D + d4 * 4) = *(const f32x4*)(vp + d4 * 4);
+      *(f32x4*)(Ks + j * AT_LD + d4 * 4) = *(const f32x4*)(kp + d4 * 4);
+      *(f32x4*)(Vs + j * AT_LD + d4 * 4) = *(const f32x4*)(vp + d4 * 4);
     }
     __syncthreads();
-    for (int j = 0; j < nj; ++j) {
+    for (int j = ks; j < nj; j += KS) {
       float s0a = 0.f, s1a = 0.f, s2a = 0.f, s3a = 0.f;
 #pragma unroll
       for (int d4 = 0; d4 < AT_D / 4; ++d4) {
-        f32x4 kk = *(const f32x4*)(Ks + j * AT_D + d4 * 4);  // same address in every lane: broadcast
+        f32x4 kk = *(const f32x4*)(Ks + j * AT_LD + d4 * 4);  // one address per key split: broadcast
         s0a = fmaf(qr[d4 * 4 + 0], kk[0], s0a);
         s1a = fmaf(qr[d4 * 4 + 1], kk[1], s1a);
         s2a = fmaf(qr[d4 * 4 + 2], kk[2], s2a);
@@ -108,14 +114,30 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
       }
 #pragma unroll
       for (int d4 = 0; d4 < AT_D / 4; ++d4) {
-        f32x4 vv = *(const f32x4*)(Vs + j * AT_D + d4 * 4);
+        f32x4 vv = *(const f32x4*)(Vs + j * AT_LD + d4 * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[d4 * 4 + e] = fmaf(pj, vv[e], o[d4 * 4 + e]);
       }
       mrun = mnew;
     }
   }
-  if (active) {
+  if (KS > 1) {  // merge the KS softmax states of a query (adjacent lanes)
+    float m = mrun;
+#pragma unroll
+    for (int off = 1; off < KS; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    const float w = mrun == -INFINITY ? 0.f : expf(mrun - m);  // a split that saw no key contributes nothing
+    lrun *= w;
+#pragma unroll
+    for (int off = 1; off < KS; off <<= 1) lrun += __shfl_xor(lrun, off, 64);
+#pragma unroll
+    for (int d = 0; d < AT_D; ++d) {
+      float v = o[d] * w;
+#pragma unroll
+      for (int off = 1; off < KS; off <<= 1) v += __shfl_xor(v, off, 64);
+      o[d] = v;
+    }
+  }
+  if (active && ks == 0) {
     float inv = 1.0f / lrun;
     float* op = out + ((int64_t)b * Nq + qi) * ldo + h * AT_D;
 #pragma unroll
@@ -132,8 +154,13 @@ int launch_attention(const float* q, int ldq, const float* null_k, const float* 
   KD_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && (s0.n == 0 || s0.ld % 4 == 0) && (s1.n == 0 || s1.ld % 4 == 0),
              "attention: strides % 4");
   KD_REQUIRE((null_k ? 1 : 0) + s0.n + s1.n > 0 && Nq > 0, "attention: empty");
-  hipLaunchKernelGGL(attention_kernel, dim3((Nq + 255) / 256, H, B), dim3(256), 0, s, q, ldq, null_k, null_v, s0,
-                     s1, out, ldo, Nq, Hkv, scale);
+  if ((int64_t)((Nq + 255) / 256) * H * B < 256) {  // would not fill the chip with one lane per query
+    hipLaunchKernelGGL(attention_kernel<4>, dim3((Nq + 63) / 64, H, B), dim3(256), 0, s, q, ldq, null_k, null_v, s0, s1,
+                       out, ldo, Nq, Hkv, scale);
+  } else {
+    hipLaunchKernelGGL(attention_kernel<1>, dim3((Nq + 255) / 256, H, B), dim3(256), 0, s, q, ldq, null_k, null_v, s0,
+                       s1, out, ldo, Nq, Hkv, scale);
+  }
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -112,7 +112,7 @@ int launch_gn_stats(const float* x, int ldx, float* stats, double* partial, int 
 
 // ------------------------------------------------------------------------- GroupNorm apply
 // y = silu( ((x-mean)*rstd*gamma + beta) * (scale+1) + shift ), folded to silu(x*A + Bc) per (b,c).
-constexpr int GA_ROWS_PER_BLOCK = 64;
+constexpr int GA_ROWS_PER_BLOCK = 64;  // upper bound; small maps use fewer rows per workgroup (see launch)
 
 __global__ __launch_bounds__(256) void gn_apply_silu_kernel(const float* __restrict__ x, int ldx,
                                                             const float* __restrict__ stats,
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void gn_apply_silu_kernel(const float* __restr
                                                             const float* __restrict__ beta,
                                                             const float* __restrict__ scale_shift,
                                                             int ld_ss, float* __restrict__ y, int HW, int C,
-                                                            int G) {
+                                                            int G, int rows_per_block) {
   const int b = blockIdx.y;
   const int C4 = C >> 2;
   const int W = C4 < 256 ? C4 : 256;
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void gn_apply_silu_kernel(const float* __restr
   const int rsub = threadIdx.x / W;
   if (rsub >= RP) return;
   const int Cg = C / G;
-  const int p0 = blockIdx.x * GA_ROWS_PER_BLOCK;
-  const int p1 = min(HW, p0 + GA_ROWS_PER_BLOCK);
+  const int p0 = blockIdx.x * rows_per_block;
+  const int p1 = min(HW, p0 + rows_per_block);
   for (int c4 = threadIdx.x - rsub * W; c4 < C4; c4 += W) {
     float A[4], Bc[4];
 #pragma unroll
@@ -163,9 +163,12 @@ int launch_gn_apply_silu(const float* x, int ldx, const float* stats, const floa
                          const float* scale_shift, int ld_ss, float* y, int B, int HW, int C, int G,
                          hipStream_t s) {
   KD_REQUIRE(C % 4 == 0 && ldx % 4 == 0, "GroupNorm apply needs C % 4 == 0");
-  int chunks = (HW + GA_ROWS_PER_BLOCK - 1) / GA_ROWS_PER_BLOCK;
+  // aim at >= 512 workgroups: a batch-1 patch at the 8x8 level would otherwise run on ONE workgroup
+  int rpb = (int)(((int64_t)B * HW + 511) / 512);
+  rpb = rpb < 1 ? 1 : (rpb > GA_ROWS_PER_BLOCK ? GA_ROWS_PER_BLOCK : rpb);
+  int chunks = (HW + rpb - 1) / rpb;
   hipLaunchKernelGGL(gn_apply_silu_kernel, dim3(chunks, B), dim3(256), 0, s, x, ldx, stats, gamma, beta,
-                     scale_shift, ld_ss, y, HW, C, G);
+                     scale_shift, ld_ss, y, HW, C, G, rpb);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -154,8 +154,12 @@ def test_layernorm(lib, device, rows, C, bias):
     assert torch.allclose(y.cpu().double(), ref, rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("B,Nq,Nk,H,Hkv", [(2, 64, 69, 8, 1), (1, 300, 5, 8, 8), (2, 256, 261, 8, 1),
-                                           (1, 1000, 1029, 4, 1)])
+@pytest.mark.parametrize("B,Nq,Nk,H,Hkv", [
+    (2, 64, 69, 8, 1), (1, 300, 5, 8, 8), (2, 256, 261, 8, 1), (1, 1000, 1029, 4, 1),   # small grids: 4 lanes per query
+    (1, 70, 3, 8, 1),                      # fewer keys than key splits (one split sees no key at all)
+    (16, 512, 517, 8, 1),                  # 256 workgroups: one lane per query
+    (33, 256, 261, 8, 8),                  # one lane per query, per-head K/V
+])
 def test_attention(lib, device, B, Nq, Nk, H, Hkv):
     E = _E()
     D = 64
