@@ -269,6 +269,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-kernel-classes", action="store_true",
+                    help="skip the per-launch profile after the timed region (rocprofv3 runs: keeps only the steps in the trace)")
     ap.add_argument("--workload", choices=("sr", "grid"), default="sr",
                     help="sr: the headline metric (default); grid: ultra-res patch grid, patches/s")
     ap.add_argument("--grid-n", type=int, default=8)
@@ -372,7 +374,7 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         dev_ms_per_step = dev_ms / args.steps
         achieved = flop_per_step / (dev_ms_per_step * 1e-3) / 1e12
-        kernels = kernel_classes(lib, handle) if world == 1 else None
+        kernels = kernel_classes(lib, handle) if world == 1 and not args.no_kernel_classes else None
         traffic = None
         tf = ROOT / "profiles" / "hbm_traffic.json"
         if tf.exists():
