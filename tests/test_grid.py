@@ -206,3 +206,39 @@ def test_tissue_mask_and_patch_filter_match_the_reference_recipe(version):
     assert got == want
     if version == "ultra":
         assert 0 < len(got) < 49
+
+
+def test_imagen_sample_fn_batches_a_wave_and_keeps_patch_order():
+    """imagen_sample_fn(max_batch): one sample() call per chunk of a wave, every patch keeps its own
+    conditioning / low-res / inpaint tensors, results come back in task order."""
+
+    class FakeImagen:
+        def __init__(self):
+            self.calls = []
+
+        def to(self, device):
+            return self
+
+        def sample(self, **kw):
+            self.calls.append((kw["batch_size"], kw["start_at_unet_number"], kw["inpaint_resample_times"]))
+            b = kw["batch_size"]
+            assert kw["cond_images"].shape[0] == b and kw["inpaint_images"].shape[0] == b
+            assert kw["inpaint_masks"].shape == (b, 4, 4) and kw["start_image_or_video"].shape[0] == b
+            # encode which patch this is: mean of its cond image + 10 * mean of its low-res image
+            tag = kw["cond_images"].mean(dim=(1, 2, 3)) + 10 * kw["start_image_or_video"].mean(dim=(1, 2, 3))
+            return tag[:, None, None, None].expand(b, 3, 4, 4).clone()
+
+    fake = FakeImagen()
+    fn = D.imagen_sample_fn(lambda stage: fake, inpaint_resample=3, device=torch.device("cpu"), max_batch={2: 4, 3: 1})
+    n = 6
+    tasks = [(0, 0, k) for k in range(n)]
+    conds = [torch.full((3, 4, 4), float(k)) for k in range(n)]
+    lows = [torch.full((3, 2, 2), float(k) / 10) for k in range(n)]
+    ips = [torch.zeros(3, 4, 4) for _ in range(n)]
+    ims = [torch.zeros(4, 4) for _ in range(n)]
+    out = fn(2, tasks, lows, conds, ips, ims)
+    assert [c[0] for c in fake.calls] == [4, 2] and all(c[1:] == (2, 3) for c in fake.calls)
+    assert [round(float(o.mean()), 4) for o in out] == [round(k + 10 * k / 10, 4) for k in range(n)]
+    fake.calls.clear()
+    out3 = fn(3, tasks[:3], lows[:3], conds[:3], ips[:3], ims[:3])
+    assert [c[0] for c in fake.calls] == [1, 1, 1] and len(out3) == 3
