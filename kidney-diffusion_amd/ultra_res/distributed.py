@@ -119,6 +119,22 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
     return prev  # type: ignore[return-value]
 
 
+def outpaint_canvas(sample_fn: Callable, num_patches_width: int, overlap: float = 0.25, canvases: int = 1,
+                    group=None, device: Optional[torch.device] = None) -> List[torch.Tensor]:
+    """The unconditional outpainting driver of the reference (outpainting.py:173-243): an n x n grid of
+    patches through stages 1 -> 2 -> 3, orientation -1, no conditioning images, each patch inpainted
+    from its finished above / left / above-left neighbours, pasted onto a zero canvas of width
+    1024 + (n-1)*int(1024*(1-overlap)).  Returns one (1,3,W,W) canvas per requested canvas."""
+    n = num_patches_width
+    pos = [(i, j) for i in range(n) for j in range(n)]
+    out = sample_grids(sample_fn, (1, 2, 3), [pos] * canvases, [None] * canvases, overlap, [n] * canvases,
+                       orientations=[-1] * canvases, group=group, device=device)
+    P = out[0][0].shape[-1]  # 1024 with the reference's models
+    stride = int(P * (1 - overlap))
+    geom = G.GridGeometry(0, 0, n, stride, P + (n - 1) * stride)
+    return [G.stitch_canvas(o, pos, geom, background=None, patch_size=P) for o in out]
+
+
 def imagen_sample_fn(load_imagen: Callable, inpaint_resample: int, device: torch.device, use_graph: bool = True,
                      seed: Optional[int] = None, max_batch=1):
     """sample_fn over the drop-in `imagen_pytorch.Imagen` (HIP engine).  `load_imagen(stage)` returns

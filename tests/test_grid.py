@@ -242,3 +242,56 @@ def test_imagen_sample_fn_batches_a_wave_and_keeps_patch_order():
     fake.calls.clear()
     out3 = fn(3, tasks[:3], lows[:3], conds[:3], ips[:3], ims[:3])
     assert [c[0] for c in fake.calls] == [1, 1, 1] and len(out3) == 3
+
+
+def test_outpaint_canvas_equals_the_reference_loop_in_row_major_order():
+    """outpainting.py:66-243 restated naively: patches in index order (row-major, which satisfies the
+    above / left / above-left dependencies for orientation -1), inpaint tensors from whatever neighbour
+    exists, no conditioning images, zero canvas.  The wavefront scheduler must give the same canvas."""
+    sizes = {1: 8, 2: 16, 3: 32}
+    old = dict(G.PATCH_SIZES)
+    G.PATCH_SIZES.update(sizes)
+    n, overlap = 3, 0.25
+
+    def stub(stage, task, low, ip, im):   # deterministic "sampler": depends on everything it is given
+        S = sizes[stage]
+        yy = torch.arange(S).float()[:, None] * 0.01 + torch.arange(S).float()[None, :] * 0.003
+        base = (yy + 0.1 * stage + 0.07 * task[1] + 0.013 * task[2])[None].repeat(3, 1, 1)
+        if low is not None:
+            base = base + 0.5 * torch.nn.functional.interpolate(low[None], S, mode="nearest")[0]
+        return torch.where(im.bool()[None], ip, base + 0.2 * ip.mean())
+
+    def sample_fn(stage, tasks, lows, conds, ips, ims):
+        assert all(c is None for c in conds)
+        return [stub(stage, t, lo, ip, im) for t, lo, ip, im in zip(tasks, lows, ips, ims)]
+
+    try:
+        got = D.outpaint_canvas(sample_fn, n, overlap)[0]
+        # the reference's loop
+        pos = [(i, j) for i in range(n) for j in range(n)]
+        prev = None
+        for stage in (1, 2, 3):
+            S, done = sizes[stage], {}
+            ov = int(overlap * S)
+            for idx, (i, j) in enumerate(pos):
+                ip, im = torch.zeros(3, S, S), torch.zeros(S, S)
+                a, l, al = done.get((i - 1, j)), done.get((i, j - 1)), done.get((i - 1, j - 1))
+                if a is not None:
+                    ip[:, :ov, :] = a[:, -ov:, :]
+                    im[:ov, :] = 1
+                if l is not None:
+                    ip[:, :, :ov] = l[:, :, -ov:]
+                    im[:, :ov] = 1
+                if al is not None:
+                    ip[:, :ov, :ov] = al[:, -ov:, -ov:]
+                done[(i, j)] = stub(stage, (0, i, j), None if prev is None else prev[idx], ip, im)
+            prev = [done[p] for p in pos]
+        P = sizes[3]
+        dist = int(P * (1 - overlap))
+        want = torch.zeros(1, 3, P + (n - 1) * dist, P + (n - 1) * dist)
+        for idx, (i, j) in enumerate(pos):
+            want[0, :, i * dist:i * dist + P, j * dist:j * dist + P] = prev[idx]
+    finally:
+        G.PATCH_SIZES.clear()
+        G.PATCH_SIZES.update(old)
+    assert got.shape == want.shape and torch.equal(got, want)
