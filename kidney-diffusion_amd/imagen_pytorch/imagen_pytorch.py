@@ -688,7 +688,8 @@ class Imagen(nn.Module):
         if not return_pil_images:
             return out
         from PIL import Image  # noqa: local import, PIL only needed for this branch
-        to_pil = lambda t: [Image.fromarray((i.clamp(0, 1).permute(1, 2, 0).cpu().numpy() * 255).round().astype("uint8"))
+        # the library maps T.ToPILImage() over the images: float -> mul(255).byte(), i.e. truncation
+        to_pil = lambda t: [Image.fromarray(i.clamp(0, 1).mul(255).to(torch.uint8).permute(1, 2, 0).cpu().numpy())
                             for i in t]
         return [to_pil(o) for o in out] if return_all_unet_outputs else to_pil(out)
 

@@ -88,6 +88,19 @@ def test_unet_forward_with_winograd_levels_matches_oracle(device):
     assert torch.equal(outs[(32, "1")], outs[(32, None)]), "sliced and unsliced Winograd must be bit-identical"
 
 
+def test_return_pil_images_truncates_like_the_library(device):
+    """sample(return_pil_images=True) (sample_cond.py:42, sample.py:53): the library maps torchvision's
+    ToPILImage over the float images, i.e. mul(255).byte() - truncation, not rounding."""
+    import numpy as np
+
+    _, pim = _imagen_pair(device, ["small1"], (16,), (3,), ("noise",))
+    ten = pim.sample(batch_size=2, seed=3, device=device)
+    pil = pim.sample(batch_size=2, seed=3, device=device, return_pil_images=True)
+    assert len(pil) == 2 and pil[0].size == (16, 16) and pil[0].mode == "RGB"
+    want = ten.clamp(0, 1).mul(255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+    assert np.array_equal(np.stack([np.asarray(p) for p in pil]), want)
+
+
 def test_plans_of_one_unet_share_their_packed_weights(device):
     """A UNet sampled at several batch / image sizes keeps ONE copy of its packed weights
     (kd_unet_create_shared): the second plan must not grow the weight store, and both plans must
