@@ -1,5 +1,8 @@
 // Experimental variants of the implicit-GEMM conv kernel + a micro-benchmark entry point
 // (kd_conv_bench).  Winners are promoted into kernels_conv.hip; nothing in the plan calls this file.
+#include <stdlib.h>
+#include <type_traits>
+
 #include "common.h"
 
 namespace kd {
@@ -1066,6 +1069,270 @@ static void launch_ring(const ConvParams& p, hipStream_t s) {
   hipLaunchKernelGGL((conv_ring_kernel<MINW>), grid, dim3(256), 0, s, p);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fully fused Winograd F(2x2,3x3) for the Cin = 128-type layers (DESIGN.md "Next" #1), experiment.
+//   y = conv3x3(SiLU(x)) + bias, x NHWC [B][H][W][C], weights pre-transformed by fw_pack_kernel.
+// One workgroup (4 waves, ONE per SIMD: 256 accumulator registers per lane) owns an 8x8 patch of
+// output tiles (16x16 pixels) x 64 output channels; wave (wm, wn) owns 32 tiles x 32 channels for ALL
+// 16 Winograd positions, so the output transform happens in its registers.  K runs over the input
+// channels in chunks of 4: raw 18x18x4 patch and the 16x64x4 weight chunk arrive by buffer DMA
+// (double-buffered), every thread transforms one (tile, channel) of the patch into V (B^T d B with
+// the activation applied on the way), then 32 MFMAs per wave.
+constexpr int FW_K = 4;
+constexpr int FW_RAW = 2048;  // 2 DMA passes x 256 pixel slots x 4 floats (324 used)
+constexpr int FW_UV = 16 * 64 * FW_K;
+
+__global__ void fw_pack_kernel(const float* __restrict__ w /*[9][N][C]*/, float* __restrict__ U, int N, int C) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * C) return;
+  int n = (int)(idx / C), c = (int)(idx % C);
+  float g[3][3], t[4][3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) g[kh][kw] = w[((int64_t)(kh * 3 + kw) * N + n) * C + c];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    t[0][k] = g[0][k];
+    t[1][k] = 0.5f * (g[0][k] + g[1][k] + g[2][k]);
+    t[2][k] = 0.5f * (g[0][k] - g[1][k] + g[2][k]);
+    t[3][k] = g[2][k];
+  }
+  const int nchunks = C / FW_K;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float u[4] = {t[r][0], 0.5f * (t[r][0] + t[r][1] + t[r][2]), 0.5f * (t[r][0] - t[r][1] + t[r][2]), t[r][2]};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      int p = r * 4 + s;
+      int64_t dst = ((((int64_t)(n / 64) * nchunks + c / FW_K) * 16 + p) * 64 + (n % 64)) * FW_K + (c % FW_K);
+      U[dst] = u[s];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void conv_fwino_kernel(const float* __restrict__ x, const float* __restrict__ U,
+                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                            int B, int H, int W, int C, int N, int flags) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // one __shared__ object per stage: distinct objects are what lets hipcc see that the DMA into stage k+1
+  // does not alias the ds_reads of stage k (otherwise it waits vmcnt(0) before every LDS read)
+  __shared__ __attribute__((aligned(1024))) float raw_0[FW_RAW], raw_1[FW_RAW], raw_2[FW_RAW];
+  __shared__ __attribute__((aligned(1024))) float us_0[FW_UV], us_1[FW_UV], us_2[FW_UV];
+  __shared__ __attribute__((aligned(1024))) float vs_0[FW_UV], vs_1[FW_UV], vs_2[FW_UV];
+  auto rawp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return raw_0; else if constexpr (decltype(S)::value == 1) return raw_1; else return raw_2; };
+  auto usp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return us_0; else if constexpr (decltype(S)::value == 1) return us_1; else return us_2; };
+  auto vsp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return vs_0; else if constexpr (decltype(S)::value == 1) return vs_1; else return vs_2; };
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int pw = W / 16, ph = H / 16;
+  const int bpatch = blockIdx.x;
+  const int b = bpatch / (pw * ph);
+  const int prem = bpatch - b * pw * ph;
+  const int y0 = (prem / pw) * 16, x0 = (prem % pw) * 16;
+  const int nhalf = blockIdx.y, n0 = nhalf * 64;
+  const int nchunks = C / FW_K;
+
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((int64_t)B * H * W * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU =
+      __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, (int)((int64_t)16 * N * C * 4), 0x00020000);
+
+  // raw patch loader: patch pixel q (18x18, origin at output origin - 1), 16 B = 4 channels
+  uint32_t voffX[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int id = q * 256 + tid;
+    int py = id / 18, px = id - py * 18;
+    int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    bool ok = id < 324 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    voffX[q] = ok ? (uint32_t)((((b * H + iy) * W + ix) * C) * 4) : OOB_OFF;
+  }
+  // this thread's (tile, channel) of the input transform and the validity of its 16 pixels
+  const int tt = tid >> 2, tc = tid & 3;
+  const int tty = tt >> 3, ttx = tt & 7;
+  uint32_t vmask = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      int iy = y0 - 1 + 2 * tty + r, ix = x0 - 1 + 2 * ttx + s;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) vmask |= 1u << (r * 4 + s);
+    }
+
+  // Static LDS stage indices everywhere (S is a compile-time constant): with run-time stage indices hipcc
+  // cannot tell the DMA's LDS writes from the ds_reads and puts s_waitcnt vmcnt(0) after every barrier,
+  // which serialises the whole prefetch.  Chunks past the end use out-of-range offsets (zeros: SiLU(0) = 0).
+  auto issue_raw = [&](int chunk, auto S) {
+    __attribute__((address_space(3))) float* rb =
+        (__attribute__((address_space(3))) float*)(rawp(S) + wave * 256);
+    const uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t)(chunk * FW_K * 4));
+    const bool live = chunk < nchunks;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, rb, 16, live ? voffX[0] : OOB_OFF, sx, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, rb + 1024, 16, live ? voffX[1] : OOB_OFF, sx, 0, 0);
+  };
+  auto issue_u = [&](int chunk, auto S) {
+    __attribute__((address_space(3))) float* ub =
+        (__attribute__((address_space(3))) float*)(usp(S) + wave * 256);
+    const uint32_t su = __builtin_amdgcn_readfirstlane((uint32_t)(((nhalf * nchunks + chunk) * FW_UV) * 4));
+    const bool live = chunk < nchunks;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, ub + q * 1024, 16, live ? (uint32_t)((q * 256 + tid) * 16) : OOB_OFF,
+                                               su, 0, 0);
+  };
+  // input transform of (tile tt, channel tc): V = B^T d B with d = SiLU(x), 0 outside the image
+  auto transform = [&](auto S) {
+    const float* rp = rawp(S) + ((2 * tty) * 18 + 2 * ttx) * 4 + tc;
+    float d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float v = rp[(r * 18 + s) * 4];
+        if (flags & 1) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));  // SiLU with the hardware reciprocal (1 ulp)
+        d[r][s] = (vmask >> (r * 4 + s)) & 1 ? v : 0.f;
+      }
+    float u[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u[0][s] = d[0][s] - d[2][s];
+      u[1][s] = d[1][s] + d[2][s];
+      u[2][s] = d[2][s] - d[1][s];
+      u[3][s] = d[1][s] - d[3][s];
+    }
+    float* vp = vsp(S) + tt * FW_K + tc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      vp[(r * 4 + 0) * 64 * FW_K] = u[r][0] - u[r][2];
+      vp[(r * 4 + 1) * 64 * FW_K] = u[r][1] + u[r][2];
+      vp[(r * 4 + 2) * 64 * FW_K] = u[r][2] - u[r][1];
+      vp[(r * 4 + 3) * 64 * FW_K] = u[r][1] - u[r][3];
+    }
+  };
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+  const int frow = lane & 31, khalf = lane >> 5;
+  // One wave per SIMD: nothing else fills the shadow of the 64-cycle MFMAs, and hipcc clusters them (its
+  // sched_group_barrier interleave spilled 1700 registers).  So the MFMAs are inline asm with the
+  // accumulators pinned to AGPRs ("+a"), and the input transform of the NEXT chunk is written between them
+  // in source order: ~5 VALU / transcendental / LDS instructions per gap.
+  auto mfma_a = [&](f32x16& c, float a, float b) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  };
+  auto fused = [&](auto S, auto Sn) {
+    const float* va = vsp(S) + (wm * 32 + frow) * FW_K + khalf * 2;
+    const float* ub = usp(S) + (wn * 32 + frow) * FW_K + khalf * 2;
+    float2 a2[16], b2[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      a2[p] = *(const float2*)(va + p * 64 * FW_K);
+      b2[p] = *(const float2*)(ub + p * 64 * FW_K);
+    }
+    const float* rp = rawp(Sn) + ((2 * tty) * 18 + 2 * ttx) * 4 + tc;
+    float* vp = vsp(Sn) + tt * FW_K + tc;
+    float d[4][4], u[4][4];
+    // the 16 raw values of the next chunk are requested up front as well: a ds_read inside an MFMA gap
+    // would stall the (in-order) wave for the LDS latency and delay the next MFMA
+#pragma unroll
+    for (int g = 0; g < 16; ++g) d[g >> 2][g & 3] = rp[((g >> 2) * 18 + (g & 3)) * 4];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {  // k-step 0 of position g  |  activation of input (g>>2, g&3)
+      mfma_a(acc[g], a2[g].x, b2[g].x);
+      const int r = g >> 2, q = g & 3;
+      float v = d[r][q];
+      if (flags & 1) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));  // bit0: SiLU fused (else input is pre-activated)
+      d[r][q] = (vmask >> g) & 1 ? v : 0.f;
+      __builtin_amdgcn_sched_barrier(0);  // keep this piece in this MFMA's shadow (hipcc re-clusters otherwise)
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {  // k-step 1 of position g  |  B^T d B and the V writes
+      mfma_a(acc[g], a2[g].y, b2[g].y);
+      if (g < 4) {
+        const int q = g;
+        u[0][q] = d[0][q] - d[2][q];
+        u[1][q] = d[1][q] + d[2][q];
+        u[2][q] = d[2][q] - d[1][q];
+        u[3][q] = d[1][q] - d[3][q];
+      } else if (g < 8) {
+        const int r = g - 4;
+        vp[(r * 4 + 0) * 64 * FW_K] = u[r][0] - u[r][2];
+        vp[(r * 4 + 1) * 64 * FW_K] = u[r][1] + u[r][2];
+        vp[(r * 4 + 2) * 64 * FW_K] = u[r][2] - u[r][1];
+        vp[(r * 4 + 3) * 64 * FW_K] = u[r][1] - u[r][3];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // Pipeline, 3 stages of raw / U / V, ONE barrier per chunk.  Iteration c: wait for raw(c+1) and U(c)
+  // (issued two iterations ago), barrier, issue raw(c+3) and U(c+2) into the stages everybody has just
+  // finished with, MFMAs of chunk c, transform of chunk c+1.
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  auto body = [&](int c, auto S, auto Sn, auto Snn) {
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_raw(c + 3, S);
+    issue_u(c + 2, Snn);
+    fused(S, Sn);
+  };
+  issue_raw(0, S0{});
+  issue_u(0, S0{});
+  issue_raw(1, S1{});
+  issue_u(1, S1{});
+  issue_raw(2, S2{});
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  transform(S0{});
+  for (int c = 0; c < nchunks; c += 3) {
+    body(c, S0{}, S1{}, S2{});
+    body(c + 1, S1{}, S2{}, S0{});
+    body(c + 2, S2{}, S0{}, S1{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");  // last MFMAs (inline asm) retired
+
+  // output transform in registers: lane owns channel n, tiles (r&3) + 8*(r>>2) + 4*(lane>>5) of its M-tile
+  const int n = n0 + wn * 32 + (lane & 31);
+  const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int t = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int ty = t >> 3, tx = t & 7;
+    float m[4][4];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = acc[p][r];
+    float q[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      q[0][s] = m[0][s] + m[1][s] + m[2][s];
+      q[1][s] = m[1][s] - m[2][s] - m[3][s];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t pix = ((int64_t)b * H + y0 + 2 * ty + i) * W + x0 + 2 * tx;
+      y[pix * N + n] = q[i][0] + q[i][1] + q[i][2] + bv;
+      y[(pix + 1) * N + n] = q[i][1] - q[i][2] - q[i][3] + bv;
+    }
+  }
+#endif
+}
+
+__global__ void silu_kernel(const float* __restrict__ a, float* __restrict__ o, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = a[i];
+    o[i] = v / (1.0f + __expf(-v));
+  }
+}
+
 __global__ void fill_rand_kernel(float* p, int64_t n, uint32_t seed) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t x = (uint32_t)i * 747796405u + seed;
@@ -1105,6 +1372,13 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
   hipLaunchKernelGGL(fill_rand_kernel, dim3(2048), dim3(256), 0, 0, w, nw, 2u);
   hipLaunchKernelGGL(fill_rand_kernel, dim3(8), dim3(256), 0, 0, bias, (int64_t)Cout, 3u);
   p.x = x; p.w = w; p.y = y; p.bias = bias;
+  float *fwU = nullptr, *xs = nullptr;
+  if (variant == 50 || variant == 51 || variant == 52) {
+    KD_HIP_CHECK(hipMalloc((void**)&fwU, (size_t)16 * Cout * Cin * 4));
+    KD_HIP_CHECK(hipMalloc((void**)&xs, nx * 4));
+    hipLaunchKernelGGL(fw_pack_kernel, dim3((unsigned)(((int64_t)Cout * Cin + 255) / 256)), dim3(256), 0, 0, w, fwU, Cout, Cin);
+    hipLaunchKernelGGL(silu_kernel, dim3(4096), dim3(256), 0, 0, x, xs, nx);
+  }
   auto run = [&]() {
     switch (variant) {
       case 0: launch_conv_igemm(p, 0); break;                         // production kernel
@@ -1141,6 +1415,15 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
       case 24: { ConvParams q = p; q.act = 4; launch_buf<128, 128, 2, 2, 2>(q, 0); } break;  // stagger 4k
       case 40: launch_ring<3>(p, 0); break;   // BK=16 3-stage ring, 1 barrier/chunk, 3 workgroups per CU
       case 41: launch_ring<2>(p, 0); break;   // same, 2 workgroups per CU
+      case 50:   // fused Winograd F(2x2,3x3): y = conv3x3(SiLU(x)) + bias (needs K == 3, H, W % 16 == 0, C % 4 == 0, Cout % 64 == 0)
+        hipLaunchKernelGGL(conv_fwino_kernel, dim3(B * (H / 16) * (W / 16), Cout / 64), dim3(256), 0, 0, x, fwU, bias, y, B,
+                           H, W, Cin, Cout, 1);
+        break;
+      case 52:   // fused Winograd on a pre-activated input (the GroupNorm apply pass stays separate)
+        hipLaunchKernelGGL(conv_fwino_kernel, dim3(B * (H / 16) * (W / 16), Cout / 64), dim3(256), 0, 0, xs, fwU, bias, y, B,
+                           H, W, Cin, Cout, 0);
+        break;
+      case 51: { ConvParams q = p; q.x = xs; launch_conv_igemm(q, 0); } break;   // reference for 50: production conv on SiLU(x)
       default: break;
     }
   };
