@@ -60,9 +60,12 @@ typedef struct kd_unet_config {
   /* static shape of the plan */
   int batch;
   int image_size;             /* S: x is [batch, channels, S, S] */
-  /* 0 = auto: Winograd F(2x2,3x3) for the ResnetBlock 3x3 convs with Cin >= 256, direct implicit
-   * GEMM elsewhere; 1 = direct implicit GEMM everywhere (bitwise the k-ordered fmaf chain);
-   * n >= 32 = Winograd from Cin >= n (experiments / tests) */
+  /* 0 = auto: for the ResnetBlock 3x3 convs Winograd F(2x2,3x3) as 16 batched GEMMs from Cin >= 256,
+   * the fused Winograd kernel below that where the map is a multiple of 16x16, Cout of 64 and the
+   * launch fills the chip, direct implicit GEMM elsewhere; 1 = direct implicit GEMM everywhere
+   * (bitwise the k-ordered fmaf chain); 2 = as 0 without the fused kernel; 3 = as 0 with the fused
+   * kernel wherever its shape rules allow (tests); n >= 32 = batched-GEMM Winograd from Cin >= n
+   * (experiments / tests) */
   int conv_algo;
 } kd_unet_config_t;
 
@@ -206,6 +209,12 @@ int kd_conv2d_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias,
  * only.  Needs even H, W; B*H*W/4 % 256 == 0; Cin % 32 == 0; Cout > 32. */
 int kd_conv3x3_winograd_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias, float* d_y,
                              int B, int H, int W, int Cin, int Cout, void* stream);
+/* The same convolution (+ optional residual d_res, NHWC with Cout channels, may be NULL) through the
+ * fused Winograd kernel the plan uses for wide maps with few channels (kernels_wino_fused.hip).
+ * Needs H % 16 == 0, W % 16 == 0, Cin % 4 == 0, Cout % 64 == 0; returns non-zero otherwise. */
+int kd_conv3x3_winograd_fused_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias,
+                                   const float* d_res, float* d_y, int B, int H, int W, int Cin,
+                                   int Cout, void* stream);
 /* GroupNorm(G) + optional FiLM (scale+1, shift: [B,2C] = [scale | shift]) + SiLU, NHWC. */
 int kd_groupnorm_silu_nhwc(const float* d_x, const float* d_gamma, const float* d_beta,
                            const float* d_scale_shift, float* d_y, int B, int HW, int C, int G,

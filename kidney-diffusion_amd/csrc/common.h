@@ -91,6 +91,14 @@ int launch_wino_in(const float* x, int ldx, const float* stats, const float* gam
 int launch_wino_out(const float* D, const float* bias, const float* res, int ldres, float* y, int B, int H, int W,
                     int C, int64_t t0, int64_t nt, hipStream_t s);
 
+// ---- fused Winograd F(2x2,3x3) conv for wide maps with few channels (kernels_wino_fused.hip)
+// y = conv3x3(x) + bias (+ res): x dense NHWC [B][H][W][C] (already activated), y dense [B][H][W][N],
+// U from launch_wino_fused_pack (16*N*C floats).  wino_fused_ok states the shapes it takes.
+bool wino_fused_ok(int B, int H, int W, int C, int N);
+int launch_wino_fused_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s);
+int launch_wino_fused(const float* x, const float* U, const float* bias, const float* res, int ldres, float* y, int B,
+                      int H, int W, int C, int N, hipStream_t s);
+
 // ---- norms / elementwise (kernels_norm.hip)
 int launch_gn_stats(const float* x, int ldx, float* stats /*[B][G][2] mean,rstd*/, double* partial,
                     int B, int HW, int C, int G, float eps, hipStream_t s);

@@ -556,6 +556,11 @@ struct Builder {
   bool wino_ok(const T& x, int cout) const {
     if (cfg.conv_algo == 1) return false;
     const int min_cin = cfg.conv_algo >= 32 ? cfg.conv_algo : 256;
+    // the fused kernel (fwino_ok) takes the layers up to Cin = 512 whose maps it can tile: measured on the
+    // 64->256 UNet, ms/step with the hand-over at Cin <= 0 / 256 / 512 / 1024 / all: 48.1 / 44.8 / 44.5 / 45.1 /
+    // 45.3 (KD_FWINO_MAX_CIN moves it for experiments, read per plan)
+    const int fw_max = getenv("KD_FWINO_MAX_CIN") ? atoi(getenv("KD_FWINO_MAX_CIN")) : 512;
+    if (cfg.conv_algo < 32 && x.C <= fw_max && fwino_ok(x, cout)) return false;
     if ((x.H & 1) || (x.W & 1) || x.C < min_cin || x.C % 32 || cout <= 32 || cout % 4) return false;
     const int64_t Mt = (int64_t)x.B * (x.H / 2) * (x.W / 2);
     return Mt % 256 == 0 && 16 * Mt < 0x7fffffff && (int64_t)16 * cout * x.C * 4 < 0x7fffffff;
@@ -630,6 +635,37 @@ struct Builder {
     return y;
   }
 
+  // ---- fused Winograd F(2x2,3x3) (kernels_wino_fused.hip) for the 3x3 convs the path above leaves to the
+  // direct kernel: wide maps with few channels, input already activated by gn_apply.  cfg.conv_algo 0:
+  // wherever the shape fits and the launch fills the chip; 1 and 2: never (2 = the non-fused path only);
+  // 3: wherever the shape fits (tests).
+  bool fwino_ok(const T& x, int cout) const {
+    if (cfg.conv_algo == 1 || cfg.conv_algo == 2) return false;
+    if (x.C < 32 || !wino_fused_ok(x.B, x.H, x.W, x.C, cout)) return false;
+    if (cfg.conv_algo == 3) return true;
+    return (int64_t)x.B * (x.H / 16) * (x.W / 16) * (cout / 64) >= 256;  // one workgroup per CU and round
+  }
+  T fwino_conv(const T& x, const std::string& conv_prefix, int Cout, const T* res) {
+    const int Cin = x.C, Bx = x.B, H = x.H, W = x.W;
+    const float* bias = P(conv_prefix + ".bias", Cout);
+    const float* wsrc = raw(conv_prefix + ".weight", (int64_t)Cout * Cin * 9);
+    float* U = cached("winof:" + conv_prefix, (size_t)16 * Cout * Cin,
+                      [&](float* dst) { KD_THROW_IF(launch_wino_fused_pack(wsrc, dst, Cout, Cin, 0)); });
+    T y = alloc(Bx, H, W, Cout);
+    size_t xo = x.off, yo = y.off, ro = res ? res->off : 0;
+    const bool hr = res != nullptr;
+    const int ldres = res ? res->C : 0;
+    kd_unet* uu = u;
+    const int64_t m = (int64_t)Bx * H * W * Cout * Cin * 9;
+    emit([=](hipStream_t s) {
+      return launch_wino_fused(uu->P(xo), U, bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W, Cin, Cout, s);
+    }, "wino fused M" + std::to_string((int64_t)Bx * H * W) + " Cin" + std::to_string(Cin) + " Cout" +
+           std::to_string(Cout), m);
+    if (!to_text) u->macs += m;
+    if (!to_text && !to_static) u->mfma_macs += (int64_t)Bx * H * W * 4 * Cout * ((Cin / 4 + 2) / 3 * 12);
+    return y;
+  }
+
   // ResnetBlock.  Does NOT free x.
   T resnet(const T& x, const std::string& pre, int dim_out, const T* ctx, bool use_gca) {
     bool has_cross = has(pre + ".cross_attn.to_q.weight");
@@ -640,8 +676,11 @@ struct Builder {
       h = wino_block(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
     } else {
       T y1 = gn_silu(x, pre + ".block1.groupnorm", nullptr, 0);
-      h = conv(y1, pack_conv(pre + ".block1.project.weight", dim_out, dim_in, dim_in, 3),
-               P(pre + ".block1.project.bias", dim_out), dim_out, 3, 1, 1, ConvOpt());
+      if (fwino_ok(y1, dim_out))
+        h = fwino_conv(y1, pre + ".block1.project", dim_out, nullptr);
+      else
+        h = conv(y1, pack_conv(pre + ".block1.project.weight", dim_out, dim_in, dim_in, 3),
+                 P(pre + ".block1.project.bias", dim_out), dim_out, 3, 1, 1, ConvOpt());
       free(y1);
     }
     if (has_cross) {
@@ -675,8 +714,11 @@ struct Builder {
       ConvOpt o2;
       if (!use_gca && !has_res_conv) o2.res = &x;  // h2 + x folded into the conv epilogue
       free(h);
-      h2 = conv(y2, pack_conv(pre + ".block2.project.weight", dim_out, dim_out, dim_out, 3),
-                P(pre + ".block2.project.bias", dim_out), dim_out, 3, 1, 1, o2);
+      if (fwino_ok(y2, dim_out))
+        h2 = fwino_conv(y2, pre + ".block2.project", dim_out, o2.res);
+      else
+        h2 = conv(y2, pack_conv(pre + ".block2.project.weight", dim_out, dim_out, dim_out, 3),
+                  P(pre + ".block2.project.bias", dim_out), dim_out, 3, 1, 1, o2);
       free(y2);
     }
     if (!use_gca && !has_res_conv) return h2;

@@ -1111,9 +1111,11 @@ __global__ void fw_pack_kernel(const float* __restrict__ w /*[9][N][C]*/, float*
   }
 }
 
+template <int DBG>
 __global__ __launch_bounds__(256, 1) void conv_fwino_kernel(const float* __restrict__ x, const float* __restrict__ U,
                                                             const float* __restrict__ bias, float* __restrict__ y,
-                                                            int B, int H, int W, int C, int N, int flags) {
+                                                            int B, int H, int W, int C, int N, int flags,
+                                                            unsigned long long* __restrict__ dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // one __shared__ object per stage: distinct objects are what lets hipcc see that the DMA into stage k+1
   // does not alias the ds_reads of stage k (otherwise it waits vmcnt(0) before every LDS read)
@@ -1227,7 +1229,16 @@ __global__ __launch_bounds__(256, 1) void conv_fwino_kernel(const float* __restr
   auto mfma_a = [&](f32x16& c, float a, float b) {
     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
   };
-  auto fused = [&](auto S, auto Sn) {
+  // DBG: s_memtime stamps of the last three chunks of two workgroups (kept in SGPRs: a store would count in vmcnt)
+  unsigned long long ts[3][6];
+  auto stamp = [&](auto I, auto Kk) {
+    if constexpr (DBG) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      ts[decltype(I)::value][decltype(Kk)::value] = t;
+    }
+  };
+  auto fused = [&](auto S, auto Sn, auto I) {
     const float* va = vsp(S) + (wm * 32 + frow) * FW_K + khalf * 2;
     const float* ub = usp(S) + (wn * 32 + frow) * FW_K + khalf * 2;
     float2 a2[16], b2[16];
@@ -1252,6 +1263,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwino_kernel(const float* __restr
       d[r][q] = (vmask >> g) & 1 ? v : 0.f;
       __builtin_amdgcn_sched_barrier(0);  // keep this piece in this MFMA's shadow (hipcc re-clusters otherwise)
     }
+    stamp(I, std::integral_constant<int, 4>{});
 #pragma unroll
     for (int g = 0; g < 16; ++g) {  // k-step 1 of position g  |  B^T d B and the V writes
       mfma_a(acc[g], a2[g].y, b2[g].y);
@@ -1279,11 +1291,16 @@ __global__ __launch_bounds__(256, 1) void conv_fwino_kernel(const float* __restr
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
   auto body = [&](int c, auto S, auto Sn, auto Snn) {
+    stamp(S, std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    stamp(S, std::integral_constant<int, 1>{});
     __builtin_amdgcn_s_barrier();
+    stamp(S, std::integral_constant<int, 2>{});
     issue_raw(c + 3, S);
     issue_u(c + 2, Snn);
-    fused(S, Sn);
+    stamp(S, std::integral_constant<int, 3>{});
+    fused(S, Sn, S);
+    stamp(S, std::integral_constant<int, 5>{});
   };
   issue_raw(0, S0{});
   issue_u(0, S0{});
@@ -1299,6 +1316,15 @@ __global__ __launch_bounds__(256, 1) void conv_fwino_kernel(const float* __restr
     body(c + 2, S2{}, S0{}, S1{});
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");  // last MFMAs (inline asm) retired
+  if constexpr (DBG) {
+    if (dbg && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0 && lane == 0) {
+      unsigned long long* o = dbg + ((blockIdx.x ? 1 : 0) * 4 + wave) * 18;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[i * 6 + k] = ts[i][k];
+    }
+  }
 
   // output transform in registers: lane owns channel n, tiles (r&3) + 8*(r>>2) + 4*(lane>>5) of its M-tile
   const int n = n0 + wn * 32 + (lane & 31);
@@ -1321,6 +1347,230 @@ __global__ __launch_bounds__(256, 1) void conv_fwino_kernel(const float* __restr
       const int64_t pix = ((int64_t)b * H + y0 + 2 * ty + i) * W + x0 + 2 * tx;
       y[pix * N + n] = q[i][0] + q[i][1] + q[i][2] + bv;
       y[(pix + 1) * N + n] = q[i][1] - q[i][2] - q[i][3] + bv;
+    }
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Second form of the fused Winograd kernel, after the stamps and scratch/mfma_fill.hip showed that the
+// fp32 MFMA shares the SIMD's VALU issue (a VALU instruction in the shadow of v_mfma_f32_32x32x2_f32
+// costs its full 4-8 cycles; only LDS instructions hide) and that one wave per SIMD leaves every LDS
+// latency exposed.  So: TWO waves per SIMD (8 waves, 128 accumulator registers each), the 16 Winograd
+// positions split between the two waves of a (32 tiles x 32 channels) tile - positions 0-7 (rows 0,1 of
+// the transformed tile) and 8-15 (rows 2,3) - and the input is PRE-ACTIVATED (the GroupNorm apply pass
+// stays a separate HBM-bound kernel): zero padding = out-of-range DMA, and the transform is 20 VALU
+// instructions per thread and chunk.  The output transform is linear, so each wave forms partial 2x2
+// outputs from its two rows and the pair exchanges halves through LDS.
+//   y = conv3x3(x) + bias, x NHWC, 3x3 / stride 1 / pad 1, H, W % 16 == 0, C % 4 == 0, N % 64 == 0.
+constexpr int F2_RAW = 2048;  // 512 pixel slots x 4 floats (324 used)
+
+template <int DBG>
+__global__ __launch_bounds__(512, 1) void conv_fwino2_kernel(const float* __restrict__ x, const float* __restrict__ U,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             int B, int H, int W, int C, int N,
+                                                             unsigned long long* __restrict__ dbg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned long long tsk[4] = {0, 0, 0, 0};
+  auto stampk = [&](auto Kk) {
+    if constexpr (DBG) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      tsk[decltype(Kk)::value] = t;
+    }
+  };
+  stampk(std::integral_constant<int, 0>{});
+  __shared__ __attribute__((aligned(1024))) float raw_0[F2_RAW], raw_1[F2_RAW], raw_2[F2_RAW];
+  __shared__ __attribute__((aligned(1024))) float us_0[FW_UV], us_1[FW_UV], us_2[FW_UV];
+  __shared__ __attribute__((aligned(1024))) float vs_0[FW_UV], vs_1[FW_UV], vs_2[FW_UV];
+  auto rawp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return raw_0; else if constexpr (decltype(S)::value == 1) return raw_1; else return raw_2; };
+  auto usp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return us_0; else if constexpr (decltype(S)::value == 1) return us_1; else return us_2; };
+  auto vsp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return vs_0; else if constexpr (decltype(S)::value == 1) return vs_1; else return vs_2; };
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int pw = W / 16, ph_ = H / 16;
+  const int nh = N / 64;
+  const int npatch = B * pw * ph_;
+  // the N/64 workgroups of one patch run back to back on ONE XCD (block ids go round-robin over the 8 XCDs)
+  int bpatch, nhalf;
+  if ((npatch & 7) == 0) {
+    const int id = blockIdx.x;
+    bpatch = (id / (8 * nh)) * 8 + (id & 7);
+    nhalf = (id >> 3) % nh;
+  } else {
+    bpatch = blockIdx.x / nh;
+    nhalf = blockIdx.x % nh;
+  }
+  const int b = bpatch / (pw * ph_);
+  const int prem = bpatch - b * pw * ph_;
+  const int y0 = (prem / pw) * 16, x0 = (prem % pw) * 16;
+  const int n0 = nhalf * 64;
+  const int nchunks = C / FW_K;
+
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((int64_t)B * H * W * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU =
+      __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, (int)((int64_t)16 * N * C * 4), 0x00020000);
+
+  // raw patch loader: thread = pixel slot of the 18x18 patch (origin at the output origin - 1), 16 B = 4 channels
+  uint32_t voffX;
+  {
+    int py = tid / 18, px = tid - py * 18;
+    int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    bool ok = tid < 324 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    voffX = ok ? (uint32_t)((((b * H + iy) * W + ix) * C) * 4) : OOB_OFF;
+  }
+  auto issue_raw = [&](int chunk, auto S) {
+    __attribute__((address_space(3))) float* rb = (__attribute__((address_space(3))) float*)(rawp(S) + wave * 256);
+    const uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t)(chunk * FW_K * 4));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, rb, 16, chunk < nchunks ? voffX : OOB_OFF, sx, 0, 0);
+  };
+  auto issue_u = [&](int chunk, auto S) {
+    __attribute__((address_space(3))) float* ub = (__attribute__((address_space(3))) float*)(usp(S) + wave * 256);
+    const uint32_t su = __builtin_amdgcn_readfirstlane((uint32_t)(((nhalf * nchunks + chunk) * FW_UV) * 4));
+    const bool live = chunk < nchunks;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, ub + q * 2048, 16, live ? (uint32_t)((q * 512 + tid) * 16) : OOB_OFF, su,
+                                               0, 0);
+  };
+  // input transform: thread = (tile tt, channel tc, row pair hb); waves 0-3 make rows 0,1 of B^T d B, waves 4-7 rows 2,3
+  const int hb = ph;  // wave-uniform
+  const int t8 = tid & 255;
+  const int tc = t8 & 3, ttx = (t8 >> 2) & 7, tty = t8 >> 5;
+  const int tt = tty * 8 + ttx;
+  const int roff = ((2 * tty + hb) * 18 + 2 * ttx) * 4 + tc;      // first of the three patch rows this thread reads
+  const int voffA = ((hb ? 3 : 0) * 4) * 64 * FW_K + tt * FW_K + tc;   // V row made of e0 - e2
+  const int voffB = ((hb ? 2 : 1) * 4) * 64 * FW_K + tt * FW_K + tc;   // V row made of e1 +- (e2 | e0)
+  auto load_raw = [&](auto S, float (&e)[3][4]) {
+    const float* rp = rawp(S) + roff;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) e[i][s] = rp[(i * 18 + s) * 4];
+  };
+  auto write_v = [&](auto S, const float (&e)[3][4]) {
+    float ua[4], ub[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      ua[s] = e[0][s] - e[2][s];                              // rows 0 (hb = 0: d0 - d2) and 3 (hb = 1: d1 - d3)
+      ub[s] = hb ? e[1][s] - e[0][s] : e[1][s] + e[2][s];     // rows 1 (d1 + d2) and 2 (d2 - d1)
+    }
+    float* va = vsp(S) + voffA;
+    float* vb = vsp(S) + voffB;
+    va[0 * 64 * FW_K] = ua[0] - ua[2];
+    va[1 * 64 * FW_K] = ua[1] + ua[2];
+    va[2 * 64 * FW_K] = ua[2] - ua[1];
+    va[3 * 64 * FW_K] = ua[1] - ua[3];
+    vb[0 * 64 * FW_K] = ub[0] - ub[2];
+    vb[1 * 64 * FW_K] = ub[1] + ub[2];
+    vb[2 * 64 * FW_K] = ub[2] - ub[1];
+    vb[3 * 64 * FW_K] = ub[1] - ub[3];
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  const int frow = lane & 31, khalf = lane >> 5;
+  const int aoff = (ph * 8) * 64 * FW_K + (wm * 32 + frow) * FW_K + khalf * 2;
+  const int boff = (ph * 8) * 64 * FW_K + (wn * 32 + frow) * FW_K + khalf * 2;
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  // iteration c: raw(c+1) and U(c) have landed (issued two iterations ago), barrier, issue raw(c+3) and U(c+2)
+  // into the stages everybody has just finished with, MFMAs of chunk c, transform of chunk c+1
+  auto body = [&](int c, auto S, auto Sn, auto Snn) {
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_raw(c + 3, S);
+    issue_u(c + 2, Snn);
+    float e[3][4];
+    load_raw(Sn, e);
+    const float* va = vsp(S) + aoff;
+    const float* ub = usp(S) + boff;
+    float2 a2[8], b2[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      a2[p] = *(const float2*)(va + p * 64 * FW_K);
+      b2[p] = *(const float2*)(ub + p * 64 * FW_K);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[p].x, b2[p].x, acc[p], 0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[p].y, b2[p].y, acc[p], 0, 0, 0);
+    write_v(Sn, e);
+  };
+  issue_raw(0, S0{});
+  issue_u(0, S0{});
+  issue_raw(1, S1{});
+  issue_u(1, S1{});
+  issue_raw(2, S2{});
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // raw(0) (and U(0)) landed
+  __builtin_amdgcn_s_barrier();
+  {
+    float e[3][4];
+    load_raw(S0{}, e);
+    write_v(S0{}, e);
+  }
+  stampk(std::integral_constant<int, 1>{});
+  for (int c = 0; c < nchunks; c += 3) {
+    body(c, S0{}, S1{}, S2{});
+    body(c + 1, S1{}, S2{}, S0{});
+    body(c + 2, S2{}, S0{}, S1{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (out-of-range, zero) DMAs still write LDS
+  __builtin_amdgcn_s_barrier();
+  stampk(std::integral_constant<int, 2>{});
+
+  // output transform: Y = A^T m A is linear in the rows of m, so each wave forms the partial 2x2 outputs of
+  // its two rows; the pair (ph = 0, 1) of a (wm, wn) tile swaps halves (r < 8 / r >= 8) through LDS
+  float* exb = (wm * 2 + wn) == 0 ? vs_0 : (wm * 2 + wn) == 1 ? vs_1 : (wm * 2 + wn) == 2 ? vs_2 : us_0;
+  float4* ex = (float4*)exb;
+  float4 part[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float q0[4], q1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (ph == 0) {   // rows 0, 1
+        q0[s] = acc[s][r] + acc[4 + s][r];
+        q1[s] = acc[4 + s][r];
+      } else {         // rows 2, 3
+        q0[s] = acc[s][r];
+        q1[s] = -acc[s][r] - acc[4 + s][r];
+      }
+    }
+    part[r] = make_float4(q0[0] + q0[1] + q0[2], q0[1] - q0[2] - q0[3], q1[0] + q1[1] + q1[2], q1[1] - q1[2] - q1[3]);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if ((r >> 3) != ph) ex[(ph * 8 + (r & 7)) * 64 + lane] = part[r];
+  __syncthreads();
+  const int n = n0 + wn * 32 + (lane & 31);
+  const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if ((r >> 3) != ph) continue;
+    const float4 o = ex[((1 - ph) * 8 + (r & 7)) * 64 + lane];
+    const int t = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int ty = t >> 3, tx = t & 7;
+    const int64_t pix = ((int64_t)b * H + y0 + 2 * ty) * W + x0 + 2 * tx;
+    y[pix * N + n] = part[r].x + o.x + bv;
+    y[(pix + 1) * N + n] = part[r].y + o.y + bv;
+    y[(pix + W) * N + n] = part[r].z + o.z + bv;
+    y[(pix + W + 1) * N + n] = part[r].w + o.w + bv;
+  }
+  if constexpr (DBG) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stampk(std::integral_constant<int, 3>{});
+    if (dbg && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && lane == 0) {
+      unsigned long long* o = dbg + ((blockIdx.x ? 1 : 0) * 8 + wave) * 4;
+      for (int k = 0; k < 4; ++k) o[k] = tsk[k];
     }
   }
 #endif
@@ -1373,7 +1623,11 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
   hipLaunchKernelGGL(fill_rand_kernel, dim3(8), dim3(256), 0, 0, bias, (int64_t)Cout, 3u);
   p.x = x; p.w = w; p.y = y; p.bias = bias;
   float *fwU = nullptr, *xs = nullptr;
-  if (variant == 50 || variant == 51 || variant == 52) {
+  unsigned long long* fwdbg = nullptr;
+  unsigned long long* fwdbg2 = nullptr;
+  if (variant == 55) { KD_HIP_CHECK(hipMalloc((void**)&fwdbg2, 2 * 8 * 4 * 8)); KD_HIP_CHECK(hipMemset(fwdbg2, 0, 2 * 8 * 4 * 8)); }
+  if (variant == 53) { KD_HIP_CHECK(hipMalloc((void**)&fwdbg, 2 * 4 * 18 * 8)); KD_HIP_CHECK(hipMemset(fwdbg, 0, 2 * 4 * 18 * 8)); }
+  if (variant >= 50 && variant <= 55) {
     KD_HIP_CHECK(hipMalloc((void**)&fwU, (size_t)16 * Cout * Cin * 4));
     KD_HIP_CHECK(hipMalloc((void**)&xs, nx * 4));
     hipLaunchKernelGGL(fw_pack_kernel, dim3((unsigned)(((int64_t)Cout * Cin + 255) / 256)), dim3(256), 0, 0, w, fwU, Cout, Cin);
@@ -1416,12 +1670,24 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
       case 40: launch_ring<3>(p, 0); break;   // BK=16 3-stage ring, 1 barrier/chunk, 3 workgroups per CU
       case 41: launch_ring<2>(p, 0); break;   // same, 2 workgroups per CU
       case 50:   // fused Winograd F(2x2,3x3): y = conv3x3(SiLU(x)) + bias (needs K == 3, H, W % 16 == 0, C % 4 == 0, Cout % 64 == 0)
-        hipLaunchKernelGGL(conv_fwino_kernel, dim3(B * (H / 16) * (W / 16), Cout / 64), dim3(256), 0, 0, x, fwU, bias, y, B,
-                           H, W, Cin, Cout, 1);
+        hipLaunchKernelGGL(conv_fwino_kernel<0>, dim3(B * (H / 16) * (W / 16), Cout / 64), dim3(256), 0, 0, x, fwU, bias, y, B,
+                           H, W, Cin, Cout, 1, nullptr);
         break;
       case 52:   // fused Winograd on a pre-activated input (the GroupNorm apply pass stays separate)
-        hipLaunchKernelGGL(conv_fwino_kernel, dim3(B * (H / 16) * (W / 16), Cout / 64), dim3(256), 0, 0, xs, fwU, bias, y, B,
-                           H, W, Cin, Cout, 0);
+        hipLaunchKernelGGL(conv_fwino_kernel<0>, dim3(B * (H / 16) * (W / 16), Cout / 64), dim3(256), 0, 0, xs, fwU, bias, y, B,
+                           H, W, Cin, Cout, 0, nullptr);
+        break;
+      case 54:   // fused Winograd, 8 waves (2 per SIMD), pre-activated input
+        hipLaunchKernelGGL(conv_fwino2_kernel<0>, dim3(B * (H / 16) * (W / 16) * (Cout / 64)), dim3(512), 0, 0, xs, fwU, bias, y,
+                           B, H, W, Cin, Cout, nullptr);
+        break;
+      case 55:   // the same with s_memtime stamps: prologue | loop | epilogue
+        hipLaunchKernelGGL(conv_fwino2_kernel<1>, dim3(B * (H / 16) * (W / 16) * (Cout / 64)), dim3(512), 0, 0, xs, fwU, bias, y,
+                           B, H, W, Cin, Cout, fwdbg2);
+        break;
+      case 53:   // variant 50 with s_memtime stamps (printed once after the timing loop)
+        hipLaunchKernelGGL(conv_fwino_kernel<1>, dim3(B * (H / 16) * (W / 16), Cout / 64), dim3(256), 0, 0, x, fwU, bias, y, B,
+                           H, W, Cin, Cout, 1, fwdbg);
         break;
       case 51: { ConvParams q = p; q.x = xs; launch_conv_igemm(q, 0); } break;   // reference for 50: production conv on SiLU(x)
       default: break;
@@ -1441,6 +1707,28 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
   float ms = 0.f;
   KD_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
   *out_us = ms * 1e3f / iters;
+  if (fwdbg) {
+    unsigned long long h[2 * 4 * 18];
+    KD_HIP_CHECK(hipMemcpy(h, fwdbg, sizeof(h), hipMemcpyDeviceToHost));
+    for (int bw = 0; bw < 8; ++bw) {
+      fprintf(stderr, "fwino stamps block%d wave%d:", bw / 4, bw % 4);
+      for (int i = 0; i < 3; ++i) {
+        fprintf(stderr, "  |");
+        for (int k = 0; k < 6; ++k) fprintf(stderr, " %lld", (long long)(h[bw * 18 + i * 6 + k] - h[bw * 18]));
+      }
+      fprintf(stderr, "\n");
+    }
+    (void)hipFree(fwdbg);
+  }
+  if (fwdbg2) {
+    unsigned long long h[2 * 8 * 4];
+    KD_HIP_CHECK(hipMemcpy(h, fwdbg2, sizeof(h), hipMemcpyDeviceToHost));
+    for (int bw = 0; bw < 16; ++bw)
+      fprintf(stderr, "fwino2 block%d wave%d: prologue %lld loop %lld epilogue %lld (start +%lld)\n", bw / 8, bw % 8,
+              (long long)(h[bw * 4 + 1] - h[bw * 4]), (long long)(h[bw * 4 + 2] - h[bw * 4 + 1]),
+              (long long)(h[bw * 4 + 3] - h[bw * 4 + 2]), (long long)(h[bw * 4] - h[(bw / 8) * 32]));
+    (void)hipFree(fwdbg2);
+  }
   // checksum of a few outputs so that variants can be compared for correctness
   float hbuf[256];
   KD_HIP_CHECK(hipMemcpy(hbuf, y + (ny / 2 / 4) * 4, sizeof(hbuf), hipMemcpyDeviceToHost));

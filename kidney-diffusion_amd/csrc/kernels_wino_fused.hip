@@ -1,0 +1,290 @@
+// Fused Winograd F(2x2,3x3) convolution for the shallow, wide-map 3x3 layers (Cin = 128-type levels).
+//
+//   y = conv3x3(x) + bias (+ res),  x NHWC already activated (GroupNorm/FiLM/SiLU applied by gn_apply),
+//   3x3 / stride 1 / pad 1, H % 16 == 0, W % 16 == 0, Cin % 4 == 0, Cout % 64 == 0.
+//
+// kernels_wino.hip runs the 16 Winograd GEMMs on the implicit-GEMM kernel and moves V and D (4x the map
+// each) through HBM; that loses below Cin = 256.  Here nothing but x, U and y touches HBM: one workgroup
+// owns a 16x16-pixel patch (8x8 output tiles) x 64 output channels and keeps ALL 16 positions'
+// accumulators in registers, so the MFMA work is 4 MACs per output and input channel instead of 9.
+//
+// What shaped it (profiles/README.md, scratch/mfma_fill.hip): on gfx950 a VALU instruction issued in the
+// shadow of v_mfma_f32_32x32x2_f32 costs its full 4-8 cycles (the fp32 MFMA holds the SIMD's vector
+// issue; only LDS / DMA instructions hide), and one wave per SIMD leaves every LDS latency exposed.  So
+//   * 8 waves = 2 per SIMD, 128 accumulator registers each: wave (ph, wm, wn) owns 32 tiles x 32 channels
+//     x the 8 positions of transformed rows {2ph, 2ph+1};
+//   * the input transform is the only VALU work in the loop: 20 instructions per thread and 4-channel
+//     chunk (thread = tile x channel x row pair); the activation stays in the HBM-bound gn_apply pass and
+//     zero padding is the out-of-range result of the buffer DMA;
+//   * raw 18x18x4 patches and 16x64x4 weight chunks arrive by buffer_load ... lds, three stages, ONE
+//     barrier per chunk; every stage is its own __shared__ object with a compile-time index, otherwise
+//     hipcc cannot tell the DMA's LDS writes from the ds_reads and waits vmcnt(0) before each of them;
+//   * the output transform A^T m A is linear in the rows of m: each wave forms partial 2x2 outputs from
+//     its two rows and the pair swaps halves through LDS.
+// Result differs from the direct conv by re-association only.
+#include "common.h"
+
+#include <type_traits>
+
+namespace kd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr uint32_t OOB_OFF = 0x80000000u;   // buffer offset past num_records: the DMA writes zeros
+constexpr int WF_K = 4;                     // input channels per chunk
+constexpr int WF_RAW = 2048;                // 512 pixel slots x 4 floats (18 x 18 = 324 used)
+constexpr int WF_UV = 16 * 64 * WF_K;       // one chunk of U (16 positions x 64 channels) or V (x 64 tiles)
+
+// OIHW 3x3 weights -> U = G g G^T in the order the kernel's DMA reads: [N/64][C/4][16][64][4]
+__global__ __launch_bounds__(256) void wino_fused_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int N,
+                                                              int C) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * C) return;
+  const int n = (int)(idx / C), c = (int)(idx % C);
+  const float* g = w + idx * 9;
+  float t[4][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float g0 = g[k], g1 = g[3 + k], g2 = g[6 + k];
+    t[0][k] = g0;
+    t[1][k] = 0.5f * (g0 + g1 + g2);
+    t[2][k] = 0.5f * (g0 - g1 + g2);
+    t[3][k] = g2;
+  }
+  const int nchunks = C / WF_K;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float u[4] = {t[r][0], 0.5f * (t[r][0] + t[r][1] + t[r][2]), 0.5f * (t[r][0] - t[r][1] + t[r][2]), t[r][2]};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int p = r * 4 + s;
+      U[((((int64_t)(n / 64) * nchunks + c / WF_K) * 16 + p) * 64 + (n % 64)) * WF_K + (c % WF_K)] = u[s];
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ U,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ res, int ldres,
+                                                            float* __restrict__ y, int B, int H, int W, int C, int N) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(1024))) float raw_0[WF_RAW], raw_1[WF_RAW], raw_2[WF_RAW];
+  __shared__ __attribute__((aligned(1024))) float us_0[WF_UV], us_1[WF_UV], us_2[WF_UV];
+  __shared__ __attribute__((aligned(1024))) float vs_0[WF_UV], vs_1[WF_UV], vs_2[WF_UV];
+  auto rawp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return raw_0; else if constexpr (decltype(S)::value == 1) return raw_1; else return raw_2; };
+  auto usp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return us_0; else if constexpr (decltype(S)::value == 1) return us_1; else return us_2; };
+  auto vsp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return vs_0; else if constexpr (decltype(S)::value == 1) return vs_1; else return vs_2; };
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int pw = W / 16, ph_ = H / 16;
+  const int nh = N / 64;
+  const int npatch = B * pw * ph_;
+  // the N/64 workgroups of one patch run back to back on ONE XCD (block ids go round-robin over the 8 XCDs)
+  int bpatch, nhalf;
+  if ((npatch & 7) == 0) {
+    const int id = blockIdx.x;
+    bpatch = (id / (8 * nh)) * 8 + (id & 7);
+    nhalf = (id >> 3) % nh;
+  } else {
+    bpatch = blockIdx.x / nh;
+    nhalf = blockIdx.x % nh;
+  }
+  const int b = bpatch / (pw * ph_);
+  const int prem = bpatch - b * pw * ph_;
+  const int y0 = (prem / pw) * 16, x0 = (prem % pw) * 16;
+  const int n0 = nhalf * 64;
+  const int nchunks = C / WF_K;
+
+  // one image per descriptor: 32-bit buffer offsets cover H*W*C*4 < 2^31 (1024^2 x 128 fp32 = 512 MB)
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)b * H * W * C), 0,
+                                                                       (int)((int64_t)H * W * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU =
+      __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, (int)((int64_t)16 * N * C * 4), 0x00020000);
+
+  // raw patch loader: thread = pixel slot of the 18x18 patch (origin at the output origin - 1), 16 B = 4 channels
+  uint32_t voffX;
+  {
+    int py = tid / 18, px = tid - py * 18;
+    int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    bool ok = tid < 324 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    voffX = ok ? (uint32_t)(((iy * W + ix) * C) * 4) : OOB_OFF;
+  }
+  auto issue_raw = [&](int chunk, auto S) {
+    __attribute__((address_space(3))) float* rb = (__attribute__((address_space(3))) float*)(rawp(S) + wave * 256);
+    const uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t)(chunk * WF_K * 4));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, rb, 16, chunk < nchunks ? voffX : OOB_OFF, sx, 0, 0);
+  };
+  auto issue_u = [&](int chunk, auto S) {
+    __attribute__((address_space(3))) float* ub = (__attribute__((address_space(3))) float*)(usp(S) + wave * 256);
+    const uint32_t su = __builtin_amdgcn_readfirstlane((uint32_t)(((nhalf * nchunks + chunk) * WF_UV) * 4));
+    const bool live = chunk < nchunks;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, ub + q * 2048, 16, live ? (uint32_t)((q * 512 + tid) * 16) : OOB_OFF, su,
+                                               0, 0);
+  };
+  // input transform: thread = (tile tt, channel tc, row pair hb); waves 0-3 make rows 0,1 of B^T d B, waves 4-7 rows 2,3
+  const int hb = ph;  // wave-uniform
+  const int t8 = tid & 255;
+  const int tc = t8 & 3, ttx = (t8 >> 2) & 7, tty = t8 >> 5;
+  const int tt = tty * 8 + ttx;
+  const int roff = ((2 * tty + hb) * 18 + 2 * ttx) * 4 + tc;      // first of the three patch rows this thread reads
+  const int voffA = ((hb ? 3 : 0) * 4) * 64 * WF_K + tt * WF_K + tc;   // V row made of e0 - e2
+  const int voffB = ((hb ? 2 : 1) * 4) * 64 * WF_K + tt * WF_K + tc;   // V row made of e1 +- (e2 | e0)
+  auto load_raw = [&](auto S, float (&e)[3][4]) {
+    const float* rp = rawp(S) + roff;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) e[i][s] = rp[(i * 18 + s) * 4];
+  };
+  auto write_v = [&](auto S, const float (&e)[3][4]) {
+    float ua[4], ub[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      ua[s] = e[0][s] - e[2][s];                              // rows 0 (hb = 0: d0 - d2) and 3 (hb = 1: d1 - d3)
+      ub[s] = hb ? e[1][s] - e[0][s] : e[1][s] + e[2][s];     // rows 1 (d1 + d2) and 2 (d2 - d1)
+    }
+    float* va = vsp(S) + voffA;
+    float* vb = vsp(S) + voffB;
+    va[0 * 64 * WF_K] = ua[0] - ua[2];
+    va[1 * 64 * WF_K] = ua[1] + ua[2];
+    va[2 * 64 * WF_K] = ua[2] - ua[1];
+    va[3 * 64 * WF_K] = ua[1] - ua[3];
+    vb[0 * 64 * WF_K] = ub[0] - ub[2];
+    vb[1 * 64 * WF_K] = ub[1] + ub[2];
+    vb[2 * 64 * WF_K] = ub[2] - ub[1];
+    vb[3 * 64 * WF_K] = ub[1] - ub[3];
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  const int frow = lane & 31, khalf = lane >> 5;
+  const int aoff = (ph * 8) * 64 * WF_K + (wm * 32 + frow) * WF_K + khalf * 2;
+  const int boff = (ph * 8) * 64 * WF_K + (wn * 32 + frow) * WF_K + khalf * 2;
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  // iteration c: raw(c+1) and U(c) have landed (issued two iterations ago), barrier, issue raw(c+3) and U(c+2)
+  // into the stages everybody has just finished with, MFMAs of chunk c, transform of chunk c+1
+  auto body = [&](int c, auto S, auto Sn, auto Snn) {
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_raw(c + 3, S);
+    issue_u(c + 2, Snn);
+    float e[3][4];
+    load_raw(Sn, e);
+    const float* va = vsp(S) + aoff;
+    const float* ub = usp(S) + boff;
+    float2 a2[8], b2[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      a2[p] = *(const float2*)(va + p * 64 * WF_K);
+      b2[p] = *(const float2*)(ub + p * 64 * WF_K);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[p].x, b2[p].x, acc[p], 0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[p].y, b2[p].y, acc[p], 0, 0, 0);
+    write_v(Sn, e);
+  };
+  issue_raw(0, S0{});
+  issue_u(0, S0{});
+  issue_raw(1, S1{});
+  issue_u(1, S1{});
+  issue_raw(2, S2{});
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // raw(0) (and U(0)) landed
+  __builtin_amdgcn_s_barrier();
+  {
+    float e[3][4];
+    load_raw(S0{}, e);
+    write_v(S0{}, e);
+  }
+  for (int c = 0; c < nchunks; c += 3) {
+    body(c, S0{}, S1{}, S2{});
+    body(c + 1, S1{}, S2{}, S0{});
+    body(c + 2, S2{}, S0{}, S1{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (out-of-range, zero) DMAs still write LDS
+  __builtin_amdgcn_s_barrier();
+
+  // output transform: Y = A^T m A is linear in the rows of m, so each wave forms the partial 2x2 outputs of
+  // its two rows; the pair (ph = 0, 1) of a (wm, wn) tile swaps halves (r < 8 / r >= 8) through LDS
+  float* exb = (wm * 2 + wn) == 0 ? vs_0 : (wm * 2 + wn) == 1 ? vs_1 : (wm * 2 + wn) == 2 ? vs_2 : us_0;
+  float4* ex = (float4*)exb;
+  float4 part[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float q0[4], q1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (ph == 0) {   // rows 0, 1
+        q0[s] = acc[s][r] + acc[4 + s][r];
+        q1[s] = acc[4 + s][r];
+      } else {         // rows 2, 3
+        q0[s] = acc[s][r];
+        q1[s] = -acc[s][r] - acc[4 + s][r];
+      }
+    }
+    part[r] = make_float4(q0[0] + q0[1] + q0[2], q0[1] - q0[2] - q0[3], q1[0] + q1[1] + q1[2], q1[1] - q1[2] - q1[3]);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if ((r >> 3) != ph) ex[(ph * 8 + (r & 7)) * 64 + lane] = part[r];
+  __syncthreads();
+  const int n = n0 + wn * 32 + (lane & 31);
+  const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if ((r >> 3) != ph) continue;
+    const float4 o = ex[((1 - ph) * 8 + (r & 7)) * 64 + lane];
+    const int t = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int ty = t >> 3, tx = t & 7;
+    const int64_t pix = ((int64_t)b * H + y0 + 2 * ty) * W + x0 + 2 * tx;
+    float o00 = part[r].x + o.x + bv, o01 = part[r].y + o.y + bv, o10 = part[r].z + o.z + bv,
+          o11 = part[r].w + o.w + bv;
+    if (res) {
+      o00 += res[pix * ldres + n];
+      o01 += res[(pix + 1) * ldres + n];
+      o10 += res[(pix + W) * ldres + n];
+      o11 += res[(pix + W + 1) * ldres + n];
+    }
+    y[pix * N + n] = o00;
+    y[(pix + 1) * N + n] = o01;
+    y[(pix + W) * N + n] = o10;
+    y[(pix + W + 1) * N + n] = o11;
+  }
+#endif
+}
+
+bool wino_fused_ok(int B, int H, int W, int C, int N) {
+  return B > 0 && H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0 && C >= WF_K && C % WF_K == 0 && N >= 64 &&
+         N % 64 == 0 && (int64_t)H * W * C * 4 < 0x7fffffff && (int64_t)16 * N * C * 4 < 0x7fffffff &&
+         (int64_t)B * (H / 16) * (W / 16) * (N / 64) < 0x7fffffff;
+}
+
+int launch_wino_fused_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s) {
+  KD_REQUIRE(O % 64 == 0 && I % WF_K == 0, "fused Winograd weights need Cout % 64 == 0 and Cin % 4 == 0");
+  const int64_t total = (int64_t)O * I;
+  hipLaunchKernelGGL(wino_fused_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oihw, U, O, I);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_wino_fused(const float* x, const float* U, const float* bias, const float* res, int ldres, float* y, int B,
+                      int H, int W, int C, int N, hipStream_t s) {
+  KD_REQUIRE(wino_fused_ok(B, H, W, C, N),
+             "fused Winograd conv needs H, W % 16 == 0, Cin % 4 == 0, Cout % 64 == 0 and maps below 2 GB per image");
+  const unsigned grid = (unsigned)((int64_t)B * (H / 16) * (W / 16) * (N / 64));
+  hipLaunchKernelGGL(wino_fused_kernel, dim3(grid), dim3(512), 0, s, x, U, bias, res, ldres, y, B, H, W, C, N);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace kd

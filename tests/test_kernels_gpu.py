@@ -119,6 +119,48 @@ def test_conv3x3_winograd_rejects_unsupported_shapes(lib, device):
     assert rc != 0 and b"even" in lib.kd_last_error()
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,res", [
+    (2, 64, 64, 128, 128, False),   # the SR UNet's top level, scaled down: 32 patches x 2 channel halves
+    (1, 16, 16, 128, 64, True),     # ONE patch: every side is zero padding; residual in the epilogue
+    (3, 32, 48, 20, 192, True),     # 5 chunks (not a multiple of the 3 pipeline stages), 3 channel slabs, H != W
+    (1, 48, 16, 4, 64, False),      # a single 4-channel chunk
+    (2, 32, 32, 256, 128, False),   # 64 chunks
+])
+def test_conv3x3_winograd_fused_matches_direct(lib, device, B, H, W, Cin, Cout, res):
+    E = _E()
+    x = torch.randn(B, Cin, H, W, generator=g(1))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g(2)) * (Cin * 9) ** -0.5
+    b = torch.randn(Cout, generator=g(3))
+    r = torch.randn(B, Cout, H, W, generator=g(4)) if res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if res:
+        ref = ref + r.double()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(device)
+    wd, bd = w.to(device), b.to(device)
+    rd = r.permute(0, 2, 3, 1).contiguous().to(device) if res else None
+    y = torch.full((B, H, W, Cout), float("nan"), device=device)
+    E.check(lib.kd_conv3x3_winograd_fused_nhwc(E.ptr(xd), E.ptr(wd), E.ptr(bd), E.ptr(rd) if res else None, E.ptr(y),
+                                               B, H, W, Cin, Cout, E.current_stream()))
+    got = y.permute(0, 3, 1, 2).cpu().double()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).norm() / ref.norm())
+    assert err <= WINO_REL, err
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), "element-wise outlier"
+    # a second call is bit-identical (no atomics, fixed summation order)
+    y2 = torch.empty_like(y)
+    E.check(lib.kd_conv3x3_winograd_fused_nhwc(E.ptr(xd), E.ptr(wd), E.ptr(bd), E.ptr(rd) if res else None, E.ptr(y2),
+                                               B, H, W, Cin, Cout, E.current_stream()))
+    assert torch.equal(y, y2)
+
+
+def test_conv3x3_winograd_fused_rejects_unsupported_shapes(lib, device):
+    E = _E()
+    t = torch.zeros(16, device=device)
+    for shape in [(1, 24, 16, 32, 64), (1, 16, 16, 30, 64), (1, 16, 16, 32, 96)]:
+        rc = lib.kd_conv3x3_winograd_fused_nhwc(E.ptr(t), E.ptr(t), None, None, E.ptr(t), *shape, E.current_stream())
+        assert rc != 0 and b"% 16" in lib.kd_last_error()
+
+
 @pytest.mark.parametrize("B,HW,C,G,film", [(2, 64, 32, 8, False), (3, 100, 96, 8, True), (1, 4096, 128, 8, True),
                                            (2, 16, 1024, 8, True), (2, 300, 384, 8, False)])
 def test_groupnorm_film_silu(lib, device, B, HW, C, G, film):

@@ -66,7 +66,9 @@ def test_unet_forward_with_winograd_levels_matches_oracle(device):
 
     outs, n_gemm = {}, {}
     # (conv_algo, KD_WINO_SLICE_MB): the last variant walks every Winograd layer in 256-tile slices
-    for algo, slice_mb in ((32, None), (1, None), (32, "1")):
+    # conv_algo=3: the FUSED Winograd kernel (kernels_wino_fused.hip) wherever its shape rules allow, even
+    # where the launch would not fill the chip (here the 16x16 maps with 64 output channels)
+    for algo, slice_mb in ((32, None), (1, None), (32, "1"), (3, None)):
         pu = H.product_unet_like(ou).to(device)
         pu.conv_algo = algo
         if slice_mb is not None:
@@ -81,9 +83,13 @@ def test_unet_forward_with_winograd_levels_matches_oracle(device):
         E.check(E.load().kd_unet_profile(pu.engine(B, S, device, with_text=False), 1, buf, len(buf),
                                          E.current_stream()))
         n_wino = buf.value.decode().count("wino gemm")
-        assert (n_wino > 0) == (algo == 32), f"conv_algo={algo}: {n_wino} Winograd GEMMs in the plan"
+        n_fused = buf.value.decode().count("wino fused")
+        if algo != 3:   # 3 keeps the batched-GEMM path from Cin >= 256 like 0
+            assert (n_wino > 0) == (algo == 32), f"conv_algo={algo}: {n_wino} Winograd GEMMs in the plan"
+        assert (n_fused > 0) == (algo == 3), f"conv_algo={algo}: {n_fused} fused Winograd convs in the plan"
         outs[(algo, slice_mb)], n_gemm[(algo, slice_mb)] = got, n_wino
     assert H.rel_l2(outs[(32, None)], outs[(1, None)]) < FWD_REL_L2
+    assert H.rel_l2(outs[(3, None)], outs[(1, None)]) < FWD_REL_L2
     assert n_gemm[(32, "1")] > n_gemm[(32, None)], "slicing did not split the Winograd layers"
     assert torch.equal(outs[(32, "1")], outs[(32, None)]), "sliced and unsliced Winograd must be bit-identical"
 
