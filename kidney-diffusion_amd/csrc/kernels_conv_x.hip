@@ -1484,11 +1484,22 @@ __global__ __launch_bounds__(512, 1) void conv_fwino2_kernel(const float* __rest
   using S2 = std::integral_constant<int, 2>;
   // iteration c: raw(c+1) and U(c) have landed (issued two iterations ago), barrier, issue raw(c+3) and U(c+2)
   // into the stages everybody has just finished with, MFMAs of chunk c, transform of chunk c+1
+  unsigned long long tsb[3][6];
+  auto stampb = [&](auto I, auto Kk) {
+    if constexpr (DBG == 2) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      tsb[decltype(I)::value][decltype(Kk)::value] = t;
+    }
+  };
   auto body = [&](int c, auto S, auto Sn, auto Snn) {
+    stampb(S, std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    stampb(S, std::integral_constant<int, 1>{});
     issue_raw(c + 3, S);
     issue_u(c + 2, Snn);
+    stampb(S, std::integral_constant<int, 2>{});
     float e[3][4];
     load_raw(Sn, e);
     const float* va = vsp(S) + aoff;
@@ -1499,11 +1510,14 @@ __global__ __launch_bounds__(512, 1) void conv_fwino2_kernel(const float* __rest
       a2[p] = *(const float2*)(va + p * 64 * FW_K);
       b2[p] = *(const float2*)(ub + p * 64 * FW_K);
     }
+    stampb(S, std::integral_constant<int, 3>{});   // all LDS reads landed (the stamp waits lgkmcnt(0))
 #pragma unroll
     for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[p].x, b2[p].x, acc[p], 0, 0, 0);
 #pragma unroll
     for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[p].y, b2[p].y, acc[p], 0, 0, 0);
+    stampb(S, std::integral_constant<int, 4>{});
     write_v(Sn, e);
+    stampb(S, std::integral_constant<int, 5>{});
   };
   issue_raw(0, S0{});
   issue_u(0, S0{});
@@ -1571,6 +1585,13 @@ __global__ __launch_bounds__(512, 1) void conv_fwino2_kernel(const float* __rest
     if (dbg && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && lane == 0) {
       unsigned long long* o = dbg + ((blockIdx.x ? 1 : 0) * 8 + wave) * 4;
       for (int k = 0; k < 4; ++k) o[k] = tsk[k];
+      if constexpr (DBG == 2) {
+        unsigned long long* ob = dbg + 64 + ((blockIdx.x ? 1 : 0) * 8 + wave) * 18;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ob[i * 6 + k] = tsb[i][k];
+      }
     }
   }
 #endif
@@ -1625,9 +1646,9 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
   float *fwU = nullptr, *xs = nullptr;
   unsigned long long* fwdbg = nullptr;
   unsigned long long* fwdbg2 = nullptr;
-  if (variant == 55) { KD_HIP_CHECK(hipMalloc((void**)&fwdbg2, 2 * 8 * 4 * 8)); KD_HIP_CHECK(hipMemset(fwdbg2, 0, 2 * 8 * 4 * 8)); }
+  if (variant == 55 || variant == 56) { KD_HIP_CHECK(hipMalloc((void**)&fwdbg2, (64 + 2 * 8 * 18) * 8)); KD_HIP_CHECK(hipMemset(fwdbg2, 0, (64 + 2 * 8 * 18) * 8)); }
   if (variant == 53) { KD_HIP_CHECK(hipMalloc((void**)&fwdbg, 2 * 4 * 18 * 8)); KD_HIP_CHECK(hipMemset(fwdbg, 0, 2 * 4 * 18 * 8)); }
-  if (variant >= 50 && variant <= 55) {
+  if (variant >= 50 && variant <= 56) {
     KD_HIP_CHECK(hipMalloc((void**)&fwU, (size_t)16 * Cout * Cin * 4));
     KD_HIP_CHECK(hipMalloc((void**)&xs, nx * 4));
     hipLaunchKernelGGL(fw_pack_kernel, dim3((unsigned)(((int64_t)Cout * Cin + 255) / 256)), dim3(256), 0, 0, w, fwU, Cout, Cin);
@@ -1681,6 +1702,10 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
         hipLaunchKernelGGL(conv_fwino2_kernel<0>, dim3(B * (H / 16) * (W / 16) * (Cout / 64)), dim3(512), 0, 0, xs, fwU, bias, y,
                            B, H, W, Cin, Cout, nullptr);
         break;
+      case 56:   // the same with s_memtime stamps inside the last three chunks
+        hipLaunchKernelGGL(conv_fwino2_kernel<2>, dim3(B * (H / 16) * (W / 16) * (Cout / 64)), dim3(512), 0, 0, xs, fwU, bias, y,
+                           B, H, W, Cin, Cout, fwdbg2);
+        break;
       case 55:   // the same with s_memtime stamps: prologue | loop | epilogue
         hipLaunchKernelGGL(conv_fwino2_kernel<1>, dim3(B * (H / 16) * (W / 16) * (Cout / 64)), dim3(512), 0, 0, xs, fwU, bias, y,
                            B, H, W, Cin, Cout, fwdbg2);
@@ -1727,6 +1752,18 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
       fprintf(stderr, "fwino2 block%d wave%d: prologue %lld loop %lld epilogue %lld (start +%lld)\n", bw / 8, bw % 8,
               (long long)(h[bw * 4 + 1] - h[bw * 4]), (long long)(h[bw * 4 + 2] - h[bw * 4 + 1]),
               (long long)(h[bw * 4 + 3] - h[bw * 4 + 2]), (long long)(h[bw * 4] - h[(bw / 8) * 32]));
+    if (variant == 56) {
+      unsigned long long hb[2 * 8 * 18];
+      KD_HIP_CHECK(hipMemcpy(hb, fwdbg2 + 64, sizeof(hb), hipMemcpyDeviceToHost));
+      for (int bw = 0; bw < 16; ++bw) {
+        fprintf(stderr, "fwino2 chunk stamps block%d wave%d:", bw / 8, bw % 8);
+        for (int i = 0; i < 3; ++i) {
+          fprintf(stderr, "  |");
+          for (int k = 0; k < 6; ++k) fprintf(stderr, " %lld", (long long)(hb[bw * 18 + i * 6 + k] - hb[bw * 18]));
+        }
+        fprintf(stderr, "\n");
+      }
+    }
     (void)hipFree(fwdbg2);
   }
   // checksum of a few outputs so that variants can be compared for correctness

@@ -125,39 +125,11 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restr
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, ub + q * 2048, 16, live ? (uint32_t)((q * 512 + tid) * 16) : OOB_OFF, su,
                                                0, 0);
   };
-  // input transform: thread = (tile tt, channel tc, row pair hb); waves 0-3 make rows 0,1 of B^T d B, waves 4-7 rows 2,3
-  const int hb = ph;  // wave-uniform
+  // input transform: thread = (tile tt, channel tc, row pair hb); waves 0-3 (hb = 0) make rows 0,1 of B^T d B,
+  // waves 4-7 (hb = 1) rows 2,3.  hb is a compile-time constant of the loop each half runs (run(HB) below)
   const int t8 = tid & 255;
   const int tc = t8 & 3, ttx = (t8 >> 2) & 7, tty = t8 >> 5;
   const int tt = tty * 8 + ttx;
-  const int roff = ((2 * tty + hb) * 18 + 2 * ttx) * 4 + tc;      // first of the three patch rows this thread reads
-  const int voffA = ((hb ? 3 : 0) * 4) * 64 * WF_K + tt * WF_K + tc;   // V row made of e0 - e2
-  const int voffB = ((hb ? 2 : 1) * 4) * 64 * WF_K + tt * WF_K + tc;   // V row made of e1 +- (e2 | e0)
-  auto load_raw = [&](auto S, float (&e)[3][4]) {
-    const float* rp = rawp(S) + roff;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) e[i][s] = rp[(i * 18 + s) * 4];
-  };
-  auto write_v = [&](auto S, const float (&e)[3][4]) {
-    float ua[4], ub[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      ua[s] = e[0][s] - e[2][s];                              // rows 0 (hb = 0: d0 - d2) and 3 (hb = 1: d1 - d3)
-      ub[s] = hb ? e[1][s] - e[0][s] : e[1][s] + e[2][s];     // rows 1 (d1 + d2) and 2 (d2 - d1)
-    }
-    float* va = vsp(S) + voffA;
-    float* vb = vsp(S) + voffB;
-    va[0 * 64 * WF_K] = ua[0] - ua[2];
-    va[1 * 64 * WF_K] = ua[1] + ua[2];
-    va[2 * 64 * WF_K] = ua[2] - ua[1];
-    va[3 * 64 * WF_K] = ua[1] - ua[3];
-    vb[0 * 64 * WF_K] = ub[0] - ub[2];
-    vb[1 * 64 * WF_K] = ub[1] + ub[2];
-    vb[2 * 64 * WF_K] = ub[2] - ub[1];
-    vb[3 * 64 * WF_K] = ub[1] - ub[3];
-  };
 
   f32x16 acc[8];
 #pragma unroll
@@ -171,28 +143,78 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restr
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
-  // iteration c: raw(c+1) and U(c) have landed (issued two iterations ago), barrier, issue raw(c+3) and U(c+2)
-  // into the stages everybody has just finished with, MFMAs of chunk c, transform of chunk c+1
-  auto body = [&](int c, auto S, auto Sn, auto Snn) {
-    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    issue_raw(c + 3, S);
-    issue_u(c + 2, Snn);
-    float e[3][4];
-    load_raw(Sn, e);
-    const float* va = vsp(S) + aoff;
-    const float* ub = usp(S) + boff;
-    float2 a2[8], b2[8];
+  auto run = [&](auto HB) {
+    constexpr int hb = decltype(HB)::value;
+    const int roff = ((2 * tty + hb) * 18 + 2 * ttx) * 4 + tc;            // first of the three patch rows read
+    const int voffA = ((hb ? 3 : 0) * 4) * 64 * WF_K + tt * WF_K + tc;    // V row made of e0 - e2
+    const int voffB = ((hb ? 2 : 1) * 4) * 64 * WF_K + tt * WF_K + tc;    // V row made of e1 +- (e2 | e0)
+    auto load_raw = [&](auto S, float (&e)[3][4]) {
+      const float* rp = rawp(S) + roff;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      a2[p] = *(const float2*)(va + p * 64 * WF_K);
-      b2[p] = *(const float2*)(ub + p * 64 * WF_K);
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) e[i][s] = rp[(i * 18 + s) * 4];
+    };
+    auto write_v = [&](auto S, const float (&e)[3][4]) {
+      float ua[4], ub[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        ua[s] = e[0][s] - e[2][s];                              // rows 0 (hb = 0: d0 - d2) and 3 (hb = 1: d1 - d3)
+        ub[s] = hb ? e[1][s] - e[0][s] : e[1][s] + e[2][s];     // rows 1 (d1 + d2) and 2 (d2 - d1)
+      }
+      float* va = vsp(S) + voffA;
+      float* vb = vsp(S) + voffB;
+      va[0 * 64 * WF_K] = ua[0] - ua[2];
+      va[1 * 64 * WF_K] = ua[1] + ua[2];
+      va[2 * 64 * WF_K] = ua[2] - ua[1];
+      va[3 * 64 * WF_K] = ua[1] - ua[3];
+      vb[0 * 64 * WF_K] = ub[0] - ub[2];
+      vb[1 * 64 * WF_K] = ub[1] + ub[2];
+      vb[2 * 64 * WF_K] = ub[2] - ub[1];
+      vb[3 * 64 * WF_K] = ub[1] - ub[3];
+    };
+    auto mfmas = [&](auto S) {
+      const float* va = vsp(S) + aoff;
+      const float* ub = usp(S) + boff;
+      float2 a2[8], b2[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        a2[p] = *(const float2*)(va + p * 64 * WF_K);
+        b2[p] = *(const float2*)(ub + p * 64 * WF_K);
+      }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[p].x, b2[p].x, acc[p], 0, 0, 0);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[p].y, b2[p].y, acc[p], 0, 0, 0);
+    };
+    // iteration c: raw(c+1) and U(c) have landed (issued two iterations ago), barrier, issue raw(c+3) and U(c+2)
+    // into the stages everybody has just finished with, MFMAs of chunk c, transform of chunk c+1.  The wait
+    // covers this wave's own V stores (lgkmcnt) as __syncthreads would.  The order INSIDE the body is hipcc's:
+    // it spreads the LDS reads between the MFMAs and carries half of them across the barrier.  Four
+    // hand-placed orders (sched_barrier fences) were all slower, 45.9-46.4 against 43.5-44.6 ms/step:
+    // every LDS read right after the barrier with the transform between or after the MFMA groups, the
+    // second k-step held back across the barrier, and the two waves of a SIMD in opposite phase order
+    // (profiles/README.md).
+    auto body = [&](int c, auto S, auto Sn, auto Snn) {
+      asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_raw(c + 3, S);
+      issue_u(c + 2, Snn);
+      float e[3][4];
+      load_raw(Sn, e);
+      mfmas(S);
+      write_v(Sn, e);
+    };
+    {
+      float e[3][4];
+      load_raw(S0{}, e);
+      write_v(S0{}, e);
     }
-#pragma unroll
-    for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[p].x, b2[p].x, acc[p], 0, 0, 0);
-#pragma unroll
-    for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[p].y, b2[p].y, acc[p], 0, 0, 0);
-    write_v(Sn, e);
+    for (int c = 0; c < nchunks; c += 3) {
+      body(c, S0{}, S1{}, S2{});
+      body(c + 1, S1{}, S2{}, S0{});
+      body(c + 2, S2{}, S0{}, S1{});
+    }
   };
   issue_raw(0, S0{});
   issue_u(0, S0{});
@@ -201,16 +223,10 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restr
   issue_raw(2, S2{});
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // raw(0) (and U(0)) landed
   __builtin_amdgcn_s_barrier();
-  {
-    float e[3][4];
-    load_raw(S0{}, e);
-    write_v(S0{}, e);
-  }
-  for (int c = 0; c < nchunks; c += 3) {
-    body(c, S0{}, S1{}, S2{});
-    body(c + 1, S1{}, S2{}, S0{});
-    body(c + 2, S2{}, S0{}, S1{});
-  }
+  if (ph == 0)
+    run(std::integral_constant<int, 0>{});
+  else
+    run(std::integral_constant<int, 1>{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (out-of-range, zero) DMAs still write LDS
   __builtin_amdgcn_s_barrier();
 
