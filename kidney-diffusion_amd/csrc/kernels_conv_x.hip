@@ -1484,6 +1484,9 @@ __global__ __launch_bounds__(512, 1) void conv_fwino2_kernel(const float* __rest
   using S2 = std::integral_constant<int, 2>;
   // iteration c: raw(c+1) and U(c) have landed (issued two iterations ago), barrier, issue raw(c+3) and U(c+2)
   // into the stages everybody has just finished with, MFMAs of chunk c, transform of chunk c+1
+  float abl[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) abl[i] = (float)(tid + i);
   unsigned long long tsb[3][6];
   auto stampb = [&](auto I, auto Kk) {
     if constexpr (DBG == 2) {
@@ -1501,7 +1504,14 @@ __global__ __launch_bounds__(512, 1) void conv_fwino2_kernel(const float* __rest
     issue_u(c + 2, Snn);
     stampb(S, std::integral_constant<int, 2>{});
     float e[3][4];
-    load_raw(Sn, e);
+    if constexpr (DBG == 3 || DBG == 4) {   // ablations: no transform at all / its VALU only (no LDS traffic)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[i][q] = abl[i * 4 + q];
+    } else {
+      load_raw(Sn, e);
+    }
     const float* va = vsp(S) + aoff;
     const float* ub = usp(S) + boff;
     float2 a2[8], b2[8];
@@ -1516,7 +1526,19 @@ __global__ __launch_bounds__(512, 1) void conv_fwino2_kernel(const float* __rest
 #pragma unroll
     for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[p].y, b2[p].y, acc[p], 0, 0, 0);
     stampb(S, std::integral_constant<int, 4>{});
-    write_v(Sn, e);
+    if constexpr (DBG == 4) {
+      float ua[4], ub4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ua[q] = e[0][q] - e[2][q];
+        ub4[q] = e[1][q] + e[2][q];
+      }
+      abl[0] = ua[0] - ua[2]; abl[1] = ua[1] + ua[2]; abl[2] = ua[2] - ua[1]; abl[3] = ua[1] - ua[3];
+      abl[4] = ub4[0] - ub4[2]; abl[5] = ub4[1] + ub4[2]; abl[6] = ub4[2] - ub4[1]; abl[7] = ub4[1] - ub4[3];
+      asm volatile("" : "+v"(abl[0]), "+v"(abl[1]), "+v"(abl[2]), "+v"(abl[3]), "+v"(abl[4]), "+v"(abl[5]), "+v"(abl[6]), "+v"(abl[7]));
+    } else if constexpr (DBG != 3) {
+      write_v(Sn, e);
+    }
     stampb(S, std::integral_constant<int, 5>{});
   };
   issue_raw(0, S0{});
@@ -1648,7 +1670,7 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
   unsigned long long* fwdbg2 = nullptr;
   if (variant == 55 || variant == 56) { KD_HIP_CHECK(hipMalloc((void**)&fwdbg2, (64 + 2 * 8 * 18) * 8)); KD_HIP_CHECK(hipMemset(fwdbg2, 0, (64 + 2 * 8 * 18) * 8)); }
   if (variant == 53) { KD_HIP_CHECK(hipMalloc((void**)&fwdbg, 2 * 4 * 18 * 8)); KD_HIP_CHECK(hipMemset(fwdbg, 0, 2 * 4 * 18 * 8)); }
-  if (variant >= 50 && variant <= 56) {
+  if (variant >= 50 && variant <= 58) {
     KD_HIP_CHECK(hipMalloc((void**)&fwU, (size_t)16 * Cout * Cin * 4));
     KD_HIP_CHECK(hipMalloc((void**)&xs, nx * 4));
     hipLaunchKernelGGL(fw_pack_kernel, dim3((unsigned)(((int64_t)Cout * Cin + 255) / 256)), dim3(256), 0, 0, w, fwU, Cout, Cin);
@@ -1700,6 +1722,14 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
         break;
       case 54:   // fused Winograd, 8 waves (2 per SIMD), pre-activated input
         hipLaunchKernelGGL(conv_fwino2_kernel<0>, dim3(B * (H / 16) * (W / 16) * (Cout / 64)), dim3(512), 0, 0, xs, fwU, bias, y,
+                           B, H, W, Cin, Cout, nullptr);
+        break;
+      case 57:   // ablation: no input transform (wrong results)
+        hipLaunchKernelGGL(conv_fwino2_kernel<3>, dim3(B * (H / 16) * (W / 16) * (Cout / 64)), dim3(512), 0, 0, xs, fwU, bias, y,
+                           B, H, W, Cin, Cout, nullptr);
+        break;
+      case 58:   // ablation: the transform's VALU without its LDS reads and stores (wrong results)
+        hipLaunchKernelGGL(conv_fwino2_kernel<4>, dim3(B * (H / 16) * (W / 16) * (Cout / 64)), dim3(512), 0, 0, xs, fwU, bias, y,
                            B, H, W, Cin, Cout, nullptr);
         break;
       case 56:   // the same with s_memtime stamps inside the last three chunks

@@ -35,7 +35,16 @@ constexpr int WF_K = 4;                     // input channels per chunk
 constexpr int WF_RAW = 2048;                // 512 pixel slots x 4 floats (18 x 18 = 324 used)
 constexpr int WF_UV = 16 * 64 * WF_K;       // one chunk of U (16 positions x 64 channels) or V (x 64 tiles)
 
-// OIHW 3x3 weights -> U = G g G^T in the order the kernel's DMA reads: [N/64][C/4][16][64][4]
+// One chunk of U or V in LDS (and U in HBM, chunk after chunk): element (position p, row, k) with row = output
+// channel (U) or tile (V) and k = channel within the chunk sits at [p/2][k/2][row][p%2][k%2].  A lane of the
+// MFMA (row, k-half) then finds both k-steps of two positions in ONE 16-byte read, and the 32 rows of a
+// k-half are contiguous: ds_read_b128 at the full LDS rate without bank conflicts (a [p][row][k] layout
+// needs two 8-byte reads per pair, which hipcc merges into ds_read2st64_b64 at half that rate).
+__host__ __device__ constexpr int64_t wf_uv_index(int64_t chunk, int p, int row, int k) {
+  return chunk * WF_UV + ((((p >> 1) * 2 + (k >> 1)) * 64 + row) * 4 + (p & 1) * 2 + (k & 1));
+}
+
+// OIHW 3x3 weights -> U = G g G^T in the order the kernel's DMA reads: [N/64][C/4] chunks of wf_uv_index
 __global__ __launch_bounds__(256) void wino_fused_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int N,
                                                               int C) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,7 +67,7 @@ __global__ __launch_bounds__(256) void wino_fused_pack_kernel(const float* __res
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int p = r * 4 + s;
-      U[((((int64_t)(n / 64) * nchunks + c / WF_K) * 16 + p) * 64 + (n % 64)) * WF_K + (c % WF_K)] = u[s];
+      U[wf_uv_index((int64_t)(n / 64) * nchunks + c / WF_K, p, n % 64, c % WF_K)] = u[s];
     }
   }
 }
@@ -106,7 +115,11 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restr
   // raw patch loader: thread = pixel slot of the 18x18 patch (origin at the output origin - 1), 16 B = 4 channels
   uint32_t voffX;
   {
-    int py = tid / 18, px = tid - py * 18;
+    // slot = row * 18 + (even columns 0, 2, .. 16 first, then the odd ones): the transform's reads of column
+    // 2 * ttx + s then run along ttx with stride 1 and are free of LDS bank conflicts (stride 2 pixels = 8
+    // floats puts lanes ttx and ttx + 4 on one bank)
+    int py = tid / 18, pq = tid - py * 18;
+    int px = pq < 9 ? 2 * pq : 2 * (pq - 9) + 1;
     int iy = y0 - 1 + py, ix = x0 - 1 + px;
     bool ok = tid < 324 && iy >= 0 && iy < H && ix >= 0 && ix < W;
     voffX = ok ? (uint32_t)(((iy * W + ix) * C) * 4) : OOB_OFF;
@@ -137,23 +150,25 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
   const int frow = lane & 31, khalf = lane >> 5;
-  const int aoff = (ph * 8) * 64 * WF_K + (wm * 32 + frow) * WF_K + khalf * 2;
-  const int boff = (ph * 8) * 64 * WF_K + (wn * 32 + frow) * WF_K + khalf * 2;
+  const int aoff = (int)wf_uv_index(0, ph * 8, wm * 32 + frow, khalf * 2);
+  const int boff = (int)wf_uv_index(0, ph * 8, wn * 32 + frow, khalf * 2);
 
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
   auto run = [&](auto HB) {
     constexpr int hb = decltype(HB)::value;
-    const int roff = ((2 * tty + hb) * 18 + 2 * ttx) * 4 + tc;            // first of the three patch rows read
-    const int voffA = ((hb ? 3 : 0) * 4) * 64 * WF_K + tt * WF_K + tc;    // V row made of e0 - e2
-    const int voffB = ((hb ? 2 : 1) * 4) * 64 * WF_K + tt * WF_K + tc;    // V row made of e1 +- (e2 | e0)
+    const int roff = ((2 * tty + hb) * 18 + ttx) * 4 + tc;               // first of the three patch rows read
+    const int voffA = (int)wf_uv_index(0, (hb ? 3 : 0) * 4, tt, tc);     // V row made of e0 - e2
+    const int voffB = (int)wf_uv_index(0, (hb ? 2 : 1) * 4, tt, tc);     // V row made of e1 +- (e2 | e0)
+    constexpr int VJ[4] = {0, 2, 2 * 64 * 4, 2 * 64 * 4 + 2};            // positions r*4 + j relative to r*4
+    constexpr int RS[4] = {0, 9, 1, 10};                                  // slot of column 2*ttx + s relative to ttx
     auto load_raw = [&](auto S, float (&e)[3][4]) {
       const float* rp = rawp(S) + roff;
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) e[i][s] = rp[(i * 18 + s) * 4];
+        for (int s = 0; s < 4; ++s) e[i][s] = rp[(i * 18 + RS[s]) * 4];
     };
     auto write_v = [&](auto S, const float (&e)[3][4]) {
       float ua[4], ub[4];
@@ -164,28 +179,34 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restr
       }
       float* va = vsp(S) + voffA;
       float* vb = vsp(S) + voffB;
-      va[0 * 64 * WF_K] = ua[0] - ua[2];
-      va[1 * 64 * WF_K] = ua[1] + ua[2];
-      va[2 * 64 * WF_K] = ua[2] - ua[1];
-      va[3 * 64 * WF_K] = ua[1] - ua[3];
-      vb[0 * 64 * WF_K] = ub[0] - ub[2];
-      vb[1 * 64 * WF_K] = ub[1] + ub[2];
-      vb[2 * 64 * WF_K] = ub[2] - ub[1];
-      vb[3 * 64 * WF_K] = ub[1] - ub[3];
+      va[VJ[0]] = ua[0] - ua[2];
+      va[VJ[1]] = ua[1] + ua[2];
+      va[VJ[2]] = ua[2] - ua[1];
+      va[VJ[3]] = ua[1] - ua[3];
+      vb[VJ[0]] = ub[0] - ub[2];
+      vb[VJ[1]] = ub[1] + ub[2];
+      vb[VJ[2]] = ub[2] - ub[1];
+      vb[VJ[3]] = ub[1] - ub[3];
     };
     auto mfmas = [&](auto S) {
       const float* va = vsp(S) + aoff;
       const float* ub = usp(S) + boff;
-      float2 a2[8], b2[8];
+      float4 a4[4], b4[4];   // positions 2i, 2i+1 of this wave's eight: (k-step 0, k-step 1) each
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        a2[p] = *(const float2*)(va + p * 64 * WF_K);
-        b2[p] = *(const float2*)(ub + p * 64 * WF_K);
+      for (int i = 0; i < 4; ++i) {
+        a4[i] = *(const float4*)(va + i * 2 * 64 * 4);
+        b4[i] = *(const float4*)(ub + i * 2 * 64 * 4);
       }
 #pragma unroll
-      for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[p].x, b2[p].x, acc[p], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[i].x, acc[2 * i], 0, 0, 0);
+        acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[i].z, acc[2 * i + 1], 0, 0, 0);
+      }
 #pragma unroll
-      for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[p].y, b2[p].y, acc[p], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[i].y, acc[2 * i], 0, 0, 0);
+        acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[i].w, acc[2 * i + 1], 0, 0, 0);
+      }
     };
     // iteration c: raw(c+1) and U(c) have landed (issued two iterations ago), barrier, issue raw(c+3) and U(c+2)
     // into the stages everybody has just finished with, MFMAs of chunk c, transform of chunk c+1.  The wait
@@ -194,7 +215,9 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restr
     // hand-placed orders (sched_barrier fences) were all slower, 45.9-46.4 against 43.5-44.6 ms/step:
     // every LDS read right after the barrier with the transform between or after the MFMA groups, the
     // second k-step held back across the barrier, and the two waves of a SIMD in opposite phase order
-    // (profiles/README.md).
+    // (profiles/README.md).  A 4-wave form on 16 x 8 pixel patches (76 KB of LDS, two unsynchronised
+    // workgroups per CU covering each other's barrier waits, prologue and epilogue) measured the same:
+    // 43.4 against 43.0 ms/step.
     auto body = [&](int c, auto S, auto Sn, auto Snn) {
       asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
