@@ -217,7 +217,8 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restr
     // second k-step held back across the barrier, and the two waves of a SIMD in opposite phase order
     // (profiles/README.md).  A 4-wave form on 16 x 8 pixel patches (76 KB of LDS, two unsynchronised
     // workgroups per CU covering each other's barrier waits, prologue and epilogue) measured the same:
-    // 43.4 against 43.0 ms/step.
+    // 43.4 against 43.0 ms/step; so did 16 x 8 patches x 128 output channels per workgroup (half the
+    // transform and patch DMA per MFMA): 44.7 against 44.1.
     auto body = [&](int c, auto S, auto Sn, auto Snn) {
       asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
