@@ -247,10 +247,16 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restr
   issue_raw(2, S2{});
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // raw(0) (and U(0)) landed
   __builtin_amdgcn_s_barrier();
-  if (ph == 0)
+  if (ph == 0) {
     run(std::integral_constant<int, 0>{});
-  else
+  } else {
+    // the second-dispatched half of the workgroup loses every issue arbitration against its (older) SIMD
+    // partner; one static priority raise for the whole loop evens that out (MI355X_MICROARCH.md, two waves
+    // per SIMD, item 4)
+    __builtin_amdgcn_s_setprio(1);   // 42.8 against 42.95 ms/step
     run(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_s_setprio(0);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (out-of-range, zero) DMAs still write LDS
   __builtin_amdgcn_s_barrier();
 

@@ -10,7 +10,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // KIND 0: v_add_f32   1: v_exp_f32   2: ds_write_b32   3: ds_read_b32 (no wait)   4: v_fma_f32 dependent chain
 template <int NF, int KIND, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void fill_kernel(float* out, unsigned long long* cyc, int iters) {
+__global__ __launch_bounds__(WAVES * 64) void fill_kernel(float* out, unsigned long long* cyc, unsigned long long* span,
+                                                          int iters) {
   __shared__ float lds[WAVES * 64 * 4];
   f32x16 acc[4];
   for (int i = 0; i < 4; ++i)
@@ -44,6 +45,11 @@ __global__ __launch_bounds__(WAVES * 64) void fill_kernel(float* out, unsigned l
   for (int i = 0; i < 8; ++i) s += f[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s + lds[threadIdx.x];
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+  // end-to-end: from the first wave's start to the last wave's end of this workgroup (all waves of the CU)
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&span[blockIdx.x * 2], t0);
+    atomicMax(&span[blockIdx.x * 2 + 1], t1);
+  }
 }
 
 template <int NF, int KIND, int WAVES>
@@ -53,15 +59,26 @@ static void run(const char* name) {
   unsigned long long* cyc;
   hipMalloc((void**)&out, blocks * WAVES * 64 * 4);
   hipMalloc((void**)&cyc, blocks * 8);
-  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((fill_kernel<NF, KIND, WAVES>), dim3(blocks), dim3(WAVES * 64), 0, 0, out, cyc, iters);
+  unsigned long long* span;
+  hipMalloc((void**)&span, blocks * 16);
+  unsigned long long hs[512];
+  for (int i = 0; i < blocks; ++i) { hs[2 * i] = ~0ull; hs[2 * i + 1] = 0; }
+  hipLaunchKernelGGL((fill_kernel<NF, KIND, WAVES>), dim3(blocks), dim3(WAVES * 64), 0, 0, out, cyc, span, iters);
+  hipMemcpy(span, hs, sizeof(hs), hipMemcpyHostToDevice);
+  hipLaunchKernelGGL((fill_kernel<NF, KIND, WAVES>), dim3(blocks), dim3(WAVES * 64), 0, 0, out, cyc, span, iters);
   hipDeviceSynchronize();
   unsigned long long h[256];
   hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
   double sum = 0;
   for (int i = 0; i < blocks; ++i) sum += (double)h[i];
-  printf("%-14s NF=%2d waves/SIMD=%d : %.1f cycles per MFMA per wave\n", name, NF, WAVES / 4, sum / blocks / iters / 16);
+  hipMemcpy(hs, span, sizeof(hs), hipMemcpyDeviceToHost);
+  double sp = 0;
+  for (int i = 0; i < blocks; ++i) sp += (double)(hs[2 * i + 1] - hs[2 * i]);
+  printf("%-14s NF=%2d waves/SIMD=%d : %.1f cycles per MFMA (wave 0 alone), %.1f cycles of the SIMD per MFMA (all its waves)\n", name,
+         NF, WAVES / 4, sum / blocks / iters / 16, sp / blocks / iters / 16 / (WAVES / 4));
   hipFree(out);
   hipFree(cyc);
+  hipFree(span);
 }
 
 template <int KIND, int WAVES>
