@@ -153,6 +153,30 @@ def test_conv3x3_winograd_fused_matches_direct(lib, device, B, H, W, Cin, Cout, 
     assert torch.equal(y, y2)
 
 
+def test_conv3x3_winograd_fused_at_benchmark_size_is_repeatable(lib, device):
+    """The SR UNet's top level at the benchmark's batch (16 x 256 x 256 x 128 -> 128: 2048 workgroups, 8 rounds
+    per CU): repeated launches are bit-identical (no race between the DMA stages, the V stores and the
+    barriers shows up under full occupancy) and image 0 matches an fp64 convolution."""
+    E = _E()
+    B, H, W, Cin, Cout = 16, 256, 256, 128, 128
+    gd = torch.Generator(device=device).manual_seed(5)
+    x = torch.randn(B, H, W, Cin, device=device, generator=gd)
+    w = torch.randn(Cout, Cin, 3, 3, device=device, generator=gd) * (Cin * 9) ** -0.5
+    b = torch.randn(Cout, device=device, generator=gd)
+    y0 = torch.empty(B, H, W, Cout, device=device)
+    E.check(lib.kd_conv3x3_winograd_fused_nhwc(E.ptr(x), E.ptr(w), E.ptr(b), None, E.ptr(y0), B, H, W, Cin, Cout,
+                                               E.current_stream()))
+    y = torch.empty_like(y0)
+    for _ in range(8):
+        y.fill_(float("nan"))
+        E.check(lib.kd_conv3x3_winograd_fused_nhwc(E.ptr(x), E.ptr(w), E.ptr(b), None, E.ptr(y), B, H, W, Cin, Cout,
+                                                   E.current_stream()))
+        assert torch.equal(y, y0)
+    ref = F.conv2d(x[:1].permute(0, 3, 1, 2).cpu().double(), w.cpu().double(), b.cpu().double(), padding=1)
+    got = y0[:1].permute(0, 3, 1, 2).cpu().double()
+    assert float((got - ref).norm() / ref.norm()) <= WINO_REL
+
+
 def test_conv3x3_winograd_fused_rejects_unsupported_shapes(lib, device):
     E = _E()
     t = torch.zeros(16, device=device)
