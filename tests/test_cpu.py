@@ -254,3 +254,26 @@ def test_philox_host_reference_is_standard_normal_and_keyed():
     assert abs(a.mean()) < 0.02 and abs(a.std() - 1) < 0.02 and abs(np.mean(a * b)) < 0.02
     assert np.array_equal(a, philox_normal(1 << 16, 1, 2))
     assert np.array_equal(a[:1001], philox_normal(1001, 1, 2))  # prefix-stable
+
+
+def test_kernels_with_counted_vmcnt_waits_use_no_scratch(tmp_path):
+    """conv_buf_kernel and wino_fused_kernel pace their LDS-DMA pipelines with counted `s_waitcnt vmcnt(N)`.
+    A register spill would add scratch loads / stores to the same counter and let a barrier pass before the
+    DMA data has landed (seen once in an experiment: wrong results AND 3x slower).  hipcc reports spills
+    only on request, so ask: every kernel of the two files must have ScratchSize 0 and no spilled VGPRs."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    csrc = ROOT / "kidney-diffusion_amd" / "csrc"
+    for src in ("kernels_conv.hip", "kernels_wino_fused.hip"):
+        out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", str(csrc / src),
+                              f"-I{csrc}", f"-I{ROOT / 'include'}", "-Rpass-analysis=kernel-resource-usage",
+                              "-o", str(tmp_path / "x.o")], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+        spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", out.stderr)]
+        assert scratch and len(scratch) == len(spills), f"{src}: no resource-usage remarks"
+        assert not any(scratch) and not any(spills), f"{src}: scratch {scratch}, spills {spills}"
