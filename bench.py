@@ -397,6 +397,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
                          "issued": 2.0 * mfma_macs / (dev_ms_per_step * 1e-3) / 1e12,
+                         "frac_issued": 2.0 * mfma_macs / (dev_ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                          "kernel": "one denoising-step graph (UNet forward + x0/quantile/DDPM update); "
                                    f"{flop_per_step / 1e12:.3f} TFLOP algorithmic per launch (2 x "
                                    f"{macs / 1e9 / BATCH:.1f} GMAC/sample x {BATCH}, direct-convolution count of "
@@ -404,7 +405,10 @@ def main():
                                    f"MFMA peak.  'issued' = the {2.0 * mfma_macs / 1e12:.3f} TFLOP the conv/GEMM "
                                    "launches actually put on the matrix cores: the ResnetBlock 3x3 convs run as "
                                    "Winograd F(2x2,3x3) in fp32 (2.25x fewer MACs; batched GEMMs from Cin >= 256, one "
-                                   "fused kernel below), so 'achieved' can exceed what the MFMA pipe executes",
+                                   "fused kernel below), so 'achieved' (and 'frac') can exceed what the MFMA pipe executes; "
+                                   "'frac_issued' = issued / peak is the share of the matrix peak actually used "
+                                   "(profiles/r01_v8_sq_summary.json has the per-kernel pipe utilisation from "
+                                   "SQ_VALU_MFMA_BUSY_CYCLES)",
                          "kernels": kernels},
         }
         if world == 1 and not args.no_cpu_baseline:
