@@ -1,10 +1,11 @@
 // Attention core, GlobalContext pooling and the small-M ("skinny") linear layers.
 //
 // The attention core is < 2 % of the UNet's FLOPs (QK^T/AV 0.1-1.8 %),
-// its projections are GEMMs and run on the MFMA kernel in kernels_conv.hip.  The core here is
-// a flash-style single pass with fp32 online softmax on the vector ALU: one lane owns one
-// query row (q and the output row live in VGPRs), K/V tiles are staged in LDS and read as
-// wave-wide broadcasts.  Multi-query layout (one shared K/V head) is handled by
+// its projections are GEMMs and run on the MFMA kernel in kernels_conv.hip.  Two forms of the core,
+// both a flash-style single pass with fp32 online softmax over 64-key K/V tiles staged in LDS:
+// attention_mfma_kernel (launches that fill the chip) puts QK^T and PV on the fp32 matrix cores;
+// attention_kernel<KS> (small launches) keeps a query row in the VGPRs of KS adjacent lanes and reads
+// K/V as wave-wide broadcasts.  Multi-query layout (one shared K/V head) is handled by
 // Hkv = 1.
 #include "common.h"
 
@@ -148,18 +149,172 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------- attention on the matrix cores (D = 64)
+// Flash-style single pass with both contractions on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32
+// accumulation).  A wave owns 32 queries of one (batch, head); the block's 4 waves share 64-key K/V tiles in
+// LDS.  The scores are computed TRANSPOSED, S^T = K Q^T (A operand = K rows from LDS, B operand = the wave's
+// Q rows, held in registers for the whole pass): a lane of the 32x32 accumulator then holds 16 keys of ONE
+// query, so the online softmax is in-lane but for one shuffle with the lane that holds the query's other 16
+// keys, and the probabilities are already in the register layout the B operand of O^T += V^T P^T wants
+// (k-step r pairs the keys (r&3) + 8(r>>2) and that + 4, one per lane half) - P never leaves the registers.
+// O^T is transposed through LDS at the end for row-contiguous stores.
+constexpr int AM_LD = AT_D + 4;   // padded K/V rows (ds_read_b128 of 32 different keys: 4 banks apart)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const float* __restrict__ q, int ldq,
+                                                                const float* __restrict__ null_k,
+                                                                const float* __restrict__ null_v, KVSeg s0, KVSeg s1,
+                                                                float* __restrict__ out, int ldo, int Nq, int Hkv,
+                                                                float scale) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(16))) float KV[2 * AT_KT * AM_LD];   // K tile | V tile; the output tile at the end
+  float* Ks = KV;
+  float* Vs = KV + AT_KT * AM_LD;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int hk = Hkv == 1 ? 0 : h;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, khalf = lane >> 5;
+  const int qi = blockIdx.x * 128 + wave * 32 + n;
+
+  float qv[32];   // Q[qi][32 * khalf + j] * scale: the B operand of k-step j (dims j and j + 32)
+  if (qi < Nq) {
+    const float* qp = q + ((int64_t)b * Nq + qi) * ldq + h * AT_D + 32 * khalf;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+      f32x4 t = *(const f32x4*)(qp + d4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qv[d4 * 4 + e] = t[e] * scale;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) qv[j] = 0.f;
+  }
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+  float mrun = -INFINITY, lsum = 0.f;
+
+  const int n_null = null_k ? 1 : 0;
+  const int Nk = n_null + s0.n + s1.n;
+  for (int j0 = 0; j0 < Nk; j0 += AT_KT) {
+    const int nj = min(AT_KT, Nk - j0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < AT_KT * (AT_D / 4); idx += 256) {
+      int j = idx / (AT_D / 4), d4 = idx - j * (AT_D / 4);
+      f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};   // rows past the last key: zeros (their p is 0)
+      if (j < nj) {
+        int key = j0 + j;
+        const float *kp, *vp;
+        if (key < n_null) {
+          kp = null_k;
+          vp = null_v;
+        } else if (key < n_null + s0.n) {
+          int64_t r = (int64_t)b * s0.n + (key - n_null);
+          kp = s0.k + r * s0.ld + hk * AT_D;
+          vp = s0.v + r * s0.ld + hk * AT_D;
+        } else {
+          int64_t r = (int64_t)b * s1.n + (key - n_null - s0.n);
+          kp = s1.k + r * s1.ld + hk * AT_D;
+          vp = s1.v + r * s1.ld + hk * AT_D;
+        }
+        kk = *(const f32x4*)(kp + d4 * 4);
+        vv = *(const f32x4*)(vp + d4 * 4);
+      }
+      *(f32x4*)(Ks + j * AM_LD + d4 * 4) = kk;
+      *(f32x4*)(Vs + j * AM_LD + d4 * 4) = vv;
+    }
+    __syncthreads();
+
+    // S^T = K Q^T for the two 32-key halves of the tile
+    f32x16 st[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+      const float* kr = Ks + (kt * 32 + n) * AM_LD + 32 * khalf;
+#pragma unroll
+      for (int j4 = 0; j4 < 8; ++j4) {
+        const f32x4 kk = *(const f32x4*)(kr + j4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[e], qv[j4 * 4 + e], st[kt], 0, 0, 0);
+      }
+    }
+    // online softmax: this lane holds keys kt*32 + (r&3) + 8(r>>2) + 4*khalf of query n
+    if (nj < AT_KT) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf >= nj) st[kt][r] = -INFINITY;
+    }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[kt][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mnew = fmaxf(mrun, mloc);      // finite: every tile holds at least one key
+    const float corr = expf(mrun - mnew);      // exp(-inf) = 0 on the first tile
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[kt][r] = expf(st[kt][r] - mnew);
+        psum += st[kt][r];
+      }
+    lsum = lsum * corr + psum;
+    mrun = mnew;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0[r] *= corr;
+      o1[r] *= corr;
+    }
+    // O^T += V^T P^T: k-step r of half kt pairs the keys this lane half holds in register r
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* vr = Vs + (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * AM_LD + n;
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], st[kt][r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], st[kt][r], o1, 0, 0, 0);
+      }
+  }
+  const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32, 64));
+  __syncthreads();   // every wave is done with the last K/V tile
+  float* os = KV + (wave * 32 + n) * AM_LD;   // out tile [query][dim]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    os[d] = o0[r] * inv;
+    os[32 + d] = o1[r] * inv;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int ql = it * 4 + (lane >> 4), d4 = lane & 15;
+    const int qo = blockIdx.x * 128 + wave * 32 + ql;
+    if (qo < Nq)
+      *(f32x4*)(out + ((int64_t)b * Nq + qo) * ldo + h * AT_D + d4 * 4) =
+          *(const f32x4*)(KV + (wave * 32 + ql) * AM_LD + d4 * 4);
+  }
+#endif
+}
+
 int launch_attention(const float* q, int ldq, const float* null_k, const float* null_v, KVSeg s0, KVSeg s1,
                      float* out, int ldo, int B, int Nq, int H, int Hkv, float scale, hipStream_t s) {
   KD_REQUIRE(Hkv == 1 || Hkv == H, "attention: Hkv must be 1 (multi-query) or H");
   KD_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && (s0.n == 0 || s0.ld % 4 == 0) && (s1.n == 0 || s1.ld % 4 == 0),
              "attention: strides % 4");
   KD_REQUIRE((null_k ? 1 : 0) + s0.n + s1.n > 0 && Nq > 0, "attention: empty");
-  if ((int64_t)((Nq + 255) / 256) * H * B < 256) {  // would not fill the chip with one lane per query
+  if ((int64_t)((Nq + 127) / 128) * H * B >= 128) {  // enough 128-query blocks: both contractions on the matrix cores
+    hipLaunchKernelGGL(attention_mfma_kernel, dim3((Nq + 127) / 128, H, B), dim3(256), 0, s, q, ldq, null_k, null_v, s0,
+                       s1, out, ldo, Nq, Hkv, scale);
+  } else {  // small launches (batch-1 patches, the test shapes): 4 lanes per query on the vector ALU
     hipLaunchKernelGGL(attention_kernel<4>, dim3((Nq + 63) / 64, H, B), dim3(256), 0, s, q, ldq, null_k, null_v, s0, s1,
                        out, ldo, Nq, Hkv, scale);
-  } else {
-    hipLaunchKernelGGL(attention_kernel<1>, dim3((Nq + 255) / 256, H, B), dim3(256), 0, s, q, ldq, null_k, null_v, s0,
-                       s1, out, ldo, Nq, Hkv, scale);
   }
   KD_HIP_CHECK(hipGetLastError());
   return 0;

@@ -223,8 +223,12 @@ def test_layernorm(lib, device, rows, C, bias):
 @pytest.mark.parametrize("B,Nq,Nk,H,Hkv", [
     (2, 64, 69, 8, 1), (1, 300, 5, 8, 8), (2, 256, 261, 8, 1), (1, 1000, 1029, 4, 1),   # small grids: 4 lanes per query
     (1, 70, 3, 8, 1),                      # fewer keys than key splits (one split sees no key at all)
-    (16, 512, 517, 8, 1),                  # 256 workgroups: one lane per query
-    (33, 256, 261, 8, 8),                  # one lane per query, per-head K/V
+    # >= 128 blocks of 128 queries: both contractions on the matrix cores (attention_mfma_kernel)
+    (16, 512, 517, 8, 1),                  # multi-query, 5 keys in the last tile
+    (33, 256, 261, 8, 8),                  # per-head K/V
+    (16, 500, 517, 8, 1),                  # ragged query count (last wave half empty)
+    (8, 1024, 37, 8, 1),                   # fewer keys than one tile (cross-attention sized)
+    (4, 512, 128, 8, 1),                   # exactly two full tiles, exactly 128 blocks
 ])
 def test_attention(lib, device, B, Nq, Nk, H, Hkv):
     E = _E()

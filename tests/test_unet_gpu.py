@@ -29,6 +29,7 @@ def _inputs(name, B, S, lowres, seed=3):
     ("small1", False, 2, 16),
     ("small2", True, 2, 32),
     ("ultra1", False, 2, 32),     # train_ultra_res.py:29-36 at dim 32 (cond images, attention at 3 levels)
+    ("ultra1", False, 8, 64),     # same, 1024 / 256 / 64 tokens x 8 heads x 8: the matrix-core attention kernel
     ("ultra2", True, 3, 64),      # train_ultra_res.py:39-48 (memory efficient SR unet)  <- headline UNet
     ("ultra3", True, 1, 64),      # train_ultra_res.py:51-60 (blocks 2,4,6,8, no self-attention but mid)
     ("uncond1", False, 1, 32),    # train_uncond.py:30-36 (cond_dim 64 here)
