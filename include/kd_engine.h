@@ -215,6 +215,15 @@ int kd_conv3x3_winograd_nhwc(const float* d_x, const float* d_w_oihw, const floa
 int kd_conv3x3_winograd_fused_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias,
                                    const float* d_res, float* d_y, int B, int H, int W, int Cin,
                                    int Cout, void* stream);
+/* ResnetBlock `Block` in one pass over x: conv3x3(SiLU(FiLM(GroupNorm_G(x)))) + bias (+ d_res), the form the
+ * plan uses for those layers: statistics, a per-(image, channel) affine fold, and the fused Winograd kernel
+ * with the activation applied to the raw patch in LDS (the activated map is never written).  d_scale_shift
+ * ([B, 2 Cin] = [scale | shift]) and d_res may be NULL.  Shape rules of kd_conv3x3_winograd_fused_nhwc plus
+ * Cin <= 512, Cin % G == 0. */
+int kd_gn_conv3x3_winograd_fused_nhwc(const float* d_x, const float* d_gamma, const float* d_beta,
+                                      const float* d_scale_shift, const float* d_w_oihw,
+                                      const float* d_bias, const float* d_res, float* d_y, int B, int H,
+                                      int W, int Cin, int Cout, int G, float eps, void* stream);
 /* GroupNorm(G) + optional FiLM (scale+1, shift: [B,2C] = [scale | shift]) + SiLU, NHWC. */
 int kd_groupnorm_silu_nhwc(const float* d_x, const float* d_gamma, const float* d_beta,
                            const float* d_scale_shift, float* d_y, int B, int HW, int C, int G,

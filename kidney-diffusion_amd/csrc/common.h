@@ -99,6 +99,13 @@ int launch_wino_fused_pack(const float* w_oihw, float* U, int O, int I, hipStrea
 int launch_wino_fused(const float* x, const float* U, const float* bias, const float* res, int ldres, float* y, int B,
                       int H, int W, int C, int N, hipStream_t s);
 
+// The same with GroupNorm (+FiLM) + SiLU applied to x on the way in: ab = launch_gn_fold's per-(image, channel)
+// affine [B][C][2]; Cin <= 512.
+int launch_gn_fold(const float* stats, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
+                   float* ab, int B, int C, int G, hipStream_t s);
+int launch_wino_fused_gn(const float* x, const float* ab, const float* U, const float* bias, const float* res, int ldres,
+                         float* y, int B, int H, int W, int C, int N, hipStream_t s);
+
 // ---- norms / elementwise (kernels_norm.hip)
 int launch_gn_stats(const float* x, int ldx, float* stats /*[B][G][2] mean,rstd*/, double* partial,
                     int B, int HW, int C, int G, float eps, hipStream_t s);

@@ -666,6 +666,51 @@ struct Builder {
     return y;
   }
 
+  // The same layer straight from the un-normalised block input: GroupNorm statistics, the per-(image, channel)
+  // affine fold, and the fused kernel that applies GroupNorm / FiLM / SiLU to the raw patch in LDS
+  // (wino_fused_gn_kernel): the activated map is never written.  KD_FWINO_GN=0 keeps the separate
+  // gn_apply_silu pass (A/B, read per plan).
+  bool fwino_gn_ok(const T& x, int cout) const {
+    const bool on = !getenv("KD_FWINO_GN") || atoi(getenv("KD_FWINO_GN")) != 0;
+    return on && x.C <= 512 && x.C % cfg.resnet_groups == 0 && fwino_ok(x, cout);
+  }
+  T fwino_gn_conv(const T& x, const std::string& gn_prefix, int ss_col, const std::string& conv_prefix, int Cout,
+                  const T* res) {
+    const int Cin = x.C, G = cfg.resnet_groups, Bx = x.B, H = x.H, W = x.W, HW = x.HW();
+    const float* gamma = P(gn_prefix + ".weight", Cin);
+    const float* beta = P(gn_prefix + ".bias", Cin);
+    const float* bias = P(conv_prefix + ".bias", Cout);
+    const float* wsrc = raw(conv_prefix + ".weight", (int64_t)Cout * Cin * 9);
+    float* U = cached("winof:" + conv_prefix, (size_t)16 * Cout * Cin,
+                      [&](float* dst) { KD_THROW_IF(launch_wino_fused_pack(wsrc, dst, Cout, Cin, 0)); });
+    if (gn_partial_bytes(Bx, HW, Cin, G) > gn_partial_max) throw std::runtime_error("gn partial scratch too small");
+    T ab = alloc_bytes((size_t)Bx * Cin * 2 * sizeof(float));
+    T y = alloc(Bx, H, W, Cout);
+    kd_unet* uu = u;
+    {
+      size_t xo = x.off, so = gn_stats_t.off, po = gn_partial_t.off, sso = t_ss.off, abo = ab.off;
+      const int ld = tmlp_total;
+      emit([=](hipStream_t s) {
+        if (launch_gn_stats(uu->P(xo), Cin, uu->P(so), (double*)uu->P(po), Bx, HW, Cin, G, 1e-5f, s)) return 1;
+        const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
+        return launch_gn_fold(uu->P(so), gamma, beta, ssp, ld, uu->P(abo), Bx, Cin, G, s);
+      }, "gn stats HW" + std::to_string(HW) + " C" + std::to_string(Cin));
+    }
+    size_t xo = x.off, yo = y.off, ro = res ? res->off : 0, abo = ab.off;
+    const bool hr = res != nullptr;
+    const int ldres = res ? res->C : 0;
+    const int64_t m = (int64_t)Bx * H * W * Cout * Cin * 9;
+    emit([=](hipStream_t s) {
+      return launch_wino_fused_gn(uu->P(xo), uu->P(abo), U, bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W,
+                                  Cin, Cout, s);
+    }, "wino fused M" + std::to_string((int64_t)Bx * H * W) + " Cin" + std::to_string(Cin) + " Cout" +
+           std::to_string(Cout), m);
+    free(ab);
+    if (!to_text) u->macs += m;
+    if (!to_text && !to_static) u->mfma_macs += (int64_t)Bx * H * W * 4 * Cout * ((Cin / 4 + 3) / 4 * 16);
+    return y;
+  }
+
   // ResnetBlock.  Does NOT free x.
   T resnet(const T& x, const std::string& pre, int dim_out, const T* ctx, bool use_gca) {
     bool has_cross = has(pre + ".cross_attn.to_q.weight");
@@ -674,6 +719,8 @@ struct Builder {
     T h;
     if (wino_ok(x, dim_out)) {
       h = wino_block(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
+    } else if (fwino_gn_ok(x, dim_out)) {
+      h = fwino_gn_conv(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
     } else {
       T y1 = gn_silu(x, pre + ".block1.groupnorm", nullptr, 0);
       if (fwino_ok(y1, dim_out))
@@ -695,6 +742,10 @@ struct Builder {
     if (wino_ok(h, dim_out)) {
       h2 = wino_block(h, pre + ".block2.groupnorm", ss_col, pre + ".block2.project", dim_out,
                       (!use_gca && !has_res_conv) ? &x : nullptr);
+      free(h);
+    } else if (fwino_gn_ok(h, dim_out)) {
+      h2 = fwino_gn_conv(h, pre + ".block2.groupnorm", ss_col, pre + ".block2.project", dim_out,
+                         (!use_gca && !has_res_conv) ? &x : nullptr);
       free(h);
     } else {
       T y2;

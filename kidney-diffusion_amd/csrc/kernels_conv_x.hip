@@ -1503,6 +1503,18 @@ __global__ __launch_bounds__(512, 1) void conv_fwino2_kernel(const float* __rest
     issue_raw(c + 3, S);
     issue_u(c + 2, Snn);
     stampb(S, std::integral_constant<int, 2>{});
+    if constexpr (DBG == 5) {   // cost probe: activate 3 values per thread of another raw stage in place (wrong results)
+      float* ap = rawp(Snn) + tid;
+      const float fa = abl[0], fb = abl[1];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        if (i < 2 || tid < 272) {
+          float v = ap[i * 512] * fa + fb;
+          v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+          ap[i * 512] = (tid & 8) ? v : 0.f;
+        }
+      }
+    }
     float e[3][4];
     if constexpr (DBG == 3 || DBG == 4) {   // ablations: no transform at all / its VALU only (no LDS traffic)
 #pragma unroll
@@ -1670,7 +1682,7 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
   unsigned long long* fwdbg2 = nullptr;
   if (variant == 55 || variant == 56) { KD_HIP_CHECK(hipMalloc((void**)&fwdbg2, (64 + 2 * 8 * 18) * 8)); KD_HIP_CHECK(hipMemset(fwdbg2, 0, (64 + 2 * 8 * 18) * 8)); }
   if (variant == 53) { KD_HIP_CHECK(hipMalloc((void**)&fwdbg, 2 * 4 * 18 * 8)); KD_HIP_CHECK(hipMemset(fwdbg, 0, 2 * 4 * 18 * 8)); }
-  if (variant >= 50 && variant <= 58) {
+  if (variant >= 50 && variant <= 59) {
     KD_HIP_CHECK(hipMalloc((void**)&fwU, (size_t)16 * Cout * Cin * 4));
     KD_HIP_CHECK(hipMalloc((void**)&xs, nx * 4));
     hipLaunchKernelGGL(fw_pack_kernel, dim3((unsigned)(((int64_t)Cout * Cin + 255) / 256)), dim3(256), 0, 0, w, fwU, Cout, Cin);
@@ -1722,6 +1734,10 @@ extern "C" int kd_conv_bench(int B, int H, int W, int Cin, int Cout, int K, int 
         break;
       case 54:   // fused Winograd, 8 waves (2 per SIMD), pre-activated input
         hipLaunchKernelGGL(conv_fwino2_kernel<0>, dim3(B * (H / 16) * (W / 16) * (Cout / 64)), dim3(512), 0, 0, xs, fwU, bias, y,
+                           B, H, W, Cin, Cout, nullptr);
+        break;
+      case 59:   // cost probe: in-place SiLU(a x + b) of the next raw stage, 3 values per thread (wrong results)
+        hipLaunchKernelGGL(conv_fwino2_kernel<5>, dim3(B * (H / 16) * (W / 16) * (Cout / 64)), dim3(512), 0, 0, xs, fwU, bias, y,
                            B, H, W, Cin, Cout, nullptr);
         break;
       case 57:   // ablation: no input transform (wrong results)

@@ -309,6 +309,283 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restr
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same convolution with GroupNorm (+ FiLM) + SiLU applied ON THE WAY IN: x is the raw block input, ab
+// holds the per-(image, channel) affine the normalisation folds to (launch_gn_fold: y = SiLU(A x + B)).
+// The activated map is never written to HBM (gn_apply_silu moved 2 x the map per layer).
+//
+// The activation is applied once per patch pixel, not once per tile that uses it (a pixel is in up to 4
+// tiles): every thread activates 2-3 values of the raw patch in place in LDS, one pipeline stage before the
+// transform reads them, so the raw patch has 4 stages here (DMA lands -> activate -> transform), U has 4
+// (stage = chunk % 4, static indices as above) and V 3 with a run-time index (V is never a DMA target, so
+// hipcc needs no static index to keep its vmcnt waits away).  Cost probe (kd_conv_bench variant 59): the
+// 21 VALU + 6 LDS instructions per thread and chunk add 4 % to the kernel, the apply pass they replace was
+// 14 % of conv + apply.  Zero padding: the pixel's slot is known to be outside the image -> 0 after the
+// activation as well.
+constexpr int WG_MAXC = 512;   // channels of the affine table kept in LDS
+
+__global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __restrict__ x, const float* __restrict__ ab,
+                                                               const float* __restrict__ U,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ res, int ldres,
+                                                               float* __restrict__ y, int B, int H, int W, int C,
+                                                               int N) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(1024))) float raw_0[WF_RAW], raw_1[WF_RAW], raw_2[WF_RAW], raw_3[WF_RAW];
+  __shared__ __attribute__((aligned(1024))) float us_0[WF_UV], us_1[WF_UV], us_2[WF_UV], us_3[WF_UV];
+  __shared__ __attribute__((aligned(1024))) float vs[3 * WF_UV];
+  __shared__ __attribute__((aligned(16))) float abl[2 * WG_MAXC];
+  auto rawp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return raw_0; else if constexpr (decltype(S)::value == 1) return raw_1; else if constexpr (decltype(S)::value == 2) return raw_2; else return raw_3; };
+  auto usp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return us_0; else if constexpr (decltype(S)::value == 1) return us_1; else if constexpr (decltype(S)::value == 2) return us_2; else return us_3; };
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int pw = W / 16, ph_ = H / 16;
+  const int nh = N / 64;
+  const int npatch = B * pw * ph_;
+  int bpatch, nhalf;
+  if ((npatch & 7) == 0) {   // the N/64 workgroups of one patch back to back on ONE XCD
+    const int id = blockIdx.x;
+    bpatch = (id / (8 * nh)) * 8 + (id & 7);
+    nhalf = (id >> 3) % nh;
+  } else {
+    bpatch = blockIdx.x / nh;
+    nhalf = blockIdx.x % nh;
+  }
+  const int b = bpatch / (pw * ph_);
+  const int prem = bpatch - b * pw * ph_;
+  const int y0 = (prem / pw) * 16, x0 = (prem % pw) * 16;
+  const int n0 = nhalf * 64;
+  const int nchunks = C / WF_K;
+
+  // the affine table of this image (C <= 512 pairs): loaded before the DMAs are issued, stored after
+  float2 abv = make_float2(0.f, 0.f);
+  if (tid < C) abv = ((const float2*)ab)[(int64_t)b * C + tid];
+
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)b * H * W * C), 0,
+                                                                       (int)((int64_t)H * W * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU =
+      __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, (int)((int64_t)16 * N * C * 4), 0x00020000);
+
+  // patch slot -> pixel (columns permuted as in wino_fused_kernel); in_image(slot) also tells the activation
+  // which of its values are padding
+  auto slot_pixel = [&](int slot, int& iy, int& ix) {
+    int py = slot / 18, pq = slot - py * 18;
+    int px = pq < 9 ? 2 * pq : 2 * (pq - 9) + 1;
+    iy = y0 - 1 + py;
+    ix = x0 - 1 + px;
+    return slot < 324 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+  };
+  uint32_t voffX;
+  {
+    int iy, ix;
+    const bool ok = slot_pixel(tid, iy, ix);
+    voffX = ok ? (uint32_t)(((iy * W + ix) * C) * 4) : OOB_OFF;
+  }
+  // activation: values tid, tid + 512, tid + 1024 of the 324 x 4 patch floats; channel tid & 3, slots (tid >> 2) + 128 i
+  bool aok[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int iy, ix;
+    aok[i] = slot_pixel((tid >> 2) + 128 * i, iy, ix);
+  }
+  auto issue_raw = [&](int chunk, auto S) {
+    __attribute__((address_space(3))) float* rb = (__attribute__((address_space(3))) float*)(rawp(S) + wave * 256);
+    const uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t)(chunk * WF_K * 4));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, rb, 16, chunk < nchunks ? voffX : OOB_OFF, sx, 0, 0);
+  };
+  auto issue_u = [&](int chunk, auto S) {
+    __attribute__((address_space(3))) float* ub = (__attribute__((address_space(3))) float*)(usp(S) + wave * 256);
+    const uint32_t su = __builtin_amdgcn_readfirstlane((uint32_t)(((nhalf * nchunks + chunk) * WF_UV) * 4));
+    const bool live = chunk < nchunks;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, ub + q * 2048, 16, live ? (uint32_t)((q * 512 + tid) * 16) : OOB_OFF, su,
+                                               0, 0);
+  };
+  auto activate = [&](int chunk, auto S) {
+    const int cc = min(chunk, nchunks - 1) * WF_K + (tid & 3);
+    const float2 a2 = *(const float2*)(abl + 2 * cc);
+    float* ap = rawp(S) + tid;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i < 2 || tid < 324 * 4 - 1024) {
+        float v = ap[i * 512] * a2.x + a2.y;
+        v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));   // SiLU, hardware exp2 / reciprocal (about 1 ulp each)
+        ap[i * 512] = aok[i] ? v : 0.f;
+      }
+    }
+  };
+  const int t8 = tid & 255;
+  const int tc = t8 & 3, ttx = (t8 >> 2) & 7, tty = t8 >> 5;
+  const int tt = tty * 8 + ttx;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  const int frow = lane & 31, khalf = lane >> 5;
+  const int aoff = (int)wf_uv_index(0, ph * 8, wm * 32 + frow, khalf * 2);
+  const int boff = (int)wf_uv_index(0, ph * 8, wn * 32 + frow, khalf * 2);
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  using S3 = std::integral_constant<int, 3>;
+  auto run = [&](auto HB) {
+    constexpr int hb = decltype(HB)::value;
+    const int roff = ((2 * tty + hb) * 18 + ttx) * 4 + tc;
+    const int voffA = (int)wf_uv_index(0, (hb ? 3 : 0) * 4, tt, tc);
+    const int voffB = (int)wf_uv_index(0, (hb ? 2 : 1) * 4, tt, tc);
+    constexpr int VJ[4] = {0, 2, 2 * 64 * 4, 2 * 64 * 4 + 2};
+    constexpr int RS[4] = {0, 9, 1, 10};
+    auto load_raw = [&](auto S, float (&e)[3][4]) {
+      const float* rp = rawp(S) + roff;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) e[i][s] = rp[(i * 18 + RS[s]) * 4];
+    };
+    auto write_v = [&](float* vst, const float (&e)[3][4]) {
+      float ua[4], ub[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        ua[s] = e[0][s] - e[2][s];
+        ub[s] = hb ? e[1][s] - e[0][s] : e[1][s] + e[2][s];
+      }
+      float* va = vst + voffA;
+      float* vb = vst + voffB;
+      va[VJ[0]] = ua[0] - ua[2];
+      va[VJ[1]] = ua[1] + ua[2];
+      va[VJ[2]] = ua[2] - ua[1];
+      va[VJ[3]] = ua[1] - ua[3];
+      vb[VJ[0]] = ub[0] - ub[2];
+      vb[VJ[1]] = ub[1] + ub[2];
+      vb[VJ[2]] = ub[2] - ub[1];
+      vb[VJ[3]] = ub[1] - ub[3];
+    };
+    auto mfmas = [&](auto S, const float* vst) {
+      const float* va = vst + aoff;
+      const float* ub = usp(S) + boff;
+      float4 a4[4], b4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a4[i] = *(const float4*)(va + i * 2 * 64 * 4);
+        b4[i] = *(const float4*)(ub + i * 2 * 64 * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[i].x, acc[2 * i], 0, 0, 0);
+        acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[i].z, acc[2 * i + 1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[i].y, acc[2 * i], 0, 0, 0);
+        acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[i].w, acc[2 * i + 1], 0, 0, 0);
+      }
+    };
+    // iteration c (stages of chunk j: raw j % 4, U j % 4, V j % 3): raw(c+2) and U(c) have landed (issued two
+    // iterations ago), barrier, issue raw(c+4) and U(c+2), activate raw(c+2), MFMAs of chunk c, transform of
+    // raw(c+1) (activated one iteration ago) into V(c+1)
+    int vcur = 0;   // V stage of chunk c
+    auto body = [&](int c, auto Sc, auto Sc1, auto Sc2) {
+      asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_raw(c + 4, Sc);
+      issue_u(c + 2, Sc2);
+      const int vnext = vcur == 2 ? 0 : vcur + 1;
+      float e[3][4];
+      load_raw(Sc1, e);
+      mfmas(Sc, vs + vcur * WF_UV);
+      activate(c + 2, Sc2);
+      write_v(vs + vnext * WF_UV, e);
+      vcur = vnext;
+    };
+    {
+      float e[3][4];
+      load_raw(S0{}, e);
+      write_v(vs, e);
+    }
+    for (int c = 0; c < nchunks; c += 4) {
+      body(c, S0{}, S1{}, S2{});
+      body(c + 1, S1{}, S2{}, S3{});
+      body(c + 2, S2{}, S3{}, S0{});
+      body(c + 3, S3{}, S0{}, S1{});
+    }
+  };
+  // prologue: the first five pieces stand in for "two iterations ago", the last three for "one iteration ago"
+  issue_raw(0, S0{});
+  issue_u(0, S0{});
+  issue_raw(1, S1{});
+  issue_raw(2, S2{});
+  issue_raw(3, S3{});
+  issue_u(1, S1{});
+  if (tid < C) *(float2*)(abl + 2 * tid) = abv;
+  asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // raw(0), U(0), raw(1) landed
+  __builtin_amdgcn_s_barrier();
+  activate(0, S0{});
+  activate(1, S1{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (ph == 0) {
+    run(std::integral_constant<int, 0>{});
+  } else {
+    __builtin_amdgcn_s_setprio(1);
+    run(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_s_setprio(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const int pair = wm * 2 + wn;
+  float4* ex = (float4*)(pair < 3 ? vs + pair * WF_UV : us_0);
+  float4 part[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float q0[4], q1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (ph == 0) {
+        q0[s] = acc[s][r] + acc[4 + s][r];
+        q1[s] = acc[4 + s][r];
+      } else {
+        q0[s] = acc[s][r];
+        q1[s] = -acc[s][r] - acc[4 + s][r];
+      }
+    }
+    part[r] = make_float4(q0[0] + q0[1] + q0[2], q0[1] - q0[2] - q0[3], q1[0] + q1[1] + q1[2], q1[1] - q1[2] - q1[3]);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if ((r >> 3) != ph) ex[(ph * 8 + (r & 7)) * 64 + lane] = part[r];
+  __syncthreads();
+  const int n = n0 + wn * 32 + (lane & 31);
+  const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if ((r >> 3) != ph) continue;
+    const float4 o = ex[((1 - ph) * 8 + (r & 7)) * 64 + lane];
+    const int t = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int ty = t >> 3, tx = t & 7;
+    const int64_t pix = ((int64_t)b * H + y0 + 2 * ty) * W + x0 + 2 * tx;
+    float o00 = part[r].x + o.x + bv, o01 = part[r].y + o.y + bv, o10 = part[r].z + o.z + bv,
+          o11 = part[r].w + o.w + bv;
+    if (res) {
+      o00 += res[pix * ldres + n];
+      o01 += res[(pix + 1) * ldres + n];
+      o10 += res[(pix + W) * ldres + n];
+      o11 += res[(pix + W + 1) * ldres + n];
+    }
+    y[pix * N + n] = o00;
+    y[(pix + 1) * N + n] = o01;
+    y[(pix + W) * N + n] = o10;
+    y[(pix + W + 1) * N + n] = o11;
+  }
+#endif
+}
+
 bool wino_fused_ok(int B, int H, int W, int C, int N) {
   return B > 0 && H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0 && C >= WF_K && C % WF_K == 0 && N >= 64 &&
          N % 64 == 0 && (int64_t)H * W * C * 4 < 0x7fffffff && (int64_t)16 * N * C * 4 < 0x7fffffff &&
@@ -329,6 +606,47 @@ int launch_wino_fused(const float* x, const float* U, const float* bias, const f
              "fused Winograd conv needs H, W % 16 == 0, Cin % 4 == 0, Cout % 64 == 0 and maps below 2 GB per image");
   const unsigned grid = (unsigned)((int64_t)B * (H / 16) * (W / 16) * (N / 64));
   hipLaunchKernelGGL(wino_fused_kernel, dim3(grid), dim3(512), 0, s, x, U, bias, res, ldres, y, B, H, W, C, N);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ab[b][c] = (A, B) with GroupNorm(+FiLM)(x)[b][c] = A x + B (same arithmetic as gn_apply_silu_kernel)
+__global__ __launch_bounds__(256) void gn_fold_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      const float* __restrict__ scale_shift, int ld_ss,
+                                                      float* __restrict__ ab, int B, int C, int G) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * C) return;
+  const int b = idx / C, c = idx - b * C;
+  const int g = c / (C / G);
+  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+  float a = rstd * gamma[c];
+  float bb = beta[c] - mean * a;
+  if (scale_shift) {
+    const float sc = scale_shift[(int64_t)b * ld_ss + c] + 1.0f;
+    const float sh = scale_shift[(int64_t)b * ld_ss + C + c];
+    a *= sc;
+    bb = bb * sc + sh;
+  }
+  ab[2 * idx] = a;
+  ab[2 * idx + 1] = bb;
+}
+
+int launch_gn_fold(const float* stats, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
+                   float* ab, int B, int C, int G, hipStream_t s) {
+  KD_REQUIRE(C % G == 0, "gn_fold: C % G");
+  hipLaunchKernelGGL(gn_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, stats, gamma, beta, scale_shift, ld_ss, ab,
+                     B, C, G);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_wino_fused_gn(const float* x, const float* ab, const float* U, const float* bias, const float* res, int ldres,
+                         float* y, int B, int H, int W, int C, int N, hipStream_t s) {
+  KD_REQUIRE(wino_fused_ok(B, H, W, C, N) && C <= WG_MAXC,
+             "GroupNorm-fused Winograd conv needs H, W % 16 == 0, Cin % 4 == 0, Cin <= 512, Cout % 64 == 0");
+  const unsigned grid = (unsigned)((int64_t)B * (H / 16) * (W / 16) * (N / 64));
+  hipLaunchKernelGGL(wino_fused_gn_kernel, dim3(grid), dim3(512), 0, s, x, ab, U, bias, res, ldres, y, B, H, W, C, N);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -153,6 +153,49 @@ def test_conv3x3_winograd_fused_matches_direct(lib, device, B, H, W, Cin, Cout, 
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,G,film,res", [
+    (2, 64, 64, 128, 128, 8, True, False),    # FiLM, 32 chunks (a multiple of the 4 pipeline stages)
+    (1, 16, 16, 128, 64, 8, False, True),     # one patch: every side is padding (must stay 0 after the activation)
+    (3, 32, 48, 40, 192, 2, True, True),      # 10 chunks (padded to 12), 3 channel slabs, H != W
+    (1, 48, 16, 8, 64, 2, False, False),      # 2 chunks
+    (2, 32, 32, 512, 128, 8, True, False),    # the largest affine table (512 channels)
+])
+def test_gn_conv3x3_winograd_fused_matches_torch(lib, device, B, H, W, Cin, Cout, G, film, res):
+    """ResnetBlock `Block` = conv3x3(SiLU(FiLM(GroupNorm(x)))) with the activation applied to the raw patch in
+    LDS inside the fused Winograd kernel (hardware exp2 / reciprocal: ~1 ulp each)."""
+    E = _E()
+    x = torch.randn(B, Cin, H, W, generator=g(1)) * 1.5 + 0.3
+    gamma = 1 + 0.2 * torch.randn(Cin, generator=g(5))
+    beta = 0.2 * torch.randn(Cin, generator=g(6))
+    ss = 0.3 * torch.randn(B, 2 * Cin, generator=g(7)) if film else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g(2)) * (Cin * 9) ** -0.5
+    b = torch.randn(Cout, generator=g(3))
+    r = torch.randn(B, Cout, H, W, generator=g(4)) if res else None
+    h = F.group_norm(x.double(), G, gamma.double(), beta.double(), eps=1e-5)
+    if film:
+        h = h * (ss[:, :Cin, None, None].double() + 1) + ss[:, Cin:, None, None].double()
+    ref = F.conv2d(F.silu(h), w.double(), b.double(), padding=1)
+    if res:
+        ref = ref + r.double()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(device)
+    gd, bed, wd, bd = gamma.to(device), beta.to(device), w.to(device), b.to(device)
+    ssd = ss.to(device) if film else None
+    rd = r.permute(0, 2, 3, 1).contiguous().to(device) if res else None
+    y = torch.full((B, H, W, Cout), float("nan"), device=device)
+    call = lambda out: E.check(lib.kd_gn_conv3x3_winograd_fused_nhwc(
+        E.ptr(xd), E.ptr(gd), E.ptr(bed), E.ptr(ssd) if film else None, E.ptr(wd), E.ptr(bd),
+        E.ptr(rd) if res else None, E.ptr(out), B, H, W, Cin, Cout, G, 1e-5, E.current_stream()))
+    call(y)
+    got = y.permute(0, 3, 1, 2).cpu().double()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).norm() / ref.norm())
+    assert err <= WINO_REL, err
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), "element-wise outlier"
+    y2 = torch.empty_like(y)
+    call(y2)
+    assert torch.equal(y, y2)
+
+
 def test_conv3x3_winograd_fused_at_benchmark_size_is_repeatable(lib, device):
     """The SR UNet's top level at the benchmark's batch (16 x 256 x 256 x 128 -> 128: 2048 workgroups, 8 rounds
     per CU): repeated launches are bit-identical (no race between the DMA stages, the V stores and the
