@@ -223,7 +223,11 @@ int kd_conv3x3_winograd_fused_nhwc(const float* d_x, const float* d_w_oihw, cons
 int kd_gn_conv3x3_winograd_fused_nhwc(const float* d_x, const float* d_gamma, const float* d_beta,
                                       const float* d_scale_shift, const float* d_w_oihw,
                                       const float* d_bias, const float* d_res, float* d_y, int B, int H,
-                                      int W, int Cin, int Cout, int G, float eps, void* stream);
+                                      int W, int Cin, int Cout, int G, float eps, float* d_out_stats,
+                                      void* stream);
+/* (d_out_stats, may be NULL: [B, G, 2] = (mean, rstd) of y per image and group of Cout / G channels, reduced
+ * from the partial sums the kernel's epilogue leaves for the GroupNorm of the next layer; needs
+ * (Cout / G) % 16 == 0.) */
 /* GroupNorm(G) + optional FiLM (scale+1, shift: [B,2C] = [scale | shift]) + SiLU, NHWC. */
 int kd_groupnorm_silu_nhwc(const float* d_x, const float* d_gamma, const float* d_beta,
                            const float* d_scale_shift, float* d_y, int B, int HW, int C, int G,

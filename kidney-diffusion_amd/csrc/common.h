@@ -103,8 +103,15 @@ int launch_wino_fused(const float* x, const float* U, const float* bias, const f
 // affine [B][C][2]; Cin <= 512.
 int launch_gn_fold(const float* stats, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
                    float* ab, int B, int C, int G, hipStream_t s);
+// out_partial != nullptr: the kernel also leaves (sum, sum of squares) partials of y per (image, group of
+// out_groups) in launch_gn_finalize's layout, wino_fused_out_stats_chunks(H, W, N, G) entries per (image, group)
 int launch_wino_fused_gn(const float* x, const float* ab, const float* U, const float* bias, const float* res, int ldres,
-                         float* y, int B, int H, int W, int C, int N, hipStream_t s);
+                         float* y, int B, int H, int W, int C, int N, double* out_partial, int out_groups,
+                         hipStream_t s);
+size_t wino_fused_out_stats_chunks(int H, int W, int N, int G);
+// stats[b][g] = (mean, rstd) from `chunks` (sum, sum of squares) partials per (b, g), summed in index order
+int launch_gn_finalize(const double* partial, float* stats, int chunks, int B, int G, double count, float eps,
+                       hipStream_t s);
 
 // ---- norms / elementwise (kernels_norm.hip)
 int launch_gn_stats(const float* x, int ldx, float* stats /*[B][G][2] mean,rstd*/, double* partial,

@@ -674,8 +674,14 @@ struct Builder {
     const bool on = !getenv("KD_FWINO_GN") || atoi(getenv("KD_FWINO_GN")) != 0;
     return on && x.C <= 512 && x.C % cfg.resnet_groups == 0 && fwino_ok(x, cout);
   }
+  // stats_in: (sum, sum of squares) partials of x left by the kernel that produced it (then no statistics pass
+  // over x); stats_out: leave such partials of y for the next layer (fwino_stats_bytes)
+  size_t fwino_stats_bytes(const T& y) const {
+    return (size_t)y.B * cfg.resnet_groups * wino_fused_out_stats_chunks(y.H, y.W, y.C, cfg.resnet_groups) * 2 *
+           sizeof(double);
+  }
   T fwino_gn_conv(const T& x, const std::string& gn_prefix, int ss_col, const std::string& conv_prefix, int Cout,
-                  const T* res) {
+                  const T* res, const T* stats_in = nullptr, const T* stats_out = nullptr) {
     const int Cin = x.C, G = cfg.resnet_groups, Bx = x.B, H = x.H, W = x.W, HW = x.HW();
     const float* gamma = P(gn_prefix + ".weight", Cin);
     const float* beta = P(gn_prefix + ".bias", Cin);
@@ -690,19 +696,29 @@ struct Builder {
     {
       size_t xo = x.off, so = gn_stats_t.off, po = gn_partial_t.off, sso = t_ss.off, abo = ab.off;
       const int ld = tmlp_total;
+      const bool have = stats_in != nullptr;
+      const size_t pin = have ? stats_in->off : 0;
+      const int chunks_in = have ? (int)wino_fused_out_stats_chunks(H, W, Cin, G) : 0;
       emit([=](hipStream_t s) {
-        if (launch_gn_stats(uu->P(xo), Cin, uu->P(so), (double*)uu->P(po), Bx, HW, Cin, G, 1e-5f, s)) return 1;
+        if (have) {
+          if (launch_gn_finalize((const double*)uu->P(pin), uu->P(so), chunks_in, Bx, G, (double)HW * (Cin / G), 1e-5f, s))
+            return 1;
+        } else if (launch_gn_stats(uu->P(xo), Cin, uu->P(so), (double*)uu->P(po), Bx, HW, Cin, G, 1e-5f, s)) {
+          return 1;
+        }
         const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
         return launch_gn_fold(uu->P(so), gamma, beta, ssp, ld, uu->P(abo), Bx, Cin, G, s);
-      }, "gn stats HW" + std::to_string(HW) + " C" + std::to_string(Cin));
+      }, std::string(have ? "gn fold HW" : "gn stats HW") + std::to_string(HW) + " C" + std::to_string(Cin));
     }
     size_t xo = x.off, yo = y.off, ro = res ? res->off : 0, abo = ab.off;
     const bool hr = res != nullptr;
     const int ldres = res ? res->C : 0;
     const int64_t m = (int64_t)Bx * H * W * Cout * Cin * 9;
+    const bool so_ = stats_out != nullptr;
+    const size_t pout = so_ ? stats_out->off : 0;
     emit([=](hipStream_t s) {
       return launch_wino_fused_gn(uu->P(xo), uu->P(abo), U, bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W,
-                                  Cin, Cout, s);
+                                  Cin, Cout, so_ ? (double*)uu->P(pout) : nullptr, so_ ? G : 0, s);
     }, "wino fused M" + std::to_string((int64_t)Bx * H * W) + " Cin" + std::to_string(Cin) + " Cout" +
            std::to_string(Cout), m);
     free(ab);
@@ -716,11 +732,22 @@ struct Builder {
     bool has_cross = has(pre + ".cross_attn.to_q.weight");
     if (has_cross && !ctx) throw std::runtime_error("cross-attention block without conditioning tokens: " + pre);
     int dim_in = x.C;
-    T h;
+    T h, h_stats;
+    bool have_h_stats = false;
     if (wino_ok(x, dim_out)) {
       h = wino_block(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
     } else if (fwino_gn_ok(x, dim_out)) {
-      h = fwino_gn_conv(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
+      // block2's GroupNorm reads exactly this conv's output (no cross-attention in between): the conv leaves
+      // the statistics partials in its epilogue
+      T probe = x;
+      probe.C = dim_out;
+      if (!has_cross && (dim_out / cfg.resnet_groups) % 16 == 0 && fwino_gn_ok(probe, dim_out) &&
+          !(getenv("KD_FWINO_STATS") && atoi(getenv("KD_FWINO_STATS")) == 0)) {
+        h_stats = alloc_bytes(fwino_stats_bytes(probe));
+        have_h_stats = true;
+      }
+      h = fwino_gn_conv(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr, nullptr,
+                        have_h_stats ? &h_stats : nullptr);
     } else {
       T y1 = gn_silu(x, pre + ".block1.groupnorm", nullptr, 0);
       if (fwino_ok(y1, dim_out))
@@ -745,8 +772,12 @@ struct Builder {
       free(h);
     } else if (fwino_gn_ok(h, dim_out)) {
       h2 = fwino_gn_conv(h, pre + ".block2.groupnorm", ss_col, pre + ".block2.project", dim_out,
-                         (!use_gca && !has_res_conv) ? &x : nullptr);
+                         (!use_gca && !has_res_conv) ? &x : nullptr, have_h_stats ? &h_stats : nullptr);
       free(h);
+      if (have_h_stats) {
+        free(h_stats);
+        have_h_stats = false;
+      }
     } else {
       T y2;
       // scale/shift rows live in t_ss at column ss_col (row stride tmlp_total)
@@ -772,6 +803,7 @@ struct Builder {
                   P(pre + ".block2.project.bias", dim_out), dim_out, 3, 1, 1, o2);
       free(y2);
     }
+    if (have_h_stats) free(h_stats);   // (only if block2 did not take the fused path after all)
     if (!use_gca && !has_res_conv) return h2;
     T out;
     if (use_gca) {

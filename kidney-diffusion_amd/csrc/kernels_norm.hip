@@ -110,6 +110,49 @@ int launch_gn_stats(const float* x, int ldx, float* stats, double* partial, int 
   return 0;
 }
 
+// many partials per (b, g) (the fused conv's epilogue leaves one per workgroup wave): one workgroup per (b, g),
+// thread t sums entries t, t + 256, ... and the 256 sums are folded pairwise - a fixed order either way
+__global__ __launch_bounds__(256) void gn_finalize_wide_kernel(const double* __restrict__ partial, float* __restrict__ stats,
+                                                               int chunks, double count, float eps) {
+  __shared__ double sh[2][256];
+  const int i = blockIdx.x, t = threadIdx.x;
+  double s = 0.0, ss = 0.0;
+  for (int c = t; c < chunks; c += 256) {
+    s += partial[((int64_t)i * chunks + c) * 2];
+    ss += partial[((int64_t)i * chunks + c) * 2 + 1];
+  }
+  sh[0][t] = s;
+  sh[1][t] = ss;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) {
+      sh[0][t] += sh[0][t + w];
+      sh[1][t] += sh[1][t + w];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const double mean = sh[0][0] / count;
+    double var = sh[1][0] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[i * 2] = (float)mean;
+    stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+int launch_gn_finalize(const double* partial, float* stats, int chunks, int B, int G, double count, float eps,
+                       hipStream_t s) {
+  const int BG = B * G;
+  if (chunks >= 64) {
+    hipLaunchKernelGGL(gn_finalize_wide_kernel, dim3(BG), dim3(256), 0, s, partial, stats, chunks, count, eps);
+    KD_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((BG + 63) / 64), dim3(64), 0, s, partial, stats, chunks, BG, count, eps);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------- GroupNorm apply
 // y = silu( ((x-mean)*rstd*gamma + beta) * (scale+1) + shift ), folded to silu(x*A + Bc) per (b,c).
 constexpr int GA_ROWS_PER_BLOCK = 64;  // upper bound; small maps use fewer rows per workgroup (see launch)

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ res, int ldres,
                                                                float* __restrict__ y, int B, int H, int W, int C,
-                                                               int N) {
+                                                               int N, double* __restrict__ opart, int oG) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(1024))) float raw_0[WF_RAW], raw_1[WF_RAW], raw_2[WF_RAW], raw_3[WF_RAW];
   __shared__ __attribute__((aligned(1024))) float us_0[WF_UV], us_1[WF_UV], us_2[WF_UV], us_3[WF_UV];
@@ -563,6 +563,7 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
   __syncthreads();
   const int n = n0 + wn * 32 + (lane & 31);
   const float bv = bias ? bias[n] : 0.f;
+  double gs1 = 0.0, gs2 = 0.0;   // sum and sum of squares of this lane's outputs (GroupNorm of the NEXT layer)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     if ((r >> 3) != ph) continue;
@@ -582,6 +583,33 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
     y[(pix + 1) * N + n] = o01;
     y[(pix + W) * N + n] = o10;
     y[(pix + W + 1) * N + n] = o11;
+    if (opart) {
+      gs1 += ((double)o00 + (double)o01) + ((double)o10 + (double)o11);
+      gs2 += ((double)o00 * o00 + (double)o01 * o01) + ((double)o10 * o10 + (double)o11 * o11);
+    }
+  }
+  // GroupNorm statistics of y for the layer that reads it: one (sum, sum of squares) per wave and 16-channel
+  // segment, in the layout gn_finalize_kernel sums in a fixed order - that layer's statistics pass over y
+  // (a full read of the map) is not needed.  Groups are multiples of 16 channels (host check).
+  if (opart) {
+#pragma unroll
+    for (int off = 1; off <= 8; off <<= 1) {
+      gs1 += __shfl_xor(gs1, off, 64);
+      gs2 += __shfl_xor(gs2, off, 64);
+    }
+    gs1 += __shfl_xor(gs1, 32, 64);
+    gs2 += __shfl_xor(gs2, 32, 64);
+    if ((lane & 47) == 0 || (lane & 47) == 16) {   // lanes 0 and 16: channel segments 0 and 1 of this wave
+      const int Cg = N / oG;
+      const int cabs = n0 + wn * 32 + (lane & 16);
+      const int g = cabs / Cg, cseg = (cabs - g * Cg) >> 4;
+      const int npi = pw * ph_;
+      const int64_t chunks = (int64_t)(Cg >> 4) * npi * 4;
+      const int64_t entry = ((int64_t)cseg * npi + prem) * 4 + (wm * 2 + ph);
+      double* op = opart + (((int64_t)b * oG + g) * chunks + entry) * 2;
+      op[0] = gs1;
+      op[1] = gs2;
+    }
   }
 #endif
 }
@@ -641,12 +669,20 @@ int launch_gn_fold(const float* stats, const float* gamma, const float* beta, co
   return 0;
 }
 
+size_t wino_fused_out_stats_chunks(int H, int W, int N, int G) {
+  return (size_t)(N / G / 16) * (H / 16) * (W / 16) * 4;
+}
+
 int launch_wino_fused_gn(const float* x, const float* ab, const float* U, const float* bias, const float* res, int ldres,
-                         float* y, int B, int H, int W, int C, int N, hipStream_t s) {
+                         float* y, int B, int H, int W, int C, int N, double* out_partial, int out_groups,
+                         hipStream_t s) {
   KD_REQUIRE(wino_fused_ok(B, H, W, C, N) && C <= WG_MAXC,
              "GroupNorm-fused Winograd conv needs H, W % 16 == 0, Cin % 4 == 0, Cin <= 512, Cout % 64 == 0");
+  KD_REQUIRE(!out_partial || (out_groups > 0 && N % out_groups == 0 && (N / out_groups) % 16 == 0),
+             "output statistics need groups of a multiple of 16 channels");
   const unsigned grid = (unsigned)((int64_t)B * (H / 16) * (W / 16) * (N / 64));
-  hipLaunchKernelGGL(wino_fused_gn_kernel, dim3(grid), dim3(512), 0, s, x, ab, U, bias, res, ldres, y, B, H, W, C, N);
+  hipLaunchKernelGGL(wino_fused_gn_kernel, dim3(grid), dim3(512), 0, s, x, ab, U, bias, res, ldres, y, B, H, W, C, N,
+                     out_partial, out_groups);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -182,10 +182,21 @@ def test_gn_conv3x3_winograd_fused_matches_torch(lib, device, B, H, W, Cin, Cout
     ssd = ss.to(device) if film else None
     rd = r.permute(0, 2, 3, 1).contiguous().to(device) if res else None
     y = torch.full((B, H, W, Cout), float("nan"), device=device)
+    # the epilogue also leaves GroupNorm statistics of y (for the next layer) where its groups are 16-channel multiples
+    Go = 8 if (Cout // 8) % 16 == 0 else 0
+    ostats = torch.full((B, max(Go, 1), 2), float("nan"), device=device)
     call = lambda out: E.check(lib.kd_gn_conv3x3_winograd_fused_nhwc(
         E.ptr(xd), E.ptr(gd), E.ptr(bed), E.ptr(ssd) if film else None, E.ptr(wd), E.ptr(bd),
-        E.ptr(rd) if res else None, E.ptr(out), B, H, W, Cin, Cout, G, 1e-5, E.current_stream()))
+        E.ptr(rd) if res else None, E.ptr(out), B, H, W, Cin, Cout, G, 1e-5, E.ptr(ostats) if Go and G == 8 else None,
+        E.current_stream()))
     call(y)
+    if Go and G == 8:
+        grp = ref.reshape(B, Go, -1)
+        want_mean = grp.mean(dim=-1)
+        want_rstd = (grp.var(dim=-1, unbiased=False) + 1e-5).rsqrt()
+        got_s = ostats.cpu().double()
+        assert torch.allclose(got_s[..., 0], want_mean, rtol=0, atol=2e-6 * float(ref.abs().max()))
+        assert torch.allclose(got_s[..., 1], want_rstd, rtol=1e-5, atol=0)
     got = y.permute(0, 3, 1, 2).cpu().double()
     assert torch.isfinite(got).all()
     err = float((got - ref).norm() / ref.norm())
