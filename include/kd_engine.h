@@ -200,7 +200,8 @@ int kd_sample_finalize(kd_unet_t* u, const kd_sample_args_t* args, float* d_img,
 
 /* 2-D convolution as implicit GEMM on fp32 MFMA.  x: NHWC [B,Hi,Wi,Cin]; w: torch OIHW
  * [Cout,Cin,KH,KW] (re-packed internally on each call of this test entry); y: NHWC.
- * act: 0 none, 1 SiLU, 2 GELU(erf). */
+ * act: 0 none, 1 SiLU, 2 GELU(erf); | 0x100: the row-run K layout of the init convs; | 0x200 (1x1 convs): the
+ * upsample form, PixelShuffle(2) of the conv output, y is [B, 2 Ho, 2 Wo, Cout / 4]. */
 int kd_conv2d_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias, float* d_y,
                    int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad,
                    int act, void* stream);

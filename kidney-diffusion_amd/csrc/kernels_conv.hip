@@ -166,6 +166,42 @@ __device__ __forceinline__ void store_tile_regs_impl(const ConvParams& p,
   }
 }
 
+// PixelShuffle(2) epilogue straight from the registers (upsample convs: weight rows packed n' = (i*2+j)*Co + c).
+// Needs Co % 32 == 0 (the 32 channels of a lane group share (i, j) and stay one 128-B line) and Wo % 32 == 0
+// (the 32 rows of an MFMA tile lie in one image row: one division per tile instead of one per element).
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void store_tile_regs_pixshuf(const ConvParams& p,
+                                                        f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
+                                                        int64_t m0, int n0, int64_t M) {
+  constexpr int TM = BM / WAVES_M / 32;
+  constexpr int TN = BN / WAVES_N / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int Co = p.Cout >> 2;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+    if (n >= p.Cout) continue;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    const int q = n / Co, c = n - q * Co;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int64_t mt = m0 + (wm * TM + i) * 32;
+      if (mt >= M) continue;
+      const int64_t row = mt / p.Wo;                 // b * Ho + oy: the whole tile is in this image row
+      const int ox0 = (int)(mt - row * p.Wo) + 4 * (lane >> 5);
+      float* yp = p.y + ((2 * row + (q >> 1)) * (2 * p.Wo) + 2 * ox0 + (q & 1)) * (int64_t)p.ldy + p.yoff + c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        float v = acc[i][j][r] + bias;
+        if (p.act != ACT_NONE) v = act_apply(v, p.act);
+        yp[(int64_t)(2 * dr) * p.ldy] = v;
+      }
+    }
+  }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __device__ __forceinline__ void store_tile_regs(const ConvParams& p,
                                                 f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32], int64_t m0,
@@ -536,6 +572,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
     store_tile_regs<BM, BN, WAVES_M, WAVES_N>(q, acc, m0, n0, M);
   } else if (p.out_mode == OUT_NHWC && (!p.gate_src || ((hw & 31) == 0 && !p.res && p.act == ACT_NONE))) {
     store_tile_regs<BM, BN, WAVES_M, WAVES_N>(p, acc, m0, n0, M);
+  } else if (p.out_mode == OUT_PIXSHUF && ((p.Cout >> 2) & 31) == 0 && (p.Wo & 31) == 0 && !p.gate_src && !p.res) {
+    store_tile_regs_pixshuf<BM, BN, WAVES_M, WAVES_N>(p, acc, m0, n0, M);
   } else {
     store_tile<BM, BN, WAVES_M, WAVES_N>(p, lds, acc, m0, n0, M);
   }

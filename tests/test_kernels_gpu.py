@@ -80,6 +80,29 @@ def test_conv_igemm(lib, device, B, H, W, Cin, Cout, K, stride, pad, act):
     assert err <= max(3 * err_cpu, CONV_REL), (err, err_cpu)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (2, 64, 64, 128, 512),    # register epilogue: Co = 128, Wo = 64 (the SR UNet's 128 -> 256 upsample, scaled down)
+    (1, 32, 96, 64, 128),     # register epilogue, Co = 32 (one lane group per (i, j)), H != W
+    (2, 16, 16, 64, 192),     # Wo = 16, Co = 48: staged through LDS
+    (1, 8, 8, 512, 256),      # small M: split-K, then the reduction kernel's epilogue
+])
+def test_conv1x1_pixel_shuffle_upsample(lib, device, B, H, W, Cin, Cout):
+    """Upsample = conv1x1(C -> 4 Co) + PixelShuffle(2): the conv's epilogue writes the shuffled map directly."""
+    E = _E()
+    x = torch.randn(B, Cin, H, W, generator=g(1))
+    w = torch.randn(Cout, Cin, 1, 1, generator=g(2)) * Cin ** -0.5
+    b = torch.randn(Cout, generator=g(3))
+    ref = F.pixel_shuffle(F.conv2d(x.double(), w.double(), b.double()), 2)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(device)
+    wd, bd = w.to(device), b.to(device)
+    y = torch.full((B, 2 * H, 2 * W, Cout // 4), float("nan"), device=device)
+    E.check(lib.kd_conv2d_nhwc(E.ptr(xd), E.ptr(wd), E.ptr(bd), E.ptr(y), B, H, W, Cin, Cout, 1, 1, 1, 0, 0x200,
+                               E.current_stream()))
+    got = y.permute(0, 3, 1, 2).cpu().double()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).norm() / ref.norm()) <= CONV_REL
+
+
 # Winograd F(2x2,3x3) re-associates the sum (4x4 tile transforms): fp32 error a few x the direct conv's
 WINO_REL = 4e-6
 
