@@ -365,14 +365,16 @@ class Unet(nn.Module):
     def n_text_tokens(self):
         return self.attn_pool.num_tokens if (self.cond_on_text and exists(self.attn_pool)) else 0
 
-    def engine(self, batch: int, image_size: int, device, with_text: bool) -> C.c_void_p:
-        """Creates (or returns the cached) execution plan for a static (batch, image_size)."""
+    def engine(self, batch: int, image_size: int, device, with_text: bool, replica: int = 0) -> C.c_void_p:
+        """Creates (or returns the cached) execution plan for a static (batch, image_size).  `replica` > 0 gives
+        further plans of the same shape with their own workspace (plans on different streams run concurrently;
+        all plans of a UNet share one packed-weight store)."""
         E.require_gpu()
         lib = E.load()
         device = torch.device(device)
         # engine extension (not a library kwarg): 0 = auto (Winograd for the deep 3x3 convs), 1 = direct only
         conv_algo = int(getattr(self, "conv_algo", os.environ.get("KD_CONV_ALGO", "0")))
-        key = (batch, image_size, device.index, bool(with_text), conv_algo)
+        key = (batch, image_size, device.index, bool(with_text), conv_algo) + ((replica,) if replica else ())
         if key in self._engines:
             return self._engines[key]
         p = self._plan
