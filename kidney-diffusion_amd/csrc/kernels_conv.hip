@@ -393,8 +393,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int64_t M = (int64_t)p.B * p.Ho * p.Wo;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // Tile order: the N tiles of one M tile run back to back on ONE XCD (workgroups are dealt round-robin to
+  // the 8 XCDs in dispatch order, x fastest), so the activation rows they share are read from HBM once and
+  // hit that XCD's L2 afterwards.  In plain (x, y) order all M tiles of N tile 0 run before N tile 1 and a
+  // map larger than the caches is streamed from HBM once per N tile.
+  int mt = blockIdx.x, nt = blockIdx.y;
+  if (gridDim.y > 1 && (gridDim.x & 7) == 0) {
+    const unsigned lid = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned slot = lid >> 3;
+    nt = slot % gridDim.y;
+    mt = (slot / gridDim.y) * 8 + (lid & 7);
+  }
+  const int64_t m0 = (int64_t)mt * BM;
+  const int n0 = nt * BN;
   const int lrow = tid >> 3;
   const int gseg = (tid & 7) ^ ((lrow >> 1) & 7);
 
