@@ -407,7 +407,7 @@ def main():
                                    "Winograd F(2x2,3x3) in fp32 (2.25x fewer MACs; batched GEMMs from Cin >= 256, one "
                                    "fused kernel below), so 'achieved' (and 'frac') can exceed what the MFMA pipe executes; "
                                    "'frac_issued' = issued / peak is the share of the matrix peak actually used "
-                                   "(profiles/r01_v9_sq_summary.json has the per-kernel pipe utilisation from "
+                                   "(profiles/r01_v12_sq_summary.json has the per-kernel pipe utilisation from "
                                    "SQ_VALU_MFMA_BUSY_CYCLES)",
                          "kernels": kernels},
         }
