@@ -123,6 +123,7 @@ int launch_gn_apply_silu(const float* x, int ldx, const float* stats, const floa
 // y = LN(x)*g (+beta) (+res)
 int launch_layernorm(const float* x, const float* g, const float* beta, const float* res, float* y, int rows,
                      int C, float eps, hipStream_t s);
+// y[row] = [a[row] | b[row] * scale_b]; a == nullptr: only the b half is written (a's producer wrote in place)
 int launch_concat2(const float* a, int Ca, const float* b, int Cb, float scale_b, float* y, int64_t rows,
                    hipStream_t s);
 // y = a*gate[b][c] + r   (NHWC, rows = B*HW)

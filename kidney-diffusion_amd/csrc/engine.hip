@@ -728,7 +728,10 @@ struct Builder {
   }
 
   // ResnetBlock.  Does NOT free x.
-  T resnet(const T& x, const std::string& pre, int dim_out, const T* ctx, bool use_gca) {
+  // ct: the buffer of the skip concat that follows this block ([B,H,W,dim_out + skip channels]); when the
+  // block ends in its 1x1 skip conv, that conv writes the block output straight into the first dim_out
+  // channels of ct and ct is returned (concat_skip then only adds the skip half); otherwise ct is ignored
+  T resnet(const T& x, const std::string& pre, int dim_out, const T* ctx, bool use_gca, const T* ct = nullptr) {
     bool has_cross = has(pre + ".cross_attn.to_q.weight");
     if (has_cross && !ctx) throw std::runtime_error("cross-attention block without conditioning tokens: " + pre);
     int dim_in = x.C;
@@ -812,6 +815,7 @@ struct Builder {
         ConvOpt o;
         o.gate_src = &h2;
         o.gate = &gate;
+        if (ct) o.dst = ct;
         out = conv(x, P(pre + ".res_conv.weight", (int64_t)dim_out * dim_in), P(pre + ".res_conv.bias", dim_out),
                    dim_out, 1, 1, 0, o);
       } else {
@@ -827,6 +831,7 @@ struct Builder {
     } else {  // res_conv without gca: out = conv1x1(x) + h2
       ConvOpt o;
       o.res = &h2;
+      if (ct) o.dst = ct;
       out = conv(x, P(pre + ".res_conv.weight", (int64_t)dim_out * dim_in), P(pre + ".res_conv.bias", dim_out),
                  dim_out, 1, 1, 0, o);
     }
@@ -841,7 +846,7 @@ struct Builder {
                       [&](float* dst) { KD_THROW_IF(launch_pack_unshuffle(src, dst, dim_out, C, 0)); });
     return conv(x, w, P(pre + ".1.bias", dim_out), dim_out, 2, 2, 0, ConvOpt());
   }
-  T upsample(const T& x, const std::string& pre, int dim_out) {  // conv1x1 -> SiLU -> PixelShuffle(2)
+  T upsample(const T& x, const std::string& pre, int dim_out, const T* ct = nullptr) {  // conv1x1 -> SiLU -> PixelShuffle(2)
     const float* wsrc = raw(pre + ".net.0.weight", (int64_t)4 * dim_out * x.C);
     const float* bsrc = raw(pre + ".net.0.bias", 4 * dim_out);
     const int C = x.C;
@@ -854,6 +859,7 @@ struct Builder {
     ConvOpt o;
     o.act = ACT_SILU;
     o.out_mode = OUT_PIXSHUF;
+    if (ct) o.dst = ct;   // straight into the first dim_out channels of the following skip concat
     return conv(x, w, b, 4 * dim_out, 1, 1, 0, o);
   }
   T concat_skip(const T& x, const T& skip, float scale) {
@@ -865,6 +871,15 @@ struct Builder {
     emit([=](hipStream_t s) { return launch_concat2(uu->P(ao), Ca, uu->P(bo), Cb, scale, uu->P(yo), rows, s); },
          "concat rows" + std::to_string(rows) + " C" + std::to_string(Ca + Cb));
     return y;
+  }
+  // the same when x's producer already wrote its Ca channels into y (resnet / upsample with ct = &y)
+  void concat_skip_tail(const T& y, int Ca, const T& skip, float scale) {
+    size_t bo = skip.off, yo = y.off;
+    int Cb = skip.C;
+    int64_t rows = y.rows();
+    kd_unet* uu = u;
+    emit([=](hipStream_t s) { return launch_concat2(nullptr, Ca, uu->P(bo), Cb, scale, uu->P(yo), rows, s); },
+         "concat rows" + std::to_string(rows) + " C" + std::to_string(Ca + Cb));
   }
 
   void collect_time_mlps() {

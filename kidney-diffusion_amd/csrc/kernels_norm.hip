@@ -295,9 +295,29 @@ static inline int grid_for(int64_t n_items) {
   int64_t b = (n_items + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
+// y[row][Ca + c] = b[row][c] * scale_b only: the producer of the first Ca channels wrote them in place
+__global__ void concat_tail_kernel(const float* __restrict__ b, int Cb4, float scale_b, float* __restrict__ y, int Cy4,
+                                   int Ca4, int64_t rows) {
+  const int64_t total = rows * Cb4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = idx / Cb4;
+    int c4 = (int)(idx - row * Cb4);
+    f32x4 v = *(const f32x4*)(b + idx * 4);
+    v *= scale_b;
+    *(f32x4*)(y + (row * Cy4 + Ca4 + c4) * 4) = v;
+  }
+}
+
 int launch_concat2(const float* a, int Ca, const float* b, int Cb, float scale_b, float* y, int64_t rows,
                    hipStream_t s) {
   KD_REQUIRE(Ca % 4 == 0 && Cb % 4 == 0, "concat needs channel counts % 4 == 0");
+  if (!a) {  // the first Ca channels of y are already in place
+    hipLaunchKernelGGL(concat_tail_kernel, dim3(grid_for(rows * Cb / 4)), dim3(256), 0, s, b, Cb / 4, scale_b, y,
+                       (Ca + Cb) / 4, Ca / 4, rows);
+    KD_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(rows * (Ca + Cb) / 4)), dim3(256), 0, s, a, Ca / 4, b, Cb / 4,
                      scale_b, y, rows);
   KD_HIP_CHECK(hipGetLastError());
