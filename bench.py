@@ -98,7 +98,7 @@ def kernel_classes(lib, handle, iters=3):
             add("GroupNorm, LayerNorm, attention core, GlobalContext, concat, gate (HBM-bound)", us)
     out = []
     for key, (n, us, flop, nbytes) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
-        e = {"kernel": key, "launches": n, "ms": us / 1e3, "share": us / total_us}
+        e = {"kernel": key, "launches": n, "ms": us / 1e3, "avg_us": us / n, "share": us / total_us}
         if flop:
             e.update(bound="mfma", achieved=flop / us / 1e6, unit="TFLOP/s", frac=flop / us / 1e6 / FP32_PEAK_TFLOPS)
             if "Winograd" in key:
@@ -409,6 +409,9 @@ def main():
                                    "'frac_issued' = issued / peak is the share of the matrix peak actually used "
                                    "(profiles/r01_v12_sq_summary.json has the per-kernel pipe utilisation from "
                                    "SQ_VALU_MFMA_BUSY_CYCLES)",
+                         # the dominant kernel on its own: HIP events around each of its launches in one forward
+                         # (profiles/r01_*_kernel_stats.csv holds rocprofv3's average duration of the same kernel)
+                         "dominant": kernels[0] if kernels else None,
                          "kernels": kernels},
         }
         if world == 1 and not args.no_cpu_baseline:
