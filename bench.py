@@ -86,7 +86,7 @@ def kernel_classes(lib, handle, iters=3):
         if label.startswith("conv k3"):
             add("conv_buf_kernel: direct 3x3 convs", us, flop=2.0 * macs)
         elif label.startswith("wino fused"):
-            add("wino_fused_kernel: fused Winograd 3x3 convs (Cin <= 512)", us, flop=2.0 * macs)
+            add("wino_fused_gn_kernel: fused Winograd 3x3 convs, GroupNorm/SiLU applied in the kernel (Cin <= 512)", us, flop=2.0 * macs)
         elif m and m.group(1) == "wino gemm":
             add("conv_buf_kernel: Winograd position GEMMs", us, flop=2.0 * macs)
         elif m:  # transforms move 5x the map: read 1x / write 4x (in), read 4x / write 1x (out)
