@@ -29,6 +29,7 @@ for p in (ROOT, ROOT / "kidney-diffusion_amd"):
 import torch  # noqa: E402
 
 BATCH, SIZE, T_SCHED = 16, 256, 250
+DOMINANT = "wino_fused_gn_kernel: fused Winograd F(2x2,3x3) 3x3 convs, GroupNorm/FiLM/SiLU applied in the kernel (Cin <= 512)"
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix = vector peak (v_mfma_f32_32x32x2_f32, exact fp32)
 SR_UNET_KW = dict(dim=128, dim_mults=(1, 2, 4, 8), num_resnet_blocks=2, memory_efficient=True,
                   layer_attns=(False, False, False, True), layer_cross_attns=(False, False, True, True),
@@ -60,8 +61,11 @@ def synthetic_inputs(batch, device=None, seed=1234):
 
 def kernel_classes(lib, handle, iters=3):
     """Per-kernel-class rates of one UNet forward, measured live with HIP events around every launch
-    (`kd_unet_profile`, include/kd_engine.h): algorithmic FLOPs (or bytes) of the launches of a class
-    divided by their summed device time.  The step graph replays exactly these launches."""
+    (`kd_unet_profile`, include/kd_engine.h), on the stream the launches run on.  For a matrix-core class
+    `achieved` = the FLOPs its launches ISSUE on the MFMA pipe (the engine's own per-op count: Winograd
+    F(2x2,3x3) layers issue 16/36 of the direct convolution's MACs, K padded to the kernel's chunk) divided by
+    their summed device time, so `frac` = achieved / peak <= 1 is a pipe utilisation; `achieved_direct_equiv`
+    prices the same time against the direct-convolution FLOPs the reference computes."""
     import re
 
     from imagen_pytorch import _engine as E
@@ -71,58 +75,106 @@ def kernel_classes(lib, handle, iters=3):
     rows = [l.split(",") for l in buf.value.decode().strip().split("\n")[1:]]
     cls = {}
 
-    def add(key, us, flop=0.0, nbytes=0.0):
-        c = cls.setdefault(key, [0, 0.0, 0.0, 0.0])
+    def add(key, us, flop=0.0, issued=0.0, nbytes=0.0):
+        c = cls.setdefault(key, [0, 0.0, 0.0, 0.0, 0.0])
         c[0] += 1
         c[1] += us
         c[2] += flop
-        c[3] += nbytes
+        c[3] += issued
+        c[4] += nbytes
 
     total_us = 0.0
-    for _, label, macs, us in rows:
-        us, macs = float(us), int(macs)
+    for _, label, macs, us, mfma in rows:
+        us, macs, mfma = float(us), int(macs), int(mfma)
         total_us += us
         m = re.match(r"(wino_in|wino_out|wino gemm) M(\d+) Cin(\d+) Cout(\d+)", label)
         if label.startswith("conv k3"):
-            add("conv_buf_kernel: direct 3x3 convs", us, flop=2.0 * macs)
+            add("conv_buf_kernel: direct 3x3 convs", us, 2.0 * macs, 2.0 * mfma)
         elif label.startswith("wino fused"):
-            add("wino_fused_gn_kernel: fused Winograd 3x3 convs, GroupNorm/SiLU applied in the kernel (Cin <= 512)", us, flop=2.0 * macs)
+            add(DOMINANT, us, 2.0 * macs, 2.0 * mfma)
         elif m and m.group(1) == "wino gemm":
-            add("conv_buf_kernel: Winograd position GEMMs", us, flop=2.0 * macs)
+            add("conv_buf_kernel: Winograd position GEMMs", us, 2.0 * macs, 2.0 * mfma)
         elif m:  # transforms move 5x the map: read 1x / write 4x (in), read 4x / write 1x (out)
             ch = int(m.group(3)) if m.group(1) == "wino_in" else int(m.group(4))
             add("wino_in_kernel + wino_out_kernel (Winograd transforms)", us, nbytes=20.0 * int(m.group(2)) * ch)
         elif label.startswith("conv") or label.startswith("skinny"):
-            add("other conv / GEMM launches (1x1, 2x2-s2, init, final, skinny)", us, flop=2.0 * macs)
+            add("other conv / GEMM launches (1x1, 2x2-s2, init, final, skinny)", us, 2.0 * macs, 2.0 * (mfma or macs))
         else:
             add("GroupNorm, LayerNorm, attention core, GlobalContext, concat, gate (HBM-bound)", us)
     out = []
-    for key, (n, us, flop, nbytes) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
+    for key, (n, us, flop, issued, nbytes) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
         e = {"kernel": key, "launches": n, "ms": us / 1e3, "avg_us": us / n, "share": us / total_us}
         if flop:
-            e.update(bound="mfma", achieved=flop / us / 1e6, unit="TFLOP/s", frac=flop / us / 1e6 / FP32_PEAK_TFLOPS)
-            if "Winograd" in key:
-                e["issued"] = e["achieved"] * 16.0 / 36.0  # what the matrix pipe executes for those FLOPs
-                e["frac_issued"] = e["issued"] / FP32_PEAK_TFLOPS
+            e.update(bound="mfma", achieved=issued / us / 1e6, unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
+                     frac=issued / us / 1e6 / FP32_PEAK_TFLOPS, achieved_direct_equiv=flop / us / 1e6,
+                     issued_tflop_per_step=issued / 1e12)
         elif nbytes:
-            e.update(bound="hbm", achieved=nbytes / us / 1e3, unit="GB/s", frac=nbytes / us / 1e3 / 8000.0)
+            e.update(bound="hbm", achieved=nbytes / us / 1e3, unit="GB/s", peak=8000.0, frac=nbytes / us / 1e3 / 8000.0)
         out.append(e)
     return out
 
 
-def cpu_baseline(unet_product, device_tables):
-    """The oracle (CPU fp32 torch restatement) timed on this host, bounded sample: batch 2 (1/8 of the
-    headline batch), one warm-up step + one timed step.  steps/s is scaled to batch 16."""
+def host_cpu_info():
+    """Threads the CPU baseline may use = min(physical cores, affinity mask, cgroup CPU quota) and the CPU model
+    string.  torch's default (all logical CPUs of the host) oversubscribes a box that is given a CPU share."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    physical = len(cores) or max(1, logical // 2)
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, q // per)
+        except (OSError, ValueError):
+            pass
+    threads = min(x for x in (physical, affinity, quota) if x)
+    return dict(model=model, logical=logical, physical=physical, affinity=affinity, cgroup_quota=quota, threads=threads)
+
+
+CPU_BATCH = 8
+
+
+def cpu_baseline(unet_product, timed_steps=3):
+    """The oracle (CPU fp32 torch restatement of the reference's path) timed on this host: batch 8 (half the
+    headline batch), one warm-up step + `timed_steps` timed steps of p_sample with injected noise;
+    steps/s is scaled to batch 16.  Returns (json entry, inputs and outputs of the FIRST step for the parity
+    check against the engine)."""
     from oracle import imagen_ref as R
     from oracle import sampler_ref as RS
 
-    nthreads = torch.get_num_threads()
+    info = host_cpu_info()
+    torch.set_num_threads(info["threads"])
     ou = R.Unet(**SR_UNET_KW, lowres_cond=True, cond_on_text=False, text_embed_dim=None)
     ou.load_state_dict(unet_product.state_dict(), strict=True)
     ou.eval()
     oim = RS.Imagen([R.NullUnet(), ou], image_sizes=(64, SIZE), timesteps=(T_SCHED, T_SCHED),
                     pred_objectives=("noise", "noise"), condition_on_text=False)
-    b = 2
+    b = CPU_BATCH
     x, lowres, lowres_noise, cond = synthetic_inputs(b)
     sched = oim.noise_schedulers[1]
     t_lr = torch.full((b,), 0.2)
@@ -131,18 +183,60 @@ def cpu_baseline(unet_product, device_tables):
     g = torch.Generator().manual_seed(99)
     kw = dict(noise_scheduler=sched, text_embeds=None, text_mask=None, cond_images=cond, lowres_cond_img=lowres,
               lowres_noise_times=t_lr, cond_scale=1.0, pred_objective="noise", dynamic_threshold=True)
-    dts = []
+    dts, first = [], None
     with torch.no_grad():
-        for k in range(2):
+        for k in range(1 + timed_steps):
             t, tn = times[k]
+            noise = torch.randn(x.shape, generator=g)
             t0 = time.perf_counter()
-            x, _ = oim.p_sample(ou, x, t, torch.randn(x.shape, generator=g), t_next=tn, **kw)
+            x_next, _ = oim.p_sample(ou, x, t, noise, t_next=tn, **kw)
             dts.append(time.perf_counter() - t0)
-    sec_per_step_b16 = dts[-1] * (BATCH / b)
-    return {"value": 1.0 / sec_per_step_b16, "unit": "denoising-steps/s (batch 16)", "cores": nthreads,
-            "kind": "port",
-            "sample": f"oracle p_sample on CPU at batch {b} (1/8 of the batch), 1 warm-up + 1 timed step "
-                      f"({dts[-1]:.2f} s), scaled x{BATCH // b} to batch 16; torch {torch.__version__} oneDNN fp32"}
+            if first is None:
+                first = dict(x=x, noise=noise, lowres=lowres, cond=cond, x_next=x_next)
+            x = x_next
+    timed = dts[1:]
+    sec_per_step_b16 = (sum(timed) / len(timed)) * (BATCH / b)
+    entry = {"value": 1.0 / sec_per_step_b16, "unit": "denoising-steps/s (batch 16)", "cores": info["threads"],
+             "kind": "port",
+             "cpu_model": info["model"],
+             "host": {k: info[k] for k in ("logical", "physical", "affinity", "cgroup_quota")},
+             "sample": f"oracle p_sample (UNet forward + x0 / dynamic threshold / posterior / noise) on CPU at batch {b} "
+                       f"(half the headline batch), 1 warm-up ({dts[0]:.2f} s) + {len(timed)} timed steps "
+                       f"({', '.join(f'{d:.2f}' for d in timed)} s), mean scaled x{BATCH // b} to batch 16; "
+                       f"torch {torch.__version__} oneDNN fp32, torch.set_num_threads({info['threads']}) = "
+                       f"min(physical cores, affinity, cgroup quota)"}
+    return entry, first
+
+
+def engine_parity(unet, first, device, lib):
+    """The engine's first denoising step on the inputs of the CPU baseline's first step (same weights, same x_T,
+    same conditioning, same injected noise, schedule index 0): relative L2 and max-abs of x_{t-1} against the
+    oracle's.  Uses a second plan of the same UNet at the CPU baseline's batch (shared packed weights)."""
+    from imagen_pytorch import _engine as E
+    from imagen_pytorch.imagen_pytorch import GaussianDiffusionContinuousTimes, beta_linear_log_snr
+
+    b = first["x"].shape[0]
+    h = unet.engine(b, SIZE, device, with_text=False)
+    dv = lambda t: t.to(device=device, dtype=torch.float32).contiguous()
+    x, noise, lowres, cond = dv(first["x"]), dv(first["noise"]), dv(first["lowres"]), dv(first["cond"])
+    ls_lr = dv(beta_linear_log_snr(torch.full((b,), 0.2)))
+    tables = GaussianDiffusionContinuousTimes(noise_schedule="cosine", timesteps=T_SCHED).step_tables()
+    sc = E.kd_schedule_t()
+    sc.T = T_SCHED
+    for name, v in tables.items():
+        setattr(sc, name, v.numpy().ctypes.data_as(C.POINTER(C.c_float)))
+    sa = E.kd_sample_args_t()
+    sa.objective, sa.dynamic_threshold, sa.percentile, sa.resample_times = 0, 1, 0.95, 1
+    sa.d_lowres, sa.d_lowres_log_snr, sa.d_cond_images = E.ptr(lowres), E.ptr(ls_lr), E.ptr(cond)
+    sa.d_noise_step = E.ptr(noise)   # index 0 of the [T*R, B, 3, S, S] layout: only step 0 runs
+    sa.use_graph = 1
+    E.check(lib.kd_sample_steps(h, C.byref(sc), C.byref(sa), E.ptr(x), 0, 1, E.current_stream()))
+    torch.cuda.synchronize()
+    got, ref = x.double().cpu(), first["x_next"].double()
+    return {"parity_rel_l2": float((got - ref).norm() / ref.norm()), "parity_max_abs": float((got - ref).abs().max()),
+            "parity_case": f"x_(t-1) of denoising step 0 at batch {b}: engine (default plan, Winograd convs) vs the CPU "
+                           "oracle on identical weights / x_T / conditioning / injected noise; stated tolerance of "
+                           "one UNet forward 2e-5 rel-L2 (tests/test_fullsize_gpu.py)"}
 
 
 F_, T_ = False, True
@@ -218,8 +312,11 @@ def grid_workload(args, world, rank, device, distributed, barrier):
                              1024 + (n - 1) * geom.out_patch_dist)
         return [G.stitch_canvas(o, positions, sub, background=zoomed.to(o[0].device)) for o in out]
 
-    for _ in range(max(1, args.warmup)):  # builds the three plans (batch 1) and their step graphs
-        run(pos[:1], cond[:1], 1)
+    # Warm-up on EVERY rank: load the three stages, build every plan shape the timed run can use (batch 1..grid_batch
+    # in stages 1-2, batch 1 in stage 3) and capture their step graphs, so none of that lands in the timed region
+    # (one patch through run() would only exercise rank 0 at batch 1).
+    for _ in range(max(1, args.warmup)):
+        sample_fn.warm({st: range(1, gb[st] + 1) for st in (1, 2, 3)}, cond[0])
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -375,12 +472,45 @@ def main():
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         dev_ms_per_step = dev_ms / args.steps
-        achieved = flop_per_step / (dev_ms_per_step * 1e-3) / 1e12
+        step_issued = 2.0 * mfma_macs / (dev_ms_per_step * 1e-3) / 1e12
+        step_direct = flop_per_step / (dev_ms_per_step * 1e-3) / 1e12
         kernels = kernel_classes(lib, handle) if world == 1 and not args.no_kernel_classes else None
-        traffic = None
-        tf = ROOT / "profiles" / "hbm_traffic.json"
-        if tf.exists():
-            traffic = json.loads(tf.read_text()).get("bytes_per_step")
+        dom = next((k for k in (kernels or []) if k["kernel"] == DOMINANT), None)
+        # committed profile artefacts of the same command (profiles/): rocprofv3's average launch duration of the
+        # dominant kernel and the PMC traffic.  They are NOT measured in this run and are labelled as such.
+        prof = {}
+        pf = ROOT / "profiles" / "current.json"
+        if pf.exists():
+            prof = json.loads(pf.read_text())
+        roof = {"bound": "mfma", "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        if dom:
+            n = dom["launches"]
+            roof.update(
+                kernel=DOMINANT,
+                achieved=dom["achieved"], frac=dom["frac"],
+                achieved_direct_equiv=dom["achieved_direct_equiv"],
+                launches_per_step=n, avg_launch_us=dom["avg_us"], share_of_step=dom["share"],
+                work=f"achieved = FLOPs the kernel ISSUES on the fp32 MFMA pipe per launch ({dom['issued_tflop_per_step'] / n * 1e3:.1f} "
+                     f"GFLOP average over its {n} launches per step = 2 x 16 Winograd positions x tiles x Cout x Cin, i.e. "
+                     "16/36 of the direct 3x3 convolution the reference computes) / average launch duration measured "
+                     "live with HIP events around each launch (kd_unet_profile, on the launch stream); "
+                     "achieved_direct_equiv prices the same time against the direct-convolution FLOPs of SURVEY §8d "
+                     "and can exceed the peak - it is not a utilisation",
+                rocprof_avg_launch_us=prof.get("dominant_avg_us"),
+                traffic=prof.get("dominant_bytes_per_launch"),
+                traffic_source=("profile-derived, not measured in this run: " + prof["source"]) if prof.get("source") else None)
+        else:  # multi-GPU runs / --no-kernel-classes: no per-launch profile, whole-step pipe utilisation instead
+            roof.update(kernel="whole denoising step (per-launch profile skipped)", achieved=step_issued,
+                        frac=step_issued / FP32_PEAK_TFLOPS, achieved_direct_equiv=step_direct, traffic=None)
+        roof["step"] = {
+            "issued_tflops": step_issued, "frac_issued": step_issued / FP32_PEAK_TFLOPS,
+            "direct_equiv_tflops": step_direct, "device_ms": dev_ms_per_step,
+            "algorithmic_tflop_per_step": flop_per_step / 1e12, "issued_tflop_per_step": 2.0 * mfma_macs / 1e12,
+            "traffic_bytes_per_step": prof.get("bytes_per_step"),
+            "note": "one denoising-step graph = UNet forward + x0 / quantile / DDPM update; device time by HIP events "
+                    "on the launch stream; issued = what the conv / GEMM launches put on the matrix cores "
+                    "(kd_unet_mfma_macs), direct_equiv = 2 x 229.2 GMAC/sample x 16 of SURVEY §8d / time"}
+        roof["kernels"] = kernels
         out = {
             "metric": "denoising-steps/sec (64->256 SR UNet, bs16)",
             "value": world * args.steps / elapsed,
@@ -394,28 +524,12 @@ def main():
                                    "random-init weights, Philox noise on device, hipGraph-replayed step",
                        "batch_per_gpu": BATCH, "image_size": SIZE, "launches_per_step": launches,
                        "parallelism": f"{world} independent batch replicas (no data-path collective)"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
-                         "issued": 2.0 * mfma_macs / (dev_ms_per_step * 1e-3) / 1e12,
-                         "frac_issued": 2.0 * mfma_macs / (dev_ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                         "kernel": "one denoising-step graph (UNet forward + x0/quantile/DDPM update); "
-                                   f"{flop_per_step / 1e12:.3f} TFLOP algorithmic per launch (2 x "
-                                   f"{macs / 1e9 / BATCH:.1f} GMAC/sample x {BATCH}, direct-convolution count of "
-                                   f"SURVEY §8d), device time by HIP events {dev_ms_per_step:.2f} ms/launch; fp32 "
-                                   f"MFMA peak.  'issued' = the {2.0 * mfma_macs / 1e12:.3f} TFLOP the conv/GEMM "
-                                   "launches actually put on the matrix cores: the ResnetBlock 3x3 convs run as "
-                                   "Winograd F(2x2,3x3) in fp32 (2.25x fewer MACs; batched GEMMs from Cin >= 256, one "
-                                   "fused kernel below), so 'achieved' (and 'frac') can exceed what the MFMA pipe executes; "
-                                   "'frac_issued' = issued / peak is the share of the matrix peak actually used "
-                                   "(profiles/r01_v12_sq_summary.json has the per-kernel pipe utilisation from "
-                                   "SQ_VALU_MFMA_BUSY_CYCLES)",
-                         # the dominant kernel on its own: HIP events around each of its launches in one forward
-                         # (profiles/r01_*_kernel_stats.csv holds rocprofv3's average duration of the same kernel)
-                         "dominant": kernels[0] if kernels else None,
-                         "kernels": kernels},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(unet, tables)
+            cpu, first = cpu_baseline(unet)
+            out["cpu_baseline"] = cpu
+            out.update(engine_parity(unet, first, device, lib))
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

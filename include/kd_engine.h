@@ -9,8 +9,13 @@
  *
  * Conventions
  *   - every pointer named d_* is a DEVICE pointer (HBM), borrowed, never freed by the library;
- *   - `stream` is a hipStream_t passed as void*; all calls are stream-ordered, no hidden syncs
- *     (kd_unet_create / kd_sampler_create allocate and synchronise; nothing else does);
+ *   - `stream` is a hipStream_t passed as void*; all launches are stream-ordered.  What synchronises:
+ *     kd_unet_create[_shared] (allocates, packs the weights, device-synchronises); the FIRST
+ *     kd_sample_* call on a plan (hipMalloc of the sampler scratch, capture + instantiate of the step
+ *     graph); a kd_sample_* call whose schedule differs from the previous call's (one stream
+ *     synchronise + one asynchronous table upload; an unchanged schedule uploads nothing);
+ *     kd_unet_profile and the single-kernel test entry points.  Successive calls on one plan must be
+ *     issued on one stream (or otherwise ordered): the plan owns ONE workspace;
  *   - every function returns 0 on success, non-zero on failure; kd_last_error() gives the text;
  *   - images are fp32 NCHW exactly as the reference passes them (sample_ultra_res.py:183-195);
  *     feature maps inside the engine are fp32 NHWC (DESIGN.md "Data layout").
@@ -109,8 +114,9 @@ int kd_unet_num_launches(const kd_unet_t* u);
 int kd_unet_text_cond(kd_unet_t* u, const float* d_text_embeds, const float* d_text_mask, int L, int drop,
                       float* d_text_tokens, float* d_text_hiddens, void* stream);
 
-/* Diagnostic: per-launch device time of one forward as CSV "index,label,macs,avg_us" (uses the
- * inputs of the preceding kd_unet_forward call; synchronises the stream). */
+/* Diagnostic: per-launch device time of one forward as CSV "index,label,macs,avg_us,mfma_macs" (macs: the
+ * algorithmic MACs of the launch as the reference computes them, mfma_macs: what it issues on the matrix
+ * cores; uses the inputs of the preceding kd_unet_forward call; synchronises the stream). */
 int kd_unet_profile(kd_unet_t* u, int iters, char* buf, size_t buflen, void* stream);
 
 /* Replaces `unet.forward_with_cond_scale(x, log_snr(t), lowres_cond_img=..,
@@ -126,6 +132,11 @@ int kd_unet_forward(kd_unet_t* u, const float* d_x, const float* d_lowres,
                     const float* d_cond_images, const float* d_log_snr,
                     const float* d_lowres_log_snr, const float* d_text_tokens,
                     const float* d_text_hiddens, float* d_out, void* stream);
+
+/* Classifier-free guidance combine of `Unet.forward_with_cond_scale` (sample.py:55-59 reaches it with
+ * cond_scale != 1): out = null + (cond - null) * cond_scale over n floats; out may alias cond. */
+int kd_cfg_combine(const float* d_cond, const float* d_null, float* d_out, float cond_scale, int64_t n,
+                   void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sampler.  Replaces `Imagen.p_sample_loop` / `p_sample` / `p_mean_variance` (SURVEY §3.2,

@@ -137,6 +137,7 @@ struct kd_unet {
   std::vector<std::function<int(hipStream_t)>> ops;
   std::vector<std::string> op_label;  // per-op description + algorithmic MACs (kd_unet_profile)
   std::vector<int64_t> op_macs;
+  std::vector<int64_t> op_mfma;  // MACs the op issues on the matrix cores (Winograd: 16/36 of op_macs, padded K)
   std::shared_ptr<WeightStore> wstore;
   char* ws = nullptr;
   size_t ws_bytes = 0;
@@ -163,6 +164,9 @@ struct kd_unet {
   uint64_t* s_seed = nullptr;  // Philox key, device-resident so the step graph does not depend on it
   void* s_qws = nullptr;
   int s_tables_cap = 0;
+  std::vector<float> s_tables_host;  // what s_tables holds (9 x T): an unchanged schedule is not uploaded again
+  float* s_tables_pinned = nullptr;  // staging for the asynchronous upload
+  size_t s_tables_pinned_floats = 0;
   // cached graph of one iteration
   hipGraphExec_t graph_exec = nullptr;
   hipStream_t cap_stream = nullptr;
@@ -175,6 +179,7 @@ struct kd_unet {
     void* frees[] = {ws, s_pred, s_x0, s_thresh, s_time, s_tables, s_iter, s_seed, s_qws, s_pred_null};
     for (void* p : frees)
       if (p) (void)hipFree(p);
+    if (s_tables_pinned) (void)hipHostFree(s_tables_pinned);
   }
 };
 
@@ -298,6 +303,7 @@ struct Builder {
     u->ops.push_back(std::move(f));
     u->op_label.push_back(std::move(label));
     u->op_macs.push_back(macs);
+    u->op_mfma.push_back(0);
   }
 
   // ---- conv / GEMM emission
@@ -379,7 +385,11 @@ struct Builder {
     // algorithmic MACs of one forward as the reference computes it: the step-invariant part of the
     // init conv is counted even though the engine runs it once per sampling call instead of per step
     if (!to_text) u->macs += m;
-    if (!to_text && !to_static) u->mfma_macs += (int64_t)x.B * Ho * Wo * Cout * p.Cin * p.KH * p.KW;
+    if (!to_text && !to_static) {
+      const int64_t issued = (int64_t)x.B * Ho * Wo * Cout * p.Cin * p.KH * p.KW;
+      u->mfma_macs += issued;
+      u->op_mfma.back() = issued;
+    }
     return y;
   }
   // token GEMM y[M,N] = x[M,K] @ w[N,K]^T
@@ -662,7 +672,11 @@ struct Builder {
     }, "wino fused M" + std::to_string((int64_t)Bx * H * W) + " Cin" + std::to_string(Cin) + " Cout" +
            std::to_string(Cout), m);
     if (!to_text) u->macs += m;
-    if (!to_text && !to_static) u->mfma_macs += (int64_t)Bx * H * W * 4 * Cout * ((Cin / 4 + 2) / 3 * 12);
+    if (!to_text && !to_static) {
+      const int64_t issued = (int64_t)Bx * H * W * 4 * Cout * ((Cin / 4 + 2) / 3 * 12);
+      u->mfma_macs += issued;
+      u->op_mfma.back() = issued;
+    }
     return y;
   }
 
@@ -723,7 +737,11 @@ struct Builder {
            std::to_string(Cout), m);
     free(ab);
     if (!to_text) u->macs += m;
-    if (!to_text && !to_static) u->mfma_macs += (int64_t)Bx * H * W * 4 * Cout * ((Cin / 4 + 3) / 4 * 16);
+    if (!to_text && !to_static) {
+      const int64_t issued = (int64_t)Bx * H * W * 4 * Cout * ((Cin / 4 + 3) / 4 * 16);
+      u->mfma_macs += issued;
+      u->op_mfma.back() = issued;
+    }
     return y;
   }
 

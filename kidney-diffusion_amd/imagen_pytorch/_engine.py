@@ -87,7 +87,7 @@ class kd_sample_args_t(C.Structure):
     ]
 
 
-# symbol -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+# symbol -> (restype, argtypes); tests/test_cpu.py::test_library_loads_and_exports_every_symbol_the_header_declares checks it against include/kd_engine.h
 SIGNATURES = {
     "kd_last_error": (C.c_char_p, []),
     "kd_version": (C.c_int, []),
@@ -120,6 +120,7 @@ SIGNATURES = {
     "kd_quantile_abs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),
     "kd_quantile_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "kd_cfg_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
     "kd_philox_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),
 }
 

@@ -200,6 +200,10 @@ class ResnetBlock(_Decl):
             self.res_conv = nn.Conv2d(dim, dim_out, 1)
 
 
+def _invalidate_engine_hook(module, incompatible_keys):  # module-level: a pickled / deep-copied Unet keeps it
+    module.invalidate_engine()
+
+
 # ============================================================================ Unet
 class Unet(nn.Module):
     """Same constructor surface as ``imagen_pytorch.Unet`` for every kwarg the reference passes;
@@ -330,8 +334,9 @@ class Unet(nn.Module):
         nn.init.zeros_(self.final_conv.bias)
 
         self._engines = {}
+        self._engines_fingerprint = None
         self._io_buffers = {}  # per (batch, size, device): sampler inputs at stable addresses (step graph reuse)
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_engine())
+        self.register_load_state_dict_post_hook(_invalidate_engine_hook)
 
     # ---- library API used by Imagen
     def cast_model_parameters(self, *, lowres_cond, text_embed_dim, channels, channels_out, cond_on_text):
@@ -344,12 +349,47 @@ class Unet(nn.Module):
 
     # ---- engine plumbing
     def invalidate_engine(self):
+        """Drops every execution plan (and the packed-weight store they share).  Called automatically by
+        load_state_dict, .to()/.cuda()/.float() and whenever a parameter was changed in place since the
+        plans were built (see `_weights_fingerprint`)."""
         lib = E._lib
         for h in self._engines.values():
             if lib is not None:
                 lib.kd_unet_destroy(h)
         self._engines = {}
         self._io_buffers = {}
+        self._engines_fingerprint = None
+
+    def _weights_fingerprint(self):
+        """(storage address, in-place version counter) of every parameter / buffer: the engine keeps PACKED
+        COPIES of the weights, so restore_parts() on a live state_dict, `p.copy_()` / `p.add_()` under no_grad
+        or an optimizer step must rebuild them.  torch bumps `_version` on every in-place write through the
+        parameter or a `detach()`ed alias (what state_dict() hands out).  Writes through `p.data` carry their
+        own version counter and are invisible here: after those, call `invalidate_engine()` yourself."""
+        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(unet) - ImagenTrainer's EMA copies (trainer.py), the reference builds the trainer around
+        a live Imagen (sample_uncond.py:22-23): the copy gets the parameters, never the engine handles (ctypes
+        pointers cannot be copied, and two owners would destroy one plan twice) nor the I/O staging buffers."""
+        import copy
+
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in ("_engines", "_io_buffers", "_engines_fingerprint"):
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new._engines, new._io_buffers, new._engines_fingerprint = {}, {}, None
+        # the load_state_dict post hook registered in __init__ was deep-copied with the hooks dict and still
+        # refers to its `module` argument (not to `self`): it stays valid for the copy
+        return new
+
+    def __getstate__(self):  # pickling (torch.save of a module): same rule
+        d = dict(self.__dict__)
+        d["_engines"], d["_io_buffers"], d["_engines_fingerprint"] = {}, {}, None
+        return d
 
     def _apply(self, fn, *a, **k):  # .to()/.cuda()/.float() move parameters: packed copies are stale
         self.invalidate_engine()
@@ -375,6 +415,10 @@ class Unet(nn.Module):
         # engine extension (not a library kwarg): 0 = auto (Winograd for the deep 3x3 convs), 1 = direct only
         conv_algo = int(getattr(self, "conv_algo", os.environ.get("KD_CONV_ALGO", "0")))
         key = (batch, image_size, device.index, bool(with_text), conv_algo) + ((replica,) if replica else ())
+        if self._engines:
+            fp = self._weights_fingerprint()
+            if fp != self._engines_fingerprint:   # a parameter was written in place: packed copies are stale
+                self.invalidate_engine()
         if key in self._engines:
             return self._engines[key]
         p = self._plan
@@ -423,6 +467,7 @@ class Unet(nn.Module):
             E.check(lib.kd_unet_create_shared(C.byref(cfg), arr, len(names), share, C.byref(handle)))
             del sd
         self._engines[key] = handle
+        self._engines_fingerprint = self._weights_fingerprint()
         return handle
 
     def forward(self, x, time, *, lowres_cond_img=None, lowres_noise_times=None, text_embeds=None, text_mask=None,
@@ -469,9 +514,17 @@ class Unet(nn.Module):
         return tok, hid
 
     def forward_with_cond_scale(self, *args, cond_scale=1.0, **kwargs):
-        if cond_scale != 1:
-            raise NotImplementedError("classifier-free guidance (cond_scale != 1) is planned (SURVEY §8f)")
-        return self.forward(*args, **kwargs)
+        """Library method: one forward at cond_scale == 1, else a second forward with the
+        conditioning dropped and null + (cond - null) * cond_scale (sample.py:55-59 reaches it through
+        trainer.sample(cond_scale=...)).  Both forwards and the combine run on the engine."""
+        logits = self.forward(*args, **kwargs)
+        if cond_scale == 1:
+            return logits
+        null_logits = self.forward(*args, **{**kwargs, "cond_drop_prob": 1.0})
+        with torch.cuda.device(logits.device):
+            E.check(E.load().kd_cfg_combine(E.ptr(logits), E.ptr(null_logits), E.ptr(logits), float(cond_scale),
+                                            logits.numel(), E.current_stream()))
+        return logits
 
 
 class NullUnet(nn.Module):

@@ -20,16 +20,37 @@ from .imagen_pytorch import Imagen, NullUnet, exists
 from .version import __version__
 
 
-def restore_parts(state_dict_target, state_dict_from):
-    """Copies every same-named, same-shaped tensor; reports and skips the rest."""
+def restore_parts(state_dict_target, state_dict_from, report=print):
+    """Copies every same-named, same-shaped tensor and returns the target (the reference falls
+    back to it when the strict load raises, sample_ultra_res.py:59-63).  The library only prints shape
+    mismatches; a checkpoint written by another imagen-pytorch version can also carry keys this module tree
+    does not have (e.g. `q_scale` / `k_scale` of the qk-norm attention) or lack keys it has - both would
+    leave the model silently half-loaded, so they are reported too (`report=None` silences it)."""
+    say = report if report is not None else (lambda *_: None)
+    unexpected, copied = [], 0
     for name, param in state_dict_from.items():
         if name not in state_dict_target:
+            unexpected.append(name)
             continue
         if param.size() == state_dict_target[name].size():
             state_dict_target[name].copy_(param)
+            copied += 1
         else:
-            print(f"layer {name}({param.size()} different than target: {state_dict_target[name].size()}")
+            say(f"layer {name}({param.size()} different than target: {state_dict_target[name].size()}")
+    missing = [k for k in state_dict_target if k not in state_dict_from]
+    if unexpected or missing:
+        say(f"restore_parts: {copied} tensors copied; {len(unexpected)} checkpoint tensors have no counterpart in "
+            f"this model (ignored): {_abbrev(unexpected)}; {len(missing)} model tensors are not in the checkpoint "
+            f"(left at their initial values): {_abbrev(missing)}")
+        if any(k.endswith(("q_scale", "k_scale")) for k in unexpected):
+            say("restore_parts: the checkpoint has q_scale / k_scale tensors: it was written by an imagen-pytorch "
+                "whose attention normalises q and k (qk-norm); load it with load_state_dict, which switches the "
+                "attention variant from the key set (Unet(attn_qk_norm=...))")
     return state_dict_target
+
+
+def _abbrev(keys, n=6):
+    return "[]" if not keys else "[" + ", ".join(keys[:n]) + (f", ... +{len(keys) - n} more]" if len(keys) > n else "]")
 
 
 def _open(path):

@@ -161,7 +161,7 @@ def imagen_sample_fn(load_imagen: Callable, inpaint_resample: int, device: torch
             cache[stage] = load_imagen(stage).to(device)
         imagen = cache[stage]
         outs = []
-        step = cap(stage)
+        step = fn._force_batch or cap(stage)
         for n0 in range(0, len(tasks), step):
             sl = slice(n0, n0 + step)
             b = len(tasks[sl])
@@ -177,4 +177,24 @@ def imagen_sample_fn(load_imagen: Callable, inpaint_resample: int, device: torch
             outs.extend(out[i] for i in range(b))
         return outs
 
+    def warm(batches_per_stage, cond_image=None):
+        """Builds what a timed run must not pay for: for every stage its Imagen on the device and, for every batch
+        size in `batches_per_stage[stage]`, the execution plan and the captured step graph (one sample() call on
+        zero inpaint tensors).  Call it on EVERY rank before the first timed grid."""
+        for stage, batches in batches_per_stage.items():
+            S, s_prev = G.PATCH_SIZES[stage], G.PATCH_SIZES.get(stage - 1)
+            for b in batches:
+                tasks = [(0, 0, n) for n in range(b)]
+                lows = [None if s_prev is None else torch.zeros(3, s_prev, s_prev, device=device) for _ in tasks]
+                conds = [None if cond_image is None else cond_image for _ in tasks]
+                ips = [torch.zeros(3, S, S, device=device) for _ in tasks]
+                ims = [torch.zeros(S, S, device=device) for _ in tasks]
+                fn._force_batch = b
+                try:
+                    fn(stage, tasks, lows, conds, ips, ims)
+                finally:
+                    fn._force_batch = None
+
+    fn.warm = warm
+    fn._force_batch = None
     return fn

@@ -188,6 +188,31 @@ def tissue_patch_positions(mask: torch.Tensor, geom: GridGeometry) -> List[Pos]:
     return [(i, j) for i in range(n) for j in range(n) if bool(hit[i, j] > 0.5)]
 
 
+def center_crop_offset(size: int, crop: int) -> int:
+    """First row / column of torchvision's `CenterCrop(crop)` window on an axis of `size` >= `crop` pixels:
+    `int(round((size - crop) / 2.0))` (torchvision.transforms.functional.center_crop) - Python's round, i.e.
+    half to even: an odd margin such as kidney mag 2's 1024 - 161 = 863 starts at 432, not 431.  The reference
+    crops with it at sample_ultra_res.py:391, :393 and :419."""
+    return int(round((size - crop) / 2.0))
+
+
+def center_crop(img: torch.Tensor, crop: int) -> torch.Tensor:
+    """`transforms.CenterCrop(crop)(img)` on the last two dims, including torchvision's zero padding of an
+    image smaller than the crop (left/top (crop - size) // 2, right/bottom (crop - size + 1) // 2)."""
+    h, w = img.shape[-2], img.shape[-1]
+    if crop > w or crop > h:
+        pl = (crop - w) // 2 if crop > w else 0
+        pt = (crop - h) // 2 if crop > h else 0
+        pr = (crop - w + 1) // 2 if crop > w else 0
+        pb = (crop - h + 1) // 2 if crop > h else 0
+        img = F.pad(img, (pl, pr, pt, pb))
+        h, w = img.shape[-2], img.shape[-1]
+        if crop == w and crop == h:
+            return img
+    top, left = center_crop_offset(h, crop), center_crop_offset(w, crop)
+    return img[..., top:top + crop, left:left + crop]
+
+
 def cond_images_for_grid(zoomed_image: torch.Tensor, geom: GridGeometry, patch_pos: Sequence[Pos],
                          fill_color: float = 0.95, centre_crop_channels: bool = False) -> torch.Tensor:
     """(N,3|6,1024,1024) conditioning images: the zoomed image shifted so that each patch sits in the
@@ -208,11 +233,9 @@ def cond_images_for_grid(zoomed_image: torch.Tensor, geom: GridGeometry, patch_p
             img[:, :, :sx] = fill_color
         else:
             img[:, :, sx:] = fill_color
-        off = (img.shape[-1] - PATCH_SIZE) // 2 if img.shape[-1] > PATCH_SIZE else 0
-        c = img[:, off:off + PATCH_SIZE, off:off + PATCH_SIZE] if img.shape[-1] >= PATCH_SIZE else img
+        c = center_crop(img, PATCH_SIZE)                       # sample_ultra_res.py:391
         if centre_crop_channels:
-            o2 = (c.shape[-1] - geom.patch_width) // 2
-            centre = c[:, o2:o2 + geom.patch_width, o2:o2 + geom.patch_width]
+            centre = center_crop(c, geom.patch_width)          # :393
             centre = F.interpolate(centre.unsqueeze(0), PATCH_SIZE, mode="nearest").squeeze(0)
             c = torch.cat((c, centre), 0)
         out.append(c)

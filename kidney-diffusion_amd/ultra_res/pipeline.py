@@ -48,8 +48,7 @@ def generate_high_res_image(sample_fn: Callable, zoomed_image: torch.Tensor, mag
     cond = G.cond_images_for_grid(zoomed_image, geom, pos, fill_color=fill_color, centre_crop_channels=version == "v2")
     lowres, stages = None, (1, 2, 3)
     if ignore_unet_1:
-        o = (cond.shape[-1] - geom.patch_width) // 2
-        lowres = [cond[:, :3, o:o + geom.patch_width, o:o + geom.patch_width]]
+        lowres = [G.center_crop(cond[:, :3], geom.patch_width)]   # transforms.CenterCrop(patch_width), :419
         stages = (2, 3)
     out = D.sample_grids(sample_fn, stages, [pos], [cond], overlap, [geom.num_patches_width],
                          orientations=[G.choose_orientation(pos)], lowres=lowres, patch_width=geom.patch_width,

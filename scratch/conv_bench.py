@@ -3,7 +3,7 @@ sys.path.insert(0,'kidney-diffusion_amd')
 from imagen_pytorch import _engine as E
 import torch; torch.cuda.init(); torch.zeros(1,device='cuda')
 lib=E.load()
-f=C.CDLL(str(E._LIB_PATH.parent/'libkd_conv_bench.so')).kd_conv_bench; f.restype=C.c_int
+f=C.CDLL(str(E._LIB_PATH.parents[2]/"scratch"/"conv_x"/"libkd_conv_bench.so")).kd_conv_bench; f.restype=C.c_int
 shapes=[(16,128,128,128,128,3),(16,64,64,256,256,3),(16,16,16,1024,1024,3),(16,32,32,512,512,3)]
 variants=[int(v) for v in sys.argv[1].split(',')] if len(sys.argv)>1 else list(range(10))
 for (B,H,W,Ci,Co,K) in shapes:

@@ -2,7 +2,7 @@ import sys, ctypes as C
 sys.path.insert(0,'kidney-diffusion_amd')
 from imagen_pytorch import _engine as E
 import torch; torch.zeros(1,device='cuda')
-lib=E.load(); f=C.CDLL(str(E._LIB_PATH.parent/'libkd_conv_bench.so')).kd_conv_bench; f.restype=C.c_int
+lib=E.load(); f=C.CDLL(str(E._LIB_PATH.parents[2]/"scratch"/"conv_x"/"libkd_conv_bench.so")).kd_conv_bench; f.restype=C.c_int
 shapes=[(16,256,256,128,128,3),(16,128,128,128,128,3),(16,64,64,256,256,3),(16,256,256,256,128,3),(16,128,128,256,128,3)]
 variants=[int(v) for v in sys.argv[1].split(',')]
 for rep in range(2):

@@ -204,6 +204,34 @@ def test_reference_style_construction_and_checkpoint_roundtrip(tmp_path):
         tr.train_step(unet_number=1)
 
 
+def test_restore_parts_reports_what_it_could_not_load_and_unets_deepcopy():
+    """A checkpoint from another library version must not be half-loaded silently (sample_ultra_res.py:59-63
+    falls back to restore_parts on any RuntimeError of the strict load)."""
+    import copy
+
+    from imagen_pytorch import Unet, restore_parts
+
+    u = Unet(**H.UNET_KW["small1"], cond_on_text=False, text_embed_dim=None)
+    sd = {k: v.clone() for k, v in u.state_dict().items()}
+    dropped = "mid_block1.block1.project.bias"
+    del sd[dropped]
+    sd["mid_attn.layers.0.0.q_scale"] = torch.ones(64)
+    sd["final_conv.bias"] = torch.ones(5)
+    lines = []
+    restore_parts(u.state_dict(), sd, report=lines.append)
+    text = "\n".join(lines)
+    assert "final_conv.bias" in text and dropped in text and "q_scale" in text and "qk-norm" in text
+    lines.clear()
+    restore_parts(u.state_dict(), u.state_dict(), report=lines.append)
+    assert not lines                                    # a complete, matching checkpoint reports nothing
+    u._engines = {"fake": 1}                            # stands for live ctypes plan handles
+    c = copy.deepcopy(u)
+    assert c._engines == {} and c._io_buffers == {} and u._engines == {"fake": 1}
+    u._engines = {}
+    for (ka, va), (kb, vb) in zip(u.state_dict().items(), c.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb) and va.data_ptr() != vb.data_ptr()
+
+
 def test_product_has_no_cpu_fallback_and_never_imports_the_oracle():
     import imagen_pytorch as ip
     from imagen_pytorch import _engine as E

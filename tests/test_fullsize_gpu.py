@@ -1,0 +1,246 @@
+"""Full-size parity: the HIP engine against the CPU oracle at the dims BASELINE.json's configs name
+(no reduced `dim`), through the drop-in Python surface and the C ABI.
+
+  C1  uncond base UNet, dim 256, 64x64, batch 1, T = 50, whole sampler   train_uncond.py:30-36, sample_uncond.py:49-55
+  C2  seg-cond base UNet, dim 256, text + 4 label planes, one forward     train.py:30-39, sample_cond.py:36-48
+  C3  SR UNet 64->256, dim 128: one forward and sampler steps, Winograd and direct plans   train_ultra_res.py:39-48
+  C4  unet3 (blocks 2,4,6,8) on a 256x256 crop, one forward               train_ultra_res.py:51-60,88
+      text + low-res SR UNet with cond_dim 512, one forward                train.py:42-53
+      3-stage cascade chained 1 -> 2 -> 3 (reduced dims, full structure)   sample_ultra_res.py:264-270
+
+Tolerances are the ones of tests/test_unet_gpu.py (2e-5 relative L2 for one forward, 2e-3 absolute on
+sampled images).  The oracle runs on the host cores of the GPU box: a 343-459 GFLOP forward takes seconds.
+"""
+import time
+
+import pytest
+import torch
+
+import helpers as H
+from oracle import imagen_ref as R
+from oracle import sampler_ref as RS
+
+pytestmark = pytest.mark.gpu
+
+FWD_REL_L2 = 2e-5
+SAMPLE_ABS = 2e-3
+
+F_, T_ = False, True
+FULL_KW = {
+    # train_uncond.py:30-36
+    "uncond1": dict(dim=256, dim_mults=(1, 2, 4, 8), cond_dim=512, num_resnet_blocks=3,
+                    layer_attns=(F_, T_, T_, T_), layer_cross_attns=(F_, T_, T_, T_)),
+    # train.py:30-39
+    "seg1": dict(dim=256, dim_mults=(1, 2, 3, 4), cond_dim=512, text_embed_dim=3, num_resnet_blocks=3,
+                 layer_attns=(F_, T_, T_, T_), layer_cross_attns=(F_, T_, T_, T_), cond_images_channels=4),
+    # train.py:42-53
+    "seg2": dict(dim=128, cond_dim=512, text_embed_dim=3, dim_mults=(1, 2, 4, 8), num_resnet_blocks=2,
+                 memory_efficient=True, layer_attns=(F_, F_, F_, T_), layer_cross_attns=(F_, F_, T_, T_),
+                 init_conv_to_final_conv_residual=True, cond_images_channels=4),
+    # train_ultra_res.py:39-48
+    "ultra2": dict(dim=128, dim_mults=(1, 2, 4, 8), num_resnet_blocks=2, memory_efficient=True,
+                   layer_attns=(F_, F_, F_, T_), layer_cross_attns=(F_, F_, T_, T_),
+                   init_conv_to_final_conv_residual=True, cond_images_channels=3),
+    # train_ultra_res.py:51-60
+    "ultra3": dict(dim=128, dim_mults=(1, 2, 4, 8), num_resnet_blocks=(2, 4, 6, 8), memory_efficient=True,
+                   layer_attns=False, layer_cross_attns=(F_, F_, F_, T_), init_conv_to_final_conv_residual=True,
+                   cond_images_channels=3),
+}
+
+
+def _oracle(name, lowres, seed, text=False):
+    kw = dict(FULL_KW[name])
+    if not text:
+        kw.pop("text_embed_dim", None)
+        u = R.Unet(**kw, lowres_cond=lowres, cond_on_text=False, text_embed_dim=None)
+    else:
+        u = R.Unet(**kw, lowres_cond=lowres, cond_on_text=True)
+    return H.randomize_(u, seed).eval()
+
+
+def _fwd_inputs(B, S, lowres, cc, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 3, S, S, generator=g)
+    lr = torch.randn(B, 3, S, S, generator=g) if lowres else None
+    cond = torch.rand(B, cc, S, S, generator=g) if cc else None
+    t = torch.randn(B, generator=g) * 3
+    tl = torch.full((B,), -1.3) if lowres else None
+    return x, lr, cond, t, tl
+
+
+def _dv(device):
+    return lambda v: None if v is None else v.to(device)
+
+
+# ------------------------------------------------------------------------------- C3: the headline UNet
+@pytest.fixture(scope="module")
+def c3():
+    """Oracle results of the headline UNet, computed once for both plans (Winograd / direct)."""
+    ou = _oracle("ultra2", True, seed=21)
+    B, S = 2, 256
+    inp = _fwd_inputs(B, S, True, 3, seed=5)
+    x, lr, cond, t, tl = inp
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = ou(x, t, lowres_cond_img=lr, lowres_noise_times=tl, cond_images=cond)
+    fwd_s = time.perf_counter() - t0
+    # sampler: stage 2 of a cascade, T = 3 (t = 1 -> 2/3 -> 1/3 -> 0: first, middle and last-step branches)
+    oim = RS.Imagen([R.NullUnet(), ou], image_sizes=(64, S), timesteps=(3, 3), pred_objectives=("noise", "noise"),
+                    condition_on_text=False)
+    g = torch.Generator().manual_seed(6)
+    start = torch.rand(1, 3, 64, 64, generator=g)
+    scond = torch.rand(1, 3, S, S, generator=g)
+    nf = RS.generator_noise_fn(31)
+    trace = []
+    sref = oim.sample(noise_fn=nf, batch_size=1, cond_images=scond, start_image_or_video=start,
+                      start_at_unet_number=2, trace=trace)
+    return dict(ou=ou, inp=inp, ref=ref, fwd_s=fwd_s, oim=oim, start=start, scond=scond, nf=nf, sref=sref,
+                trace=trace)
+
+
+@pytest.mark.parametrize("conv_algo", [0, 1])
+def test_c3_sr_unet_forward_and_sampler_steps_match_oracle(device, c3, conv_algo):
+    import imagen_pytorch as ip
+
+    dv = _dv(device)
+    pu = H.product_unet_like(c3["ou"]).to(device)
+    pu.conv_algo = conv_algo
+    x, lr, cond, t, tl = c3["inp"]
+    got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
+    err = H.rel_l2(got, c3["ref"])
+    assert err < FWD_REL_L2, f"C3 forward, conv_algo={conv_algo}: rel-L2 {err:.3e}"
+    # full p_sample steps (x0, dynamic threshold, posterior, noise) on the same UNet
+    pim = ip.Imagen([ip.NullUnet(), pu], image_sizes=(64, 256), timesteps=(3, 3), pred_objectives=("noise", "noise"),
+                    condition_on_text=False).to(device)
+    pim.unets[1].conv_algo = conv_algo
+    ptrace = []
+    sgot = pim.sample(noise_fn=c3["nf"], batch_size=1, cond_images=dv(c3["scond"]),
+                      start_image_or_video=dv(c3["start"]), start_at_unet_number=2, trace=ptrace, device=device)
+    for k, (a, b) in enumerate(zip(ptrace, c3["trace"])):
+        assert H.rel_l2(a, b) < 1e-4 * (k + 1), (k, H.rel_l2(a, b))
+    assert (sgot.cpu() - c3["sref"]).abs().max() < SAMPLE_ABS
+
+
+# ------------------------------------------------------------------------------- C1: end to end
+def test_c1_uncond_base_unet_50_steps_end_to_end(device):
+    """BASELINE configs[0]: unconditional base UNet 64x64, 50 DDPM steps, batch 1 - the whole sampler on both
+    paths with identical injected noise (BASELINE.md §3 'full-parity config')."""
+    import imagen_pytorch as ip
+
+    ou = _oracle("uncond1", False, seed=41)
+    oim = RS.Imagen([ou], image_sizes=(64,), timesteps=(50,), pred_objectives=("noise",), condition_on_text=False)
+    pim = ip.Imagen([ip.Unet(**oim.unets[0]._locals)], image_sizes=(64,), timesteps=(50,),
+                    pred_objectives=("noise",), condition_on_text=False)
+    pim.load_state_dict(oim.state_dict(), strict=True)
+    pim = pim.to(device)
+    nf = RS.generator_noise_fn(2024)
+    otrace, ptrace = [], []
+    ref = oim.sample(noise_fn=nf, batch_size=1, trace=otrace)
+    got = pim.sample(noise_fn=nf, batch_size=1, trace=ptrace, device=device)
+    assert len(otrace) == len(ptrace) == 50
+    worst = max(H.rel_l2(a, b) for a, b in zip(ptrace, otrace))
+    err = float((got.cpu() - ref).abs().max())
+    print(f"C1 end to end: max|diff| {err:.3e}, worst per-step rel-L2 {worst:.3e}")
+    assert err < SAMPLE_ABS, err
+    # the production path (graph replay of the whole loop) gives the same image as the stepwise trace run
+    got2 = pim.sample(noise_fn=nf, batch_size=1, device=device)
+    assert torch.equal(got, got2)
+
+
+# ------------------------------------------------------------------------------- C2: seg-cond base UNet
+def test_c2_segcond_base_unet_forward_matches_oracle(device):
+    """BASELINE configs[1] UNet at full size: text_embeds (B,1,3), four one-hot label planes
+    (sample_cond.py:36-38, 75-80)."""
+    ou = _oracle("seg1", False, seed=51, text=True)
+    pu = H.product_unet_like(ou).to(device)
+    B, S = 2, 64
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 3, S, S, generator=g)
+    t = torch.randn(B, generator=g) * 2
+    text = torch.tensor([0.0, 0.5, 0.2]).reshape(1, 1, 3).repeat_interleave(B, dim=0)
+    mask = torch.any(text != 0.0, dim=-1)
+    labels = torch.nn.functional.one_hot(torch.randint(0, 4, (B, 1024, 1024), generator=g), 4)
+    labels = labels.permute(0, 3, 1, 2).float()   # resized inside (nearest), as the reference passes them
+    with torch.no_grad():
+        ref = ou(x, t, text_embeds=text, text_mask=mask, cond_images=labels)
+    dv = _dv(device)
+    got = pu(dv(x), dv(t), text_embeds=dv(text), text_mask=dv(mask), cond_images=dv(labels))
+    err = H.rel_l2(got, ref)
+    assert err < FWD_REL_L2, f"C2 forward: rel-L2 {err:.3e}"
+
+
+def test_text_lowres_sr_unet_cond_dim_512_forward_matches_oracle(device):
+    """train.py:42-53: the SR UNet of the seg-cond cascade - text + low-res conditioning + cond_dim 512 (the
+    cross-attention context is 4 time tokens + 36 pooled text tokens of width 512)."""
+    ou = _oracle("seg2", True, seed=52, text=True)
+    pu = H.product_unet_like(ou).to(device)
+    B, S = 1, 256
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, 3, S, S, generator=g)
+    lr = torch.randn(B, 3, S, S, generator=g)
+    t = torch.randn(B, generator=g)
+    tl = torch.full((B,), -1.1)
+    text = torch.tensor([0.0, 0.5, 0.2]).reshape(1, 1, 3).repeat_interleave(B, dim=0)
+    mask = torch.any(text != 0.0, dim=-1)
+    labels = torch.nn.functional.one_hot(torch.randint(0, 4, (B, S, S), generator=g), 4).permute(0, 3, 1, 2).float()
+    dv = _dv(device)
+    for drop in (0.0, 1.0):
+        with torch.no_grad():
+            ref = ou(x, t, lowres_cond_img=lr, lowres_noise_times=tl, text_embeds=text, text_mask=mask,
+                     cond_images=labels, cond_drop_prob=drop)
+        got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), text_embeds=dv(text),
+                 text_mask=dv(mask), cond_images=dv(labels), cond_drop_prob=drop)
+        err = H.rel_l2(got, ref)
+        assert err < FWD_REL_L2, f"text+lowres SR UNet, drop={drop}: rel-L2 {err:.3e}"
+
+
+# ------------------------------------------------------------------------------- C4 stage 3 on a crop
+def test_unet3_on_a_256_crop_forward_matches_oracle(device):
+    """train_ultra_res.py:51-60 at full dim on the 256x256 crop it is trained on (:88): 753.5 GFLOP."""
+    from imagen_pytorch import _engine as E
+
+    ou = _oracle("ultra3", True, seed=61)
+    pu = H.product_unet_like(ou).to(device)
+    x, lr, cond, t, tl = _fwd_inputs(1, 256, True, 3, seed=10)
+    with torch.no_grad():
+        ref = ou(x, t, lowres_cond_img=lr, lowres_noise_times=tl, cond_images=cond)
+    dv = _dv(device)
+    got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
+    err = H.rel_l2(got, ref)
+    assert err < FWD_REL_L2, f"unet3 crop forward: rel-L2 {err:.3e}"
+    gmac = E.load().kd_unet_macs(pu.engine(1, 256, device, with_text=False)) / 1e9
+    assert abs(gmac - 376.7) / 376.7 < 0.01, gmac
+
+
+# ------------------------------------------------------------------------------- 3-stage cascade, chained
+def test_three_stage_cascade_chained_matches_oracle(device):
+    """BASELINE configs[3] structure (64 -> 256 -> 1024 cascade, one sample() call through all three UNets,
+    each stage conditioned on the previous one's output) at reduced dims / sizes so the oracle runs in
+    seconds: unet kwargs of train_ultra_res.py:29-60 at dim 32, image sizes (16, 32, 64)."""
+    import imagen_pytorch as ip
+
+    ous = [H.oracle_unet("ultra1", seed=71), H.oracle_unet("ultra2", lowres_cond=True, seed=72),
+           H.oracle_unet("ultra3", lowres_cond=True, seed=73)]
+    kw = dict(image_sizes=(16, 32, 64), timesteps=(4, 3, 3), pred_objectives=("noise", "v", "v"),
+              condition_on_text=False)
+    oim = RS.Imagen(ous, **kw)
+    pim = ip.Imagen([ip.Unet(**u._locals) for u in oim.unets], random_crop_sizes=(None, None, 16), **kw)
+    pim.load_state_dict(oim.state_dict(), strict=True)
+    pim = pim.to(device)
+    g = torch.Generator().manual_seed(12)
+    cond = torch.rand(2, 3, 64, 64, generator=g)
+    nf = RS.generator_noise_fn(99)
+    ref = oim.sample(noise_fn=nf, batch_size=2, cond_images=cond, return_all_unet_outputs=True)
+    got = pim.sample(noise_fn=nf, batch_size=2, cond_images=cond.to(device), return_all_unet_outputs=True,
+                     device=device)
+    assert [tuple(o.shape) for o in got] == [(2, 3, 16, 16), (2, 3, 32, 32), (2, 3, 64, 64)]
+    for stage, (a, b) in enumerate(zip(got, ref), 1):
+        err = float((a.cpu() - b).abs().max())
+        assert err < SAMPLE_ABS * stage, (stage, err)   # each stage inherits the previous stage's deviation
+    # stop_at_unet_number / start_at_unet_number split of the same chain (the reference's per-stage loop,
+    # sample_ultra_res.py:264-270) gives the same images as the single call
+    s1 = pim.sample(noise_fn=nf, batch_size=2, cond_images=cond.to(device), stop_at_unet_number=1, device=device)
+    assert torch.equal(s1, got[0])
+    s2 = pim.sample(noise_fn=nf, batch_size=2, cond_images=cond.to(device), start_at_unet_number=2,
+                    stop_at_unet_number=2, start_image_or_video=s1, device=device)
+    assert torch.equal(s2, got[1])

@@ -71,10 +71,15 @@ def test_inpaint_assembly_matches_reference_slicing():
     assert patch.abs().sum() == 0 and mask.sum() == 0
 
 
-def test_cond_images_and_stitch_semantics():
+def test_cond_images_and_stitch_semantics(monkeypatch):
     geom = G.GridGeometry(patch_width=8, patch_dist=6, num_patches_width=2, out_patch_dist=768, canvas_width=1792)
     z = torch.rand(1, 3, 14, 14)
     pos = geom.positions
+    # an image narrower than PATCH_SIZE is zero-padded to it, as torchvision's CenterCrop does (:391)
+    padded = G.cond_images_for_grid(z, geom, pos[:1], fill_color=0.95)
+    assert padded.shape == (1, 3, 1024, 1024) and padded[0, :, :505].abs().sum() == 0
+    assert torch.equal(padded[0, :, 505 + 3:505 + 14, 505 + 3:505 + 14], z[0][:, :-3, :-3])
+    monkeypatch.setattr(G, "PATCH_SIZE", 14)   # small stand-in for the 1024-px conditioning image
     conds = G.cond_images_for_grid(z, geom, pos, fill_color=0.95)
     assert conds.shape == (4, 3, 14, 14)
     # patch (0,0) centre (4,4) moves to the image centre (7,7): shift +3, top/left 3 rows filled

@@ -56,8 +56,9 @@ def _reference_level(zoomed, mag_level, overlap, pos_filter=None):
             img[:, :, :sx] = 0.95
         else:
             img[:, :, sx:] = 0.95
-        off = (W - PS) // 2 if W > PS else 0
-        conds.append(img[:, off:off + PS, off:off + PS] if W >= PS else img)
+        assert W >= PS   # (narrower images are zero-padded by torchvision: covered in test_grid / test_geometry_pins)
+        off = int(round((W - PS) / 2.0))   # torchvision CenterCrop (sample_ultra_res.py:391), half-to-even
+        conds.append(img[:, off:off + PS, off:off + PS])
 
     def ready(p, o, rest):
         return (p[0] - 1, p[1]) not in rest and (p[0], p[1] + o) not in rest and (p[0] - 1, p[1] + o) not in rest
