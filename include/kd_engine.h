@@ -72,6 +72,12 @@ typedef struct kd_unet_config {
    * kernel wherever its shape rules allow (tests); n >= 32 = batched-GEMM Winograd from Cin >= n
    * (experiments / tests) */
   int conv_algo;
+  /* Attention similarity variant - imagen-pytorch changed it between versions, and the reference's pinned
+   * 1.18.5 is not available to check: 0 = q * dim_head^-0.5 . k (the library default
+   * the reference's configs get); 1 = `Unet(cosine_sim_attn=True)`: l2norm(q) . l2norm(k) * 16;
+   * 2 = learned per-channel `q_scale` / `k_scale` on the normalised q / k, * 8 (later versions; the host
+   * switches to it when a checkpoint carries those keys).  Applies to self-, cross- and text-pooling attention. */
+  int attn_qk_norm;
 } kd_unet_config_t;
 
 /* One named parameter tensor of the UNet's state_dict (key WITHOUT the `unets.N.` prefix,

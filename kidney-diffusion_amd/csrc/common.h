@@ -176,6 +176,8 @@ int launch_text_select(const float* tok, const float* mask, const float* null_em
                        int C, int drop, hipStream_t s);
 int launch_add_rows_bcast(const float* x, const float* add, float* y, int B, int R, int C, hipStream_t s);
 int launch_mean_rows(const float* x, float* y, int B, int R, int C, hipStream_t s);
+// in place: each 64-float head segment of x[row][h*64 ..] -> x / max(||x||, 1e-12) (* scale_vec[64] if given)
+int launch_l2norm_heads(float* x, int ld, int64_t rows, int heads, const float* scale_vec, hipStream_t s);
 int launch_cfg_combine(const float* cond, const float* nul, float* out, float scale, int64_t n, hipStream_t s);
 
 // ---- sampler (kernels_sampler.hip)

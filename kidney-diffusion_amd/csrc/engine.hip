@@ -447,6 +447,32 @@ struct Builder {
     return y;
   }
 
+  // ---- attention similarity variants (cfg.attn_qk_norm, include/kd_engine.h)
+  float attn_scale() const {
+    return cfg.attn_qk_norm == 1 ? 16.0f : cfg.attn_qk_norm == 2 ? 8.0f : 1.0f / sqrtf((float)cfg.attn_dim_head);
+  }
+  // in place on a workspace tensor: normalise (and scale) the `heads` 64-wide segments at the start of each row
+  void qk_norm(const T& t, int ld, int heads, const float* scale_vec) {
+    size_t off = t.off;
+    int64_t rows = t.rows();
+    kd_unet* uu = u;
+    emit([=](hipStream_t s) { return launch_l2norm_heads(uu->P(off), ld, rows, heads, scale_vec, s); },
+         "qk l2norm rows" + std::to_string(rows) + " heads" + std::to_string(heads));
+  }
+  const float* q_scale_of(const std::string& pre) { return cfg.attn_qk_norm == 2 ? P(pre + ".q_scale", cfg.attn_dim_head) : nullptr; }
+  const float* k_scale_of(const std::string& pre) { return cfg.attn_qk_norm == 2 ? P(pre + ".k_scale", cfg.attn_dim_head) : nullptr; }
+  // learned null key / value [2][D]; with qk-norm the key row is normalised (and scaled) once, at plan build
+  const float* null_kv_of(const std::string& pre) {
+    const int D = cfg.attn_dim_head;
+    const float* raw_nkv = P(pre + ".null_kv", 2 * D);
+    if (!cfg.attn_qk_norm) return raw_nkv;
+    const float* ks = k_scale_of(pre);
+    return cached("null_kv_qknorm" + std::to_string(cfg.attn_qk_norm) + ":" + pre, (size_t)2 * D, [&](float* dst) {
+      KD_HIP_THROW(hipMemcpyAsync(dst, raw_nkv, (size_t)2 * D * sizeof(float), hipMemcpyDeviceToDevice, 0));
+      KD_THROW_IF(launch_l2norm_heads(dst, 2 * D, 1, 1, ks, 0));
+    });
+  }
+
   // ---- modules
   // cross attention of feature tokens to the conditioning tokens c [B,Nc,cond_dim]; returns attn(x)+x
   T cross_attn(const T& x, const std::string& pre, const T& c) {
@@ -455,12 +481,16 @@ struct Builder {
     T q = linear(xn, P(pre + ".to_q.weight", (int64_t)inner * dim), nullptr, inner);
     free(xn);
     T kv = linear(c, P(pre + ".to_kv.weight", (int64_t)2 * inner * c.C), nullptr, 2 * inner);
-    const float* nkv = P(pre + ".null_kv", 2 * D);
+    const float* nkv = null_kv_of(pre);
+    if (cfg.attn_qk_norm) {
+      qk_norm(q, inner, H, q_scale_of(pre));
+      qk_norm(kv, 2 * inner, H, k_scale_of(pre));
+    }
     T o = alloc(x.B, x.H, x.W, inner);
     {
       size_t qo = q.off, kvo = kv.off, oo = o.off;
       int Bx = x.B, Nq = x.HW(), Nc = c.HW();
-      float scale = 1.0f / sqrtf((float)D);
+      float scale = attn_scale();
       kd_unet* uu = u;
       emit([=](hipStream_t s) {
         KVSeg s0{uu->P(kvo), uu->P(kvo) + inner, 2 * inner, Nc};
@@ -494,12 +524,17 @@ struct Builder {
                    2 * D);
       free(cn);
     }
-    const float* nkv = P(a + ".null_kv", 2 * D);
+    const float* nkv = null_kv_of(a);
+    if (cfg.attn_qk_norm) {
+      qk_norm(q, inner, H, q_scale_of(a));
+      qk_norm(kv, 2 * D, 1, k_scale_of(a));
+      if (has_ctx) qk_norm(ckv, 2 * D, 1, k_scale_of(a));
+    }
     T o = alloc(x.B, x.H, x.W, inner);
     {
       size_t qo = q.off, kvo = kv.off, oo = o.off, co = has_ctx ? ckv.off : 0;
       int Bx = x.B, N = x.HW(), Nc = has_ctx ? ctx->HW() : 0;
-      float scale = 1.0f / sqrtf((float)D);
+      float scale = attn_scale();
       kd_unet* uu = u;
       emit([=](hipStream_t s) {
         KVSeg s0{nullptr, nullptr, 0, 0};

@@ -74,4 +74,28 @@ int launch_cfg_combine(const float* cond, const float* nul, float* out, float sc
   return 0;
 }
 
+// qk-norm attention variants (Unet(cosine_sim_attn=True) of imagen-pytorch 1.18.x; learned q_scale / k_scale of
+// later versions): every 64-wide head segment of a row is replaced by x / max(||x||, 1e-12) (* scale_vec) -
+// torch's F.normalize(dim=-1) followed by the learned per-channel scale.  One wave per (row, head), in place.
+__global__ __launch_bounds__(256) void l2norm_heads_kernel(float* __restrict__ x, int ld, int64_t rows, int heads,
+                                                          const float* __restrict__ scale_vec) {
+  const int lane = threadIdx.x & 63;
+  const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seg >= rows * heads) return;
+  float* p = x + (seg / heads) * ld + (seg % heads) * 64 + lane;
+  const float v = *p;
+  float ss = v * v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+  const float r = v / fmaxf(sqrtf(ss), 1e-12f);
+  *p = scale_vec ? r * scale_vec[lane] : r;
+}
+int launch_l2norm_heads(float* x, int ld, int64_t rows, int heads, const float* scale_vec, hipStream_t s) {
+  const int64_t segs = rows * heads;
+  if (segs <= 0) return 0;
+  hipLaunchKernelGGL(l2norm_heads_kernel, dim3((unsigned)((segs + 3) / 4)), dim3(256), 0, s, x, ld, rows, heads, scale_vec);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 }  // namespace kd

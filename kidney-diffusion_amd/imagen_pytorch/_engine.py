@@ -49,6 +49,7 @@ class kd_unet_config_t(C.Structure):
         ("batch", C.c_int),
         ("image_size", C.c_int),
         ("conv_algo", C.c_int),
+        ("attn_qk_norm", C.c_int),
     ]
 
 

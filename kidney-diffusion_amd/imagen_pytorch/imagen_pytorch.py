@@ -105,9 +105,25 @@ class Parallel(_Decl):
         self.fns = nn.ModuleList(fns)
 
 
-class Attention(_Decl):
+class _QKNorm:
+    """Attention similarity variant of the module (include/kd_engine.h `attn_qk_norm`): 0 scaled dot product,
+    1 cosine-sim (l2norm q, k; x16), 2 learned q_scale / k_scale on the normalised q, k (x8).  Variant 2 owns
+    two more parameters; a module switches to it when a checkpoint carries them (Unet._load_from_state_dict)."""
+    dim_head = 64
+
+    def set_qk_norm(self, mode):
+        if mode == 2 and not hasattr(self, "q_scale"):
+            ref = self.to_q.weight
+            self.q_scale = nn.Parameter(torch.ones(self.dim_head, device=ref.device, dtype=ref.dtype))
+            self.k_scale = nn.Parameter(torch.ones(self.dim_head, device=ref.device, dtype=ref.dtype))
+        if mode != 2 and hasattr(self, "q_scale"):
+            del self.q_scale, self.k_scale
+
+
+class Attention(_Decl, _QKNorm):
     def __init__(self, dim, *, dim_head, heads, context_dim=None):
         super().__init__()
+        self.dim_head = dim_head
         inner = dim_head * heads
         self.norm = LayerNorm(dim)
         self.null_kv = nn.Parameter(torch.randn(2, dim_head))
@@ -118,9 +134,10 @@ class Attention(_Decl):
         self.to_out = nn.Sequential(nn.Linear(inner, dim, bias=False), LayerNorm(dim))
 
 
-class CrossAttention(_Decl):
+class CrossAttention(_Decl, _QKNorm):
     def __init__(self, dim, *, context_dim, dim_head, heads):
         super().__init__()
+        self.dim_head = dim_head
         inner = dim_head * heads
         self.norm = LayerNorm(dim)
         self.null_kv = nn.Parameter(torch.randn(2, dim_head))
@@ -143,9 +160,10 @@ class TransformerBlock(_Decl):
                            _feed_forward(dim, ff_mult)]) for _ in range(depth)])
 
 
-class PerceiverAttention(_Decl):
+class PerceiverAttention(_Decl, _QKNorm):
     def __init__(self, *, dim, dim_head, heads):
         super().__init__()
+        self.dim_head = dim_head
         inner = dim_head * heads
         self.norm = nn.LayerNorm(dim)
         self.norm_latents = nn.LayerNorm(dim)
@@ -219,7 +237,12 @@ class Unet(nn.Module):
         attn_pool_text=True, attn_pool_num_latents=32, dropout=0.0, memory_efficient=False,
         init_conv_to_final_conv_residual=False, use_global_context_attn=True, scale_skip_connection=True,
         final_resnet_block=True, final_conv_kernel_size=3, self_cond=False, pixel_shuffle_upsample=True,
+        cosine_sim_attn=False, attn_qk_norm=None,
     ):
+        """`cosine_sim_attn` is the library's kwarg (1.18.x: l2-normalised q, k with a fixed scale of 16).
+        `attn_qk_norm` (engine extension, 0 / 1 / 2, see include/kd_engine.h) overrides it; 2 = the learned
+        q_scale / k_scale attention of later library versions, which load_state_dict() also selects by itself
+        when the incoming keys contain `q_scale` - so the first real checkpoint decides the variant."""
         super().__init__()
         self._locals = {k: v for k, v in locals().items() if k not in ("self", "__class__")}
         unsupported = dict(use_linear_attn=use_linear_attn, use_linear_cross_attn=use_linear_cross_attn,
@@ -336,7 +359,34 @@ class Unet(nn.Module):
         self._engines = {}
         self._engines_fingerprint = None
         self._io_buffers = {}  # per (batch, size, device): sampler inputs at stable addresses (step graph reuse)
+        self.attn_qk_norm = 0
+        self.set_attn_qk_norm(int(attn_qk_norm) if exists(attn_qk_norm) else (1 if cosine_sim_attn else 0))
         self.register_load_state_dict_post_hook(_invalidate_engine_hook)
+
+    def set_attn_qk_norm(self, mode: int):
+        assert mode in (0, 1, 2), "attn_qk_norm: 0 scaled dot product, 1 cosine-sim, 2 learned q/k scales"
+        if getattr(self, "_engines", None):
+            self.invalidate_engine()
+        self.attn_qk_norm = mode
+        self._locals["attn_qk_norm"] = mode
+        for m in self.modules():
+            if isinstance(m, _QKNorm):
+                m.set_qk_norm(mode)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # Runs before the children load: a checkpoint whose attention blocks carry q_scale / k_scale was written
+        # by a library version with qk-norm attention -> grow those parameters so that the strict load succeeds
+        # and the engine plans the matching similarity (and the other way round for a checkpoint without them).
+        has = any(k.startswith(prefix) and k.endswith(".q_scale") for k in state_dict)
+        if has and self.attn_qk_norm != 2:
+            print("imagen_pytorch: checkpoint carries q_scale / k_scale -> attention variant switched to qk-norm "
+                  "(learned scales, x8)")
+            self.set_attn_qk_norm(2)
+        elif not has and self.attn_qk_norm == 2 and any(k.startswith(prefix) for k in state_dict):
+            print("imagen_pytorch: checkpoint has no q_scale / k_scale -> attention variant switched back to the "
+                  "scaled dot product")
+            self.set_attn_qk_norm(0)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     # ---- library API used by Imagen
     def cast_model_parameters(self, *, lowres_cond, text_embed_dim, channels, channels_out, cond_on_text):
@@ -414,7 +464,8 @@ class Unet(nn.Module):
         device = torch.device(device)
         # engine extension (not a library kwarg): 0 = auto (Winograd for the deep 3x3 convs), 1 = direct only
         conv_algo = int(getattr(self, "conv_algo", os.environ.get("KD_CONV_ALGO", "0")))
-        key = (batch, image_size, device.index, bool(with_text), conv_algo) + ((replica,) if replica else ())
+        key = (batch, image_size, device.index, bool(with_text), conv_algo, self.attn_qk_norm) + \
+            ((replica,) if replica else ())
         if self._engines:
             fp = self._weights_fingerprint()
             if fp != self._engines_fingerprint:   # a parameter was written in place: packed copies are stale
@@ -447,6 +498,7 @@ class Unet(nn.Module):
         cfg.attend_at_middle, cfg.use_gca = int(p["attend_at_middle"]), int(p["use_gca"])
         cfg.batch, cfg.image_size = batch, image_size
         cfg.conv_algo = conv_algo
+        cfg.attn_qk_norm = self.attn_qk_norm
 
         with torch.cuda.device(device):
             sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous()

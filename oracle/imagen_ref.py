@@ -159,7 +159,33 @@ class CrossEmbedLayer(nn.Module):
 
 
 # --------------------------------------------------------------------------- attention
-class Attention(nn.Module):
+class _QKNorm:
+    """Similarity variants (SURVEY A.1 marks this version-dependent; 1.18.5 itself cannot be inspected here):
+    mode 0  sim = (q * dim_head^-0.5) . k                       library default, what the reference's configs get
+    mode 1  `cosine_sim_attn=True` of 1.18.x: sim = l2norm(q) . l2norm(k) * 16      (q * self.scale with scale 1)
+    mode 2  later versions: sim = (l2norm(q) * q_scale) . (l2norm(k) * k_scale) * 8, learned per-channel scales
+    k includes the null key and the context keys (they are concatenated before the normalisation)."""
+    qk_norm = 0
+
+    def set_qk_norm(self, mode):
+        self.qk_norm = mode
+        if mode == 2 and not hasattr(self, "q_scale"):
+            d = self.null_kv.shape[-1] if hasattr(self, "null_kv") else self.dim_head
+            self.q_scale = nn.Parameter(torch.ones(d))
+            self.k_scale = nn.Parameter(torch.ones(d))
+        if mode != 2 and hasattr(self, "q_scale"):
+            del self.q_scale, self.k_scale
+
+    def similarity_inputs(self, q, k):
+        if self.qk_norm == 0:
+            return q * self.scale, k, 1.0
+        q, k = F.normalize(q, dim=-1), F.normalize(k, dim=-1)
+        if self.qk_norm == 1:
+            return q, k, 16.0
+        return q * self.q_scale, k * self.k_scale, 8.0
+
+
+class Attention(nn.Module, _QKNorm):
     """Multi-query self attention (one shared k/v head) with learned null k/v and
     optional context k/v."""
 
@@ -184,7 +210,7 @@ class Attention(nn.Module):
         x = self.norm(x)
         q = self.to_q(x)
         k, v = self.to_kv(x).chunk(2, dim=-1)
-        q = q.reshape(b, n, h, -1).permute(0, 2, 1, 3) * self.scale
+        q = q.reshape(b, n, h, -1).permute(0, 2, 1, 3)
         nk, nv = self.null_kv.unbind(dim=-2)
         k = torch.cat((nk.expand(b, 1, -1), k), dim=-2)
         v = torch.cat((nv.expand(b, 1, -1), v), dim=-2)
@@ -193,14 +219,15 @@ class Attention(nn.Module):
             ck, cv = self.to_context(context).chunk(2, dim=-1)
             k = torch.cat((ck, k), dim=-2)
             v = torch.cat((cv, v), dim=-2)
-        sim = torch.einsum("bhid,bjd->bhij", q, k)
+        q, k, sim_scale = self.similarity_inputs(q, k)
+        sim = torch.einsum("bhid,bjd->bhij", q, k) * sim_scale
         attn = sim.softmax(dim=-1, dtype=torch.float32)
         out = torch.einsum("bhij,bjd->bhid", attn, v)
         out = out.permute(0, 2, 1, 3).reshape(b, n, -1)
         return self.to_out(out)
 
 
-class CrossAttention(nn.Module):
+class CrossAttention(nn.Module, _QKNorm):
     """Multi-head cross attention of feature tokens to the conditioning tokens."""
 
     def __init__(self, dim, *, context_dim=None, dim_head=64, heads=8):
@@ -226,8 +253,8 @@ class CrossAttention(nn.Module):
         nk, nv = self.null_kv.unbind(dim=-2)
         k = torch.cat((nk.expand(b, h, 1, -1), k), dim=-2)
         v = torch.cat((nv.expand(b, h, 1, -1), v), dim=-2)
-        q = q * self.scale
-        sim = torch.einsum("bhid,bhjd->bhij", q, k)
+        q, k, sim_scale = self.similarity_inputs(q, k)
+        sim = torch.einsum("bhid,bhjd->bhij", q, k) * sim_scale
         attn = sim.softmax(dim=-1, dtype=torch.float32)
         out = torch.einsum("bhij,bhjd->bhid", attn, v)
         out = out.permute(0, 2, 1, 3).reshape(b, n, -1)
@@ -264,9 +291,10 @@ class TransformerBlock(nn.Module):
         return x.reshape(b, h, w, c).permute(0, 3, 1, 2)
 
 
-class PerceiverAttention(nn.Module):
+class PerceiverAttention(nn.Module, _QKNorm):
     def __init__(self, *, dim, dim_head=64, heads=8):
         super().__init__()
+        self.dim_head = dim_head
         self.scale = dim_head ** -0.5
         self.heads = heads
         inner = dim_head * heads
@@ -285,8 +313,8 @@ class PerceiverAttention(nn.Module):
         k, v = self.to_kv(kv_input).chunk(2, dim=-1)
         split = lambda t: t.reshape(b, t.shape[1], h, -1).permute(0, 2, 1, 3)
         q, k, v = split(q), split(k), split(v)
-        q = q * self.scale
-        sim = torch.einsum("bhid,bhjd->bhij", q, k)
+        q, k, sim_scale = self.similarity_inputs(q, k)
+        sim = torch.einsum("bhid,bhjd->bhij", q, k) * sim_scale
         attn = sim.softmax(dim=-1, dtype=torch.float32)
         out = torch.einsum("bhij,bhjd->bhid", attn, v)
         out = out.permute(0, 2, 1, 3).reshape(b, q.shape[2], -1)
@@ -411,7 +439,7 @@ class Unet(nn.Module):
         init_cross_embed_kernel_sizes=(3, 7, 15), attn_pool_text=True,
         attn_pool_num_latents=32, memory_efficient=False,
         init_conv_to_final_conv_residual=False, use_global_context_attn=True,
-        scale_skip_connection=True, final_conv_kernel_size=3,
+        scale_skip_connection=True, final_conv_kernel_size=3, cosine_sim_attn=False, attn_qk_norm=None,
     ):
         super().__init__()
         self._locals = {k: v for k, v in locals().items() if k not in ("self", "__class__")}
@@ -553,6 +581,25 @@ class Unet(nn.Module):
                                     padding=final_conv_kernel_size // 2)
         nn.init.zeros_(self.final_conv.weight)
         nn.init.zeros_(self.final_conv.bias)
+        self.attn_qk_norm = 0
+        self.set_attn_qk_norm(int(attn_qk_norm) if exists(attn_qk_norm) else (1 if cosine_sim_attn else 0))
+
+    # attention similarity switch (class _QKNorm): constructor kwarg, or taken from a checkpoint's key set
+    def set_attn_qk_norm(self, mode):
+        assert mode in (0, 1, 2)
+        self.attn_qk_norm = mode
+        self._locals["attn_qk_norm"] = mode
+        for m in self.modules():
+            if isinstance(m, _QKNorm):
+                m.set_qk_norm(mode)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        has = any(k.startswith(prefix) and k.endswith(".q_scale") for k in state_dict)
+        if has and self.attn_qk_norm != 2:
+            self.set_attn_qk_norm(2)
+        elif not has and self.attn_qk_norm == 2 and any(k.startswith(prefix) for k in state_dict):
+            self.set_attn_qk_norm(0)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     # Imagen re-creates each Unet with the cascade-dependent kwargs
     def cast_model_parameters(self, *, lowres_cond, text_embed_dim, channels, channels_out,

@@ -452,3 +452,48 @@ def test_full_size_sr_unet_is_deterministic_and_batch_independent(device):
     E.check(E.load().kd_unet_profile(u.engine(3, S, device, with_text=False), 1, buf, len(buf), E.current_stream()))
     assert "wino" not in buf.value.decode()
     assert H.rel_l2(direct, full) < FWD_REL_L2
+
+
+# ------------------------------------------------------------------------------- attention similarity variants
+@pytest.mark.parametrize("mode", [1, 2])
+def test_qk_norm_attention_variants_match_oracle(device, mode):
+    """The library changed its attention similarity between versions and 1.18.5 cannot be inspected
+    here, so both alternatives to the default are built and switchable: 1 = `cosine_sim_attn=True` (l2-normalised
+    q / k, x16), 2 = learned q_scale / k_scale (x8), selected by the checkpoint's key set.  Self-attention (with
+    context and null keys), cross-attention and the text pooling attention against the oracle."""
+    import imagen_pytorch as ip
+    from oracle import imagen_ref as R
+
+    # (a) ultra-res base UNet: self-attention with context at three levels + cross-attention in the res-blocks
+    kw = dict(H.UNET_KW["ultra1"])
+    ou = H.randomize_(R.Unet(**kw, cond_on_text=False, text_embed_dim=None, attn_qk_norm=mode), 31).eval()
+    plain = {k: v for k, v in ou._locals.items() if k != "attn_qk_norm"}
+    pu = ip.Unet(**plain, **({"cosine_sim_attn": True} if mode == 1 else {}))   # mode 2 comes from the key set
+    pu.load_state_dict(ou.state_dict(), strict=True)
+    assert pu.attn_qk_norm == mode
+    pu = pu.to(device)
+    x, lr, cond, t, tl = _inputs("ultra1", 2, 32, False)
+    with torch.no_grad():
+        ref = ou(x, t, cond_images=cond)
+        ref0 = R.Unet(**kw, cond_on_text=False, text_embed_dim=None)
+        ref0.load_state_dict({k: v for k, v in ou.state_dict().items() if "_scale" not in k})
+        base = ref0.eval()(x, t, cond_images=cond)
+    dv = lambda v: None if v is None else v.to(device)
+    got = pu(dv(x), dv(t), cond_images=dv(cond))
+    assert H.rel_l2(got, ref) < FWD_REL_L2, H.rel_l2(got, ref)
+    assert H.rel_l2(ref, base) > 1e-3, "the variant must actually change the function"
+    # (b) text-conditioned UNet: the PerceiverResampler attention takes the same switch
+    ou = H.randomize_(R.Unet(**SEG_KW, cond_on_text=True, attn_qk_norm=mode), 32).eval()
+    pu = ip.Unet(**{k: v for k, v in ou._locals.items() if k != "attn_qk_norm"}, attn_qk_norm=mode)
+    pu.load_state_dict(ou.state_dict(), strict=True)
+    pu = pu.to(device)
+    B, S = 2, 16
+    g = torch.Generator().manual_seed(2)
+    x, t = torch.randn(B, 3, S, S, generator=g), torch.randn(B, generator=g)
+    text = torch.tensor([0.0, 0.5, 0.2]).reshape(1, 1, 3).repeat_interleave(B, dim=0)
+    mask = torch.any(text != 0.0, dim=-1)
+    labels = torch.nn.functional.one_hot(torch.randint(0, 4, (B, S, S), generator=g), 4).permute(0, 3, 1, 2).float()
+    with torch.no_grad():
+        ref = ou(x, t, text_embeds=text, text_mask=mask, cond_images=labels)
+    got = pu(dv(x), dv(t), text_embeds=dv(text), text_mask=dv(mask), cond_images=dv(labels))
+    assert H.rel_l2(got, ref) < FWD_REL_L2, H.rel_l2(got, ref)
