@@ -56,11 +56,19 @@ struct ConvParams {
   // ksplit is filled in by launch_conv_igemm
   float* partial;
   int ksplit;
+  // GroupNorm partials of the output for the layer that reads it (SegSrc): [B][seg_nseg][seg chunks][2] doubles with
+  // segment (yoff + n - seg_c0) / 16; chunks: Ho*Wo/32 MFMA row tiles per image (x 4 sub-positions for OUT_PIXSHUF).
+  // Needs Ho*Wo % 32 == 0, Cout % 16 == 0, yoff % 16 == 0, no split-K.  nullptr = off.
+  double* seg_partial;
+  int seg_nseg;
+  int seg_c0;  // channel of y that is segment 0 of seg_partial (several launches can fill slices of one buffer)
 };
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s);
 // number of K splits launch_conv_igemm uses for this shape when `partial` is provided (1 = none)
 int conv_ksplit(const ConvParams& p);
+// chunks per image of the GroupNorm partials the launch can leave (ConvParams::seg_partial), 0 = it cannot
+int conv_seg_chunks(const ConvParams& p);
 int64_t conv_macs(const ConvParams& p);
 
 // weight re-packing (device→device)
@@ -126,9 +134,25 @@ int launch_layernorm(const float* x, const float* g, const float* beta, const fl
 // y[row] = [a[row] | b[row] * scale_b]; a == nullptr: only the b half is written (a's producer wrote in place)
 int launch_concat2(const float* a, int Ca, const float* b, int Cb, float scale_b, float* y, int64_t rows,
                    hipStream_t s);
-// y = a*gate[b][c] + r   (NHWC, rows = B*HW)
-int launch_gate_add(const float* a, const float* gate, const float* r, float* y, int B, int HW, int C,
-                    hipStream_t s);
+// y = a*gate[b][c] + r   (NHWC; a dense, r / y with row strides ldr / ldy); seg: optional segment partials of y,
+// [B][C/16][gate_add_chunks(B, HW)][2] doubles (SegSrc below)
+int launch_gate_add(const float* a, const float* gate, const float* r, int ldr, float* y, int ldy, double* seg, int B,
+                    int HW, int C, hipStream_t s);
+int gate_add_chunks(int B, int HW);
+
+// GroupNorm statistics handed from the kernel that WRITES a map to the layer that normalises it: (sum, sum of
+// squares) in fp64 per image, 16-channel segment and producer-defined chunk, [B][nseg][nchunk][2].  Producers:
+// launch_gate_add, the conv epilogues (ConvParams::seg_partial), launch_wino_fused_gn (out_partial).
+struct SegSrc {
+  const double* partial;  // nullptr: unused
+  int nseg, nchunk;
+  int c0;                 // first channel of the normalised tensor this source covers
+  float scale;            // the GroupNorm sees scale * x (skip connections: 2^-1/2)
+  float ab_mul;           // factor folded into the affine's A for these channels (scale if the consumer reads x unscaled)
+};
+// stats [B][G][2] (mean, rstd) and / or ab [B][C][2] (launch_gn_fold's affine) from one or two sources
+int launch_gn_fold_seg(SegSrc s0, SegSrc s1, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
+                       float* ab, float* stats, int B, int C, int G, double count, float eps, hipStream_t s);
 int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s);
 int launch_act(const float* a, float* y, int64_t n, int act, hipStream_t s);
 // init image assembly: NCHW planes -> NHWC [B][H][W][Cpad] with channel order cond | x | lowres, zero pad

@@ -286,7 +286,77 @@ struct Builder {
     if (--it->second == 0) {
       refs.erase(it);
       arena.release(t.off);
+      drop_seg(t.off);
     }
+  }
+  // ---- GroupNorm partials handed from the kernel that writes a map to the layer that normalises it (SegSrc,
+  // common.h): per tensor (keyed by its workspace offset) up to two channel ranges with their partial buffers.
+  // KD_SEG_STATS=0 keeps the separate statistics passes (A/B, read per plan).
+  struct SegPart {
+    size_t off = 0;   // partial buffer [B][nseg][nchunk][2] doubles
+    int nseg = 0, nchunk = 0, c0 = 0;
+    float scale = 1.0f, ab_mul = 1.0f;
+  };
+  std::unordered_map<size_t, std::vector<SegPart>> seg_of;
+  const bool seg_on = !(getenv("KD_SEG_STATS") && atoi(getenv("KD_SEG_STATS")) == 0);
+  void drop_seg(size_t tensor_off) {
+    auto it = seg_of.find(tensor_off);
+    if (it == seg_of.end()) return;
+    for (auto& sp : it->second) arena.release(sp.off);
+    seg_of.erase(it);
+  }
+  // reserves the partial buffer of channels [c0, c0 + 16 nseg) of tensor t; returns its workspace offset
+  size_t add_seg(const T& t, int c0, int nseg, int nchunk, float scale = 1.0f, float ab_mul = 1.0f) {
+    SegPart sp;
+    sp.off = arena.alloc((size_t)t.B * nseg * nchunk * 2 * sizeof(double));
+    sp.nseg = nseg; sp.nchunk = nchunk; sp.c0 = c0; sp.scale = scale; sp.ab_mul = ab_mul;
+    seg_of[t.off].push_back(sp);
+    return sp.off;
+  }
+  // the sources covering ALL C channels of x in order (at most two), or false
+  bool seg_sources(const T& x, SegPart (&out)[2], int& n) const {
+    n = 0;
+    if (!seg_on || x.C % cfg.resnet_groups || (x.C / cfg.resnet_groups) % 16) return false;
+    auto it = seg_of.find(x.off);
+    if (it == seg_of.end()) return false;
+    std::vector<SegPart> v = it->second;
+    std::sort(v.begin(), v.end(), [](const SegPart& a, const SegPart& b) { return a.c0 < b.c0; });
+    int c = 0;
+    for (auto& sp : v) {
+      if (sp.c0 != c || n == 2) return false;
+      out[n++] = sp;
+      c += 16 * sp.nseg;
+    }
+    return c == x.C;
+  }
+  // emits the GroupNorm statistics of x into gn_stats_t - from the producer's partials when x has them (then
+  // `ab` != nullptr also gets the folded affine in the same launch and true is returned), else by a pass over x
+  bool emit_gn_stats(const T& x, const float* gamma, const float* beta, int ss_col, const T* ab) {
+    const int G = cfg.resnet_groups, Bx = x.B, HW = x.HW(), C = x.C;
+    SegPart sp[2];
+    int n = 0;
+    kd_unet* uu = u;
+    const size_t so = gn_stats_t.off, sso = t_ss.off;
+    const int ld = tmlp_total;
+    if (seg_sources(x, sp, n)) {
+      const SegPart a = sp[0], b2 = n > 1 ? sp[1] : SegPart();
+      const bool two = n > 1, has_ab = ab != nullptr;
+      const size_t abo = has_ab ? ab->off : 0;
+      emit([=](hipStream_t s) {
+        SegSrc s0{(const double*)uu->P(a.off), a.nseg, a.nchunk, a.c0, a.scale, a.ab_mul};
+        SegSrc s1{two ? (const double*)uu->P(b2.off) : nullptr, b2.nseg, b2.nchunk, b2.c0, b2.scale, b2.ab_mul};
+        const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
+        return launch_gn_fold_seg(s0, s1, gamma, beta, ssp, ld, has_ab ? uu->P(abo) : nullptr, uu->P(so), Bx, C, G,
+                                  (double)HW * (C / G), 1e-5f, s);
+      }, "gn fold seg HW" + std::to_string(HW) + " C" + std::to_string(C));
+      return has_ab;
+    }
+    if (gn_partial_bytes(Bx, HW, C, G) > gn_partial_max) throw std::runtime_error("gn partial scratch too small");
+    const size_t xo = x.off, po = gn_partial_t.off;
+    emit([=](hipStream_t s) {
+      return launch_gn_stats(uu->P(xo), C, uu->P(so), (double*)uu->P(po), Bx, HW, C, G, 1e-5f, s);
+    }, "gn stats HW" + std::to_string(HW) + " C" + std::to_string(C));
+    return false;
   }
   bool to_text = false;    // building the text-conditioning sub-plan: ops go to u->text_ops
   bool to_static = false;  // emitting step-invariant work (run once per sampling call): u->static_ops
@@ -321,6 +391,9 @@ struct Builder {
     int res_coff = 0;           // channel offset into res (res row stride stays res->C)
     int64_t macs_override = -1; // algorithmic MACs when the launch computes padded / re-associated work
     int wz_rows = 0;            // batched 1x1 GEMM over 16 Winograd positions (ConvParams::wz_rows)
+    bool want_seg = false;      // the output feeds a GroupNorm: leave its partials in the epilogue where possible
+    int seg_c0 = -1, seg_cn = 0;  // channel range of y the partial buffer spans (default: this launch's own range);
+                                  // launches filling slices of one tensor name the same span and share the buffer
   };
   T conv(const T& x, const float* w, const float* bias, int Cout, int K, int stride, int pad, const ConvOpt& o) {
     int Ho = (x.H + 2 * pad - K) / stride + 1, Wo = (x.W + 2 * pad - K) / stride + 1;
@@ -363,6 +436,29 @@ struct Builder {
     T part;
     if (ks > 1) part = alloc_bytes((size_t)ks * x.B * Ho * Wo * Cout * sizeof(float));
     const size_t parto = part.off;
+    // GroupNorm partials of the output, left by the epilogue (channels [yoff, yoff + Cout) of y, or the Cout / 4
+    // shuffled channels): several launches filling slices of one tensor (init conv) share the chunk count
+    size_t sego = 0;
+    int seg_nseg = 0, seg_c0 = 0;
+    if (o.want_seg && seg_on && !ext && !to_text && !to_static && ks == 1) {
+      const int cw = o.out_mode == OUT_PIXSHUF ? Cout / 4 : Cout;
+      seg_c0 = o.seg_c0 >= 0 ? o.seg_c0 : o.yoff;
+      const int span = o.seg_c0 >= 0 ? o.seg_cn : cw;
+      ConvParams probe = p;
+      probe.res = has_res ? (const float*)16 : nullptr;
+      probe.gate_src = has_gs ? (const float*)16 : nullptr;
+      probe.seg_c0 = seg_c0;
+      const int nchunk = conv_seg_chunks(probe);
+      if (nchunk > 0 && cw % 16 == 0 && span % 16 == 0 && o.yoff >= seg_c0 && o.yoff + cw <= seg_c0 + span) {
+        SegPart* have = nullptr;
+        auto it = seg_of.find(y.off);
+        if (it != seg_of.end())
+          for (auto& sp : it->second)
+            if (sp.c0 == seg_c0 && sp.nseg == span / 16 && sp.nchunk == nchunk) have = &sp;
+        seg_nseg = span / 16;
+        sego = have ? have->off : add_seg(y, seg_c0, seg_nseg, nchunk);
+      }
+    }
     emit([=](hipStream_t s) {
       ConvParams q = p;
       q.x = uu->P(xo);
@@ -371,6 +467,11 @@ struct Builder {
       q.gate_src = has_gs ? uu->P(gso) : nullptr;
       q.gate = has_gs ? uu->P(go) : nullptr;
       q.partial = ks > 1 ? uu->P(parto) : nullptr;
+      if (seg_nseg) {
+        q.seg_partial = (double*)uu->P(sego);
+        q.seg_nseg = seg_nseg;
+        q.seg_c0 = seg_c0;
+      }
       return launch_conv_igemm(q, s);
     });
     if (ks > 1) free(part);
@@ -430,20 +531,21 @@ struct Builder {
     return y;
   }
 
-  T gn_silu(const T& x, const std::string& prefix, const float* ss, int ld_ss) {
+  // GroupNorm -> [FiLM: scale/shift rows of t_ss at column ss_col] -> SiLU as its own pass (layers the fused conv
+  // does not take)
+  T gn_silu(const T& x, const std::string& prefix, int ss_col) {
     const float* gamma = P(prefix + ".weight", x.C);
     const float* beta = P(prefix + ".bias", x.C);
     int G = cfg.resnet_groups;
     T y = alloc(x.B, x.H, x.W, x.C);
-    size_t pb = gn_partial_bytes(x.B, x.HW(), x.C, G);
-    if (pb > gn_partial_max) throw std::runtime_error("gn partial scratch too small");
-    size_t xo = x.off, yo = y.off, so = gn_stats_t.off, po = gn_partial_t.off;
-    int Bx = x.B, HW = x.HW(), C = x.C;
+    emit_gn_stats(x, gamma, beta, ss_col, nullptr);
+    size_t xo = x.off, yo = y.off, so = gn_stats_t.off, sso = t_ss.off;
+    int Bx = x.B, HW = x.HW(), C = x.C, ld = tmlp_total;
     kd_unet* uu = u;
     emit([=](hipStream_t s) {
-      if (launch_gn_stats(uu->P(xo), C, uu->P(so), (double*)uu->P(po), Bx, HW, C, G, 1e-5f, s)) return 1;
-      return launch_gn_apply_silu(uu->P(xo), C, uu->P(so), gamma, beta, ss, ld_ss, uu->P(yo), Bx, HW, C, G, s);
-    }, "gn HW" + std::to_string(HW) + " C" + std::to_string(C));
+      const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
+      return launch_gn_apply_silu(uu->P(xo), C, uu->P(so), gamma, beta, ssp, ld, uu->P(yo), Bx, HW, C, G, s);
+    }, "gn apply HW" + std::to_string(HW) + " C" + std::to_string(C));
     return y;
   }
 
@@ -620,7 +722,6 @@ struct Builder {
     const float* wsrc = raw(conv_prefix + ".weight", (int64_t)Cout * Cin * 9);
     float* U = cached("wino:" + conv_prefix, (size_t)16 * Cout * Cin,
                       [&](float* dst) { KD_THROW_IF(launch_wino_pack(wsrc, dst, Cout, Cin, 0)); });
-    if (gn_partial_bytes(Bx, HW, Cin, G) > gn_partial_max) throw std::runtime_error("gn partial scratch too small");
     // The map can be walked in slices of tiles (V and D are 4x the slice each) to bound the workspace:
     // KD_WINO_SLICE_MB caps V+D per slice.  Default: one slice - slices small enough to stay in the
     // 256 MB Infinity Cache were measured and are slower (56.5 ms/step unsliced, 59.3 at 96 MB,
@@ -631,13 +732,7 @@ struct Builder {
       nt_slice = (slice_mb << 20) / (64 * (int64_t)(Cin + Cout)) / 256 * 256;
       nt_slice = std::min(Mt, std::max<int64_t>(nt_slice, 256));
     }
-    {
-      size_t xo = x.off, so = gn_stats_t.off, po = gn_partial_t.off;
-      kd_unet* uu = u;
-      emit([=](hipStream_t s) {
-        return launch_gn_stats(uu->P(xo), Cin, uu->P(so), (double*)uu->P(po), Bx, HW, Cin, G, 1e-5f, s);
-      }, "gn stats HW" + std::to_string(HW) + " C" + std::to_string(Cin));
-    }
+    emit_gn_stats(x, gamma, beta, ss_col, nullptr);
     T V = alloc(1, 1, (int)(16 * nt_slice), Cin);
     T D = alloc(1, 1, (int)(16 * nt_slice), Cout);
     T y = alloc(Bx, H, W, Cout);
@@ -723,51 +818,37 @@ struct Builder {
     const bool on = !getenv("KD_FWINO_GN") || atoi(getenv("KD_FWINO_GN")) != 0;
     return on && x.C <= 512 && x.C % cfg.resnet_groups == 0 && fwino_ok(x, cout);
   }
-  // stats_in: (sum, sum of squares) partials of x left by the kernel that produced it (then no statistics pass
-  // over x); stats_out: leave such partials of y for the next layer (fwino_stats_bytes)
-  size_t fwino_stats_bytes(const T& y) const {
-    return (size_t)y.B * cfg.resnet_groups * wino_fused_out_stats_chunks(y.H, y.W, y.C, cfg.resnet_groups) * 2 *
-           sizeof(double);
-  }
   T fwino_gn_conv(const T& x, const std::string& gn_prefix, int ss_col, const std::string& conv_prefix, int Cout,
-                  const T* res, const T* stats_in = nullptr, const T* stats_out = nullptr) {
-    const int Cin = x.C, G = cfg.resnet_groups, Bx = x.B, H = x.H, W = x.W, HW = x.HW();
+                  const T* res) {
+    const int Cin = x.C, G = cfg.resnet_groups, Bx = x.B, H = x.H, W = x.W;
     const float* gamma = P(gn_prefix + ".weight", Cin);
     const float* beta = P(gn_prefix + ".bias", Cin);
     const float* bias = P(conv_prefix + ".bias", Cout);
     const float* wsrc = raw(conv_prefix + ".weight", (int64_t)Cout * Cin * 9);
     float* U = cached("winof:" + conv_prefix, (size_t)16 * Cout * Cin,
                       [&](float* dst) { KD_THROW_IF(launch_wino_fused_pack(wsrc, dst, Cout, Cin, 0)); });
-    if (gn_partial_bytes(Bx, HW, Cin, G) > gn_partial_max) throw std::runtime_error("gn partial scratch too small");
     T ab = alloc_bytes((size_t)Bx * Cin * 2 * sizeof(float));
     T y = alloc(Bx, H, W, Cout);
     kd_unet* uu = u;
-    {
-      size_t xo = x.off, so = gn_stats_t.off, po = gn_partial_t.off, sso = t_ss.off, abo = ab.off;
+    // statistics: from the partials x's producer left (one launch gives the folded affine too), else a pass over x
+    if (!emit_gn_stats(x, gamma, beta, ss_col, &ab)) {
+      size_t so = gn_stats_t.off, sso = t_ss.off, abo = ab.off;
       const int ld = tmlp_total;
-      const bool have = stats_in != nullptr;
-      const size_t pin = have ? stats_in->off : 0;
-      const int chunks_in = have ? (int)wino_fused_out_stats_chunks(H, W, Cin, G) : 0;
       emit([=](hipStream_t s) {
-        if (have) {
-          if (launch_gn_finalize((const double*)uu->P(pin), uu->P(so), chunks_in, Bx, G, (double)HW * (Cin / G), 1e-5f, s))
-            return 1;
-        } else if (launch_gn_stats(uu->P(xo), Cin, uu->P(so), (double*)uu->P(po), Bx, HW, Cin, G, 1e-5f, s)) {
-          return 1;
-        }
         const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
         return launch_gn_fold(uu->P(so), gamma, beta, ssp, ld, uu->P(abo), Bx, Cin, G, s);
-      }, std::string(have ? "gn fold HW" : "gn stats HW") + std::to_string(HW) + " C" + std::to_string(Cin));
+      }, "gn fold C" + std::to_string(Cin));
     }
+    // the epilogue leaves the partials of y for whichever GroupNorm reads it next (block2, or the next block)
+    const bool so_ = seg_on && Cout % 16 == 0 && !(getenv("KD_FWINO_STATS") && atoi(getenv("KD_FWINO_STATS")) == 0);
+    const size_t pout = so_ ? add_seg(y, 0, Cout / 16, (int)wino_fused_out_stats_chunks(H, W, Cout, Cout / 16)) : 0;
     size_t xo = x.off, yo = y.off, ro = res ? res->off : 0, abo = ab.off;
     const bool hr = res != nullptr;
     const int ldres = res ? res->C : 0;
     const int64_t m = (int64_t)Bx * H * W * Cout * Cin * 9;
-    const bool so_ = stats_out != nullptr;
-    const size_t pout = so_ ? stats_out->off : 0;
     emit([=](hipStream_t s) {
       return launch_wino_fused_gn(uu->P(xo), uu->P(abo), U, bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W,
-                                  Cin, Cout, so_ ? (double*)uu->P(pout) : nullptr, so_ ? G : 0, s);
+                                  Cin, Cout, so_ ? (double*)uu->P(pout) : nullptr, so_ ? Cout / 16 : 0, s);
     }, "wino fused M" + std::to_string((int64_t)Bx * H * W) + " Cin" + std::to_string(Cin) + " Cout" +
            std::to_string(Cout), m);
     free(ab);
@@ -788,24 +869,13 @@ struct Builder {
     bool has_cross = has(pre + ".cross_attn.to_q.weight");
     if (has_cross && !ctx) throw std::runtime_error("cross-attention block without conditioning tokens: " + pre);
     int dim_in = x.C;
-    T h, h_stats;
-    bool have_h_stats = false;
+    T h;
     if (wino_ok(x, dim_out)) {
       h = wino_block(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
     } else if (fwino_gn_ok(x, dim_out)) {
-      // block2's GroupNorm reads exactly this conv's output (no cross-attention in between): the conv leaves
-      // the statistics partials in its epilogue
-      T probe = x;
-      probe.C = dim_out;
-      if (!has_cross && (dim_out / cfg.resnet_groups) % 16 == 0 && fwino_gn_ok(probe, dim_out) &&
-          !(getenv("KD_FWINO_STATS") && atoi(getenv("KD_FWINO_STATS")) == 0)) {
-        h_stats = alloc_bytes(fwino_stats_bytes(probe));
-        have_h_stats = true;
-      }
-      h = fwino_gn_conv(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr, nullptr,
-                        have_h_stats ? &h_stats : nullptr);
+      h = fwino_gn_conv(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
     } else {
-      T y1 = gn_silu(x, pre + ".block1.groupnorm", nullptr, 0);
+      T y1 = gn_silu(x, pre + ".block1.groupnorm", -1);
       if (fwino_ok(y1, dim_out))
         h = fwino_conv(y1, pre + ".block1.project", dim_out, nullptr);
       else
@@ -828,29 +898,13 @@ struct Builder {
       free(h);
     } else if (fwino_gn_ok(h, dim_out)) {
       h2 = fwino_gn_conv(h, pre + ".block2.groupnorm", ss_col, pre + ".block2.project", dim_out,
-                         (!use_gca && !has_res_conv) ? &x : nullptr, have_h_stats ? &h_stats : nullptr);
+                         (!use_gca && !has_res_conv) ? &x : nullptr);
       free(h);
-      if (have_h_stats) {
-        free(h_stats);
-        have_h_stats = false;
-      }
     } else {
-      T y2;
-      // scale/shift rows live in t_ss at column ss_col (row stride tmlp_total)
-      const float* gamma = P(pre + ".block2.groupnorm.weight", dim_out);
-      const float* beta = P(pre + ".block2.groupnorm.bias", dim_out);
-      int G = cfg.resnet_groups;
-      y2 = alloc(h.B, h.H, h.W, dim_out);
-      size_t xo = h.off, yo = y2.off, so = gn_stats_t.off, po = gn_partial_t.off, sso = t_ss.off;
-      int Bx = h.B, HW = h.HW(), C = dim_out, ld = tmlp_total;
-      kd_unet* uu = u;
-      emit([=](hipStream_t s) {
-        if (launch_gn_stats(uu->P(xo), C, uu->P(so), (double*)uu->P(po), Bx, HW, C, G, 1e-5f, s)) return 1;
-        const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
-        return launch_gn_apply_silu(uu->P(xo), C, uu->P(so), gamma, beta, ssp, ld, uu->P(yo), Bx, HW, C, G, s);
-      }, "gn HW" + std::to_string(HW) + " C" + std::to_string(C));
+      T y2 = gn_silu(h, pre + ".block2.groupnorm", ss_col);
       ConvOpt o2;
       if (!use_gca && !has_res_conv) o2.res = &x;  // h2 + x folded into the conv epilogue
+      o2.want_seg = true;
       free(h);
       if (fwino_ok(y2, dim_out))
         h2 = fwino_conv(y2, pre + ".block2.project", dim_out, o2.res);
@@ -859,7 +913,6 @@ struct Builder {
                   P(pre + ".block2.project.bias", dim_out), dim_out, 3, 1, 1, o2);
       free(y2);
     }
-    if (have_h_stats) free(h_stats);   // (only if block2 did not take the fused path after all)
     if (!use_gca && !has_res_conv) return h2;
     T out;
     if (use_gca) {
@@ -868,6 +921,7 @@ struct Builder {
         ConvOpt o;
         o.gate_src = &h2;
         o.gate = &gate;
+        o.want_seg = true;
         if (ct) o.dst = ct;
         out = conv(x, P(pre + ".res_conv.weight", (int64_t)dim_out * dim_in), P(pre + ".res_conv.bias", dim_out),
                    dim_out, 1, 1, 0, o);
@@ -875,15 +929,19 @@ struct Builder {
         out = alloc(x.B, x.H, x.W, dim_out);
         size_t ao = h2.off, go = gate.off, ro = x.off, yo = out.off;
         int Bx = x.B, HW = x.HW();
+        const bool sg = seg_on && dim_out % 16 == 0;   // GroupNorm partials of `out` for the block that reads it
+        const size_t sgo = sg ? add_seg(out, 0, dim_out / 16, gate_add_chunks(Bx, HW)) : 0;
         kd_unet* uu = u;
         emit([=](hipStream_t s) {
-          return launch_gate_add(uu->P(ao), uu->P(go), uu->P(ro), uu->P(yo), Bx, HW, dim_out, s);
+          return launch_gate_add(uu->P(ao), uu->P(go), uu->P(ro), dim_out, uu->P(yo), dim_out,
+                                 sg ? (double*)uu->P(sgo) : nullptr, Bx, HW, dim_out, s);
         }, "gate_add HW" + std::to_string(HW) + " C" + std::to_string(dim_out));
       }
       free(gate);
     } else {  // res_conv without gca: out = conv1x1(x) + h2
       ConvOpt o;
       o.res = &h2;
+      o.want_seg = true;
       if (ct) o.dst = ct;
       out = conv(x, P(pre + ".res_conv.weight", (int64_t)dim_out * dim_in), P(pre + ".res_conv.bias", dim_out),
                  dim_out, 1, 1, 0, o);
@@ -897,7 +955,9 @@ struct Builder {
     const int C = x.C;
     float* w = cached("unshuffle:" + pre, (size_t)dim_out * 4 * C,
                       [&](float* dst) { KD_THROW_IF(launch_pack_unshuffle(src, dst, dim_out, C, 0)); });
-    return conv(x, w, P(pre + ".1.bias", dim_out), dim_out, 2, 2, 0, ConvOpt());
+    ConvOpt o;
+    o.want_seg = true;   // feeds the GroupNorm of the level's first ResnetBlock
+    return conv(x, w, P(pre + ".1.bias", dim_out), dim_out, 2, 2, 0, o);
   }
   T upsample(const T& x, const std::string& pre, int dim_out, const T* ct = nullptr) {  // conv1x1 -> SiLU -> PixelShuffle(2)
     const float* wsrc = raw(pre + ".net.0.weight", (int64_t)4 * dim_out * x.C);
@@ -912,6 +972,7 @@ struct Builder {
     ConvOpt o;
     o.act = ACT_SILU;
     o.out_mode = OUT_PIXSHUF;
+    o.want_seg = true;
     if (ct) o.dst = ct;   // straight into the first dim_out channels of the following skip concat
     return conv(x, w, b, 4 * dim_out, 1, 1, 0, o);
   }

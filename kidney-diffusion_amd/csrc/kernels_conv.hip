@@ -126,7 +126,28 @@ __device__ __forceinline__ void store_tile(const ConvParams& p, float* lds,
 // row: every global store / residual / gate read is a full 128-B line, with no LDS round trip and no
 // barriers (measured against store_tile on the Winograd GEMMs: +5..9 %).  bias and the per-image gate
 // are one scalar per lane.  Needs hw_o % 32 == 0 when a gate is applied (one image per 32-row MFMA tile).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool GATE, bool RES, bool ACT>
+// GroupNorm partials of the stored tile for the layer that reads the map (ConvParams::seg_partial, SegSrc in
+// common.h): (s1, s2) = this lane's sum / sum of squares over its 16 rows of one channel; the 16 lanes x 2
+// half-waves of a 16-channel segment are folded with shuffles and lanes 0 / 16 write the segment's partial of
+// this 32-row tile (chunk).  All 64 lanes call it (shuffles); `valid` masks columns past Cout.
+__device__ __forceinline__ void seg_partial_store(double* __restrict__ seg, int nseg, int64_t nchunk, int64_t b,
+                                                  int64_t chunk, int ch, bool valid, double s1, double s2) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int off = 1; off <= 8; off <<= 1) {
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+  }
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  if ((lane & 47) == 0 && valid) {   // lanes 0 and 16
+    double* o = seg + ((b * nseg + (ch >> 4)) * nchunk + chunk) * 2;
+    o[0] = s1;
+    o[1] = s2;
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool GATE, bool RES, bool ACT, bool STATS>
 __device__ __forceinline__ void store_tile_regs_impl(const ConvParams& p,
                                                      f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                                      int64_t m0, int n0, int64_t M) {
@@ -138,29 +159,40 @@ __device__ __forceinline__ void store_tile_regs_impl(const ConvParams& p,
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-    if (n >= p.Cout) continue;
-    const float bias = p.bias ? p.bias[n] : 0.f;
+    const bool n_ok = n < p.Cout;
+    if (!STATS && !n_ok) continue;
+    if (STATS && n0 + (wn * TN + j) * 32 >= p.Cout) continue;   // wave-uniform: the whole column block is outside
+    const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int64_t mt = m0 + (wm * TM + i) * 32;  // first row of this 32x32 MFMA tile
       if (mt >= M) continue;
       float gate = 0.f;
-      if (GATE) gate = p.gate[(mt / hw_o) * p.Cout + n];
+      if (GATE && n_ok) gate = p.gate[(mt / hw_o) * p.Cout + n];
       const int64_t mb = mt + 4 * (lane >> 5);
       float* yp = p.y + mb * p.ldy + p.yoff + n;
       const float* gp = GATE ? p.gate_src + mb * p.ldgs + n : nullptr;
       const float* rp = RES ? p.res + mb * p.ldres + n : nullptr;
       const bool full = mt + 32 <= M;
+      double s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int dr = (r & 3) + 8 * (r >> 2);
-        if (full || mb + dr < M) {
+        if (n_ok && (full || mb + dr < M)) {
           float v = acc[i][j][r] + bias;
           if (ACT) v = act_apply(v, p.act);
           if (GATE) v += gp[(int64_t)dr * p.ldgs] * gate;
           if (RES) v += rp[(int64_t)dr * p.ldres];
           yp[(int64_t)dr * p.ldy] = v;
+          if (STATS) {
+            s1 += (double)v;
+            s2 += (double)v * (double)v;
+          }
         }
+      }
+      if (STATS) {
+        const int64_t b = mt / hw_o;
+        seg_partial_store(p.seg_partial, p.seg_nseg, hw_o >> 5, b, (mt - b * hw_o) >> 5, p.yoff + n - p.seg_c0, n_ok, s1, s2);
       }
     }
   }
@@ -169,7 +201,7 @@ __device__ __forceinline__ void store_tile_regs_impl(const ConvParams& p,
 // PixelShuffle(2) epilogue straight from the registers (upsample convs: weight rows packed n' = (i*2+j)*Co + c).
 // Needs Co % 32 == 0 (the 32 channels of a lane group share (i, j) and stay one 128-B line) and Wo % 32 == 0
 // (the 32 rows of an MFMA tile lie in one image row: one division per tile instead of one per element).
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STATS>
 __device__ __forceinline__ void store_tile_regs_pixshuf(const ConvParams& p,
                                                         f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                                         int64_t m0, int n0, int64_t M) {
@@ -178,11 +210,14 @@ __device__ __forceinline__ void store_tile_regs_pixshuf(const ConvParams& p,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int Co = p.Cout >> 2;
+  const int hw_o = p.Ho * p.Wo;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-    if (n >= p.Cout) continue;
-    const float bias = p.bias ? p.bias[n] : 0.f;
+    const bool n_ok = n < p.Cout;
+    if (!STATS && !n_ok) continue;
+    if (STATS && n0 + (wn * TN + j) * 32 >= p.Cout) continue;
+    const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
     const int q = n / Co, c = n - q * Co;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -191,12 +226,22 @@ __device__ __forceinline__ void store_tile_regs_pixshuf(const ConvParams& p,
       const int64_t row = mt / p.Wo;                 // b * Ho + oy: the whole tile is in this image row
       const int ox0 = (int)(mt - row * p.Wo) + 4 * (lane >> 5);
       float* yp = p.y + ((2 * row + (q >> 1)) * (2 * p.Wo) + 2 * ox0 + (q & 1)) * (int64_t)p.ldy + p.yoff + c;
+      double s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int dr = (r & 3) + 8 * (r >> 2);
         float v = acc[i][j][r] + bias;
         if (p.act != ACT_NONE) v = act_apply(v, p.act);
-        yp[(int64_t)(2 * dr) * p.ldy] = v;
+        if (n_ok) yp[(int64_t)(2 * dr) * p.ldy] = v;
+        if (STATS && n_ok) {
+          s1 += (double)v;
+          s2 += (double)v * (double)v;
+        }
+      }
+      if (STATS) {   // chunk = (input row tile) * 4 + sub-position: each 32-row tile feeds 4 output positions
+        const int64_t b = mt / hw_o;
+        seg_partial_store(p.seg_partial, p.seg_nseg, (int64_t)(hw_o >> 5) * 4, b, ((mt - b * hw_o) >> 5) * 4 + q,
+                          p.yoff + c - p.seg_c0, n_ok, s1, s2);
       }
     }
   }
@@ -208,17 +253,26 @@ __device__ __forceinline__ void store_tile_regs(const ConvParams& p,
                                                 int n0, int64_t M) {
   // the (wave-uniform) epilogue variant is chosen once, outside the unrolled store loops
   const bool act = p.act != ACT_NONE;
+  if (p.seg_partial) {   // output feeds a GroupNorm: the variants that occur in the plans
+    if (p.gate_src)
+      store_tile_regs_impl<BM, BN, WAVES_M, WAVES_N, true, false, false, true>(p, acc, m0, n0, M);
+    else if (p.res)
+      store_tile_regs_impl<BM, BN, WAVES_M, WAVES_N, false, true, false, true>(p, acc, m0, n0, M);
+    else
+      store_tile_regs_impl<BM, BN, WAVES_M, WAVES_N, false, false, false, true>(p, acc, m0, n0, M);
+    return;
+  }
   if (p.gate_src) {
-    store_tile_regs_impl<BM, BN, WAVES_M, WAVES_N, true, false, false>(p, acc, m0, n0, M);  // resblock tail
+    store_tile_regs_impl<BM, BN, WAVES_M, WAVES_N, true, false, false, false>(p, acc, m0, n0, M);  // resblock tail
   } else if (p.res) {
     if (act)
-      store_tile_regs_impl<BM, BN, WAVES_M, WAVES_N, false, true, true>(p, acc, m0, n0, M);
+      store_tile_regs_impl<BM, BN, WAVES_M, WAVES_N, false, true, true, false>(p, acc, m0, n0, M);
     else
-      store_tile_regs_impl<BM, BN, WAVES_M, WAVES_N, false, true, false>(p, acc, m0, n0, M);
+      store_tile_regs_impl<BM, BN, WAVES_M, WAVES_N, false, true, false, false>(p, acc, m0, n0, M);
   } else if (act) {
-    store_tile_regs_impl<BM, BN, WAVES_M, WAVES_N, false, false, true>(p, acc, m0, n0, M);
+    store_tile_regs_impl<BM, BN, WAVES_M, WAVES_N, false, false, true, false>(p, acc, m0, n0, M);
   } else {
-    store_tile_regs_impl<BM, BN, WAVES_M, WAVES_N, false, false, false>(p, acc, m0, n0, M);
+    store_tile_regs_impl<BM, BN, WAVES_M, WAVES_N, false, false, false, false>(p, acc, m0, n0, M);
   }
 }
 
@@ -584,7 +638,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
   } else if (p.out_mode == OUT_NHWC && (!p.gate_src || ((hw & 31) == 0 && !p.res && p.act == ACT_NONE))) {
     store_tile_regs<BM, BN, WAVES_M, WAVES_N>(p, acc, m0, n0, M);
   } else if (p.out_mode == OUT_PIXSHUF && ((p.Cout >> 2) & 31) == 0 && (p.Wo & 31) == 0 && !p.gate_src && !p.res) {
-    store_tile_regs_pixshuf<BM, BN, WAVES_M, WAVES_N>(p, acc, m0, n0, M);
+    if (p.seg_partial)
+      store_tile_regs_pixshuf<BM, BN, WAVES_M, WAVES_N, true>(p, acc, m0, n0, M);
+    else
+      store_tile_regs_pixshuf<BM, BN, WAVES_M, WAVES_N, false>(p, acc, m0, n0, M);
   } else {
     store_tile<BM, BN, WAVES_M, WAVES_N>(p, lds, acc, m0, n0, M);
   }
@@ -649,8 +706,27 @@ int conv_ksplit(const ConvParams& p) {
   return (nchunks + per - 1) / per;
 }
 
+// Chunks per image of the GroupNorm partials this launch can leave in its epilogue (ConvParams::seg_partial), or 0
+// when its epilogue cannot (split-K, the LDS-staged epilogue, ragged shapes): the plan then keeps the statistics pass.
+int conv_seg_chunks(const ConvParams& p) {
+  const int64_t hw = (int64_t)p.Ho * p.Wo, M = (int64_t)p.B * hw;
+  if ((hw & 31) || (p.Cout & 15) || ((p.yoff - p.seg_c0) & 15) || (p.partial && conv_ksplit(p) > 1)) return 0;
+  if (p.out_mode == OUT_NHWC) {
+    if (p.act != ACT_NONE || (p.gate_src && p.res)) return 0;
+    return (int)(hw >> 5);
+  }
+  if (p.out_mode == OUT_PIXSHUF) {
+    const bool fast = fast_shape_ok(p) && M > 64;
+    if (!fast || ((p.Cout >> 2) & 31) || (p.Wo & 31) || p.gate_src || p.res) return 0;
+    return (int)(hw >> 5) * 4;
+  }
+  return 0;
+}
+
 int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
   KD_REQUIRE(p.Cin % 4 == 0 && p.ldx % 4 == 0, "igemm needs Cin and ldx multiples of 4");
+  KD_REQUIRE(!p.seg_partial || (conv_seg_chunks(p) > 0 && p.seg_nseg > 0),
+             "conv: this launch cannot leave GroupNorm partials (see conv_seg_chunks)");
   KD_REQUIRE(((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.w & 15) == 0, "igemm operands must be 16-B aligned");
   if (p.out_mode == OUT_PIXSHUF) KD_REQUIRE(p.Cout % 4 == 0, "pixel-shuffle needs Cout % 4 == 0");
   int64_t M = (int64_t)p.B * p.Ho * p.Wo;

@@ -324,31 +324,161 @@ int launch_concat2(const float* a, int Ca, const float* b, int Cb, float scale_b
   return 0;
 }
 
-__global__ void gate_add_kernel(const float* __restrict__ a, const float* __restrict__ gate,
-                                const float* __restrict__ r, float* __restrict__ y, int64_t HW, int C4,
-                                int64_t total) {
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    int64_t pix = idx / C4;
-    int c4 = (int)(idx - pix * C4);
-    int b = (int)(pix / HW);
-    f32x4 v = *(const f32x4*)(a + idx * 4);
-    f32x4 rr = *(const f32x4*)(r + idx * 4);
-    if (gate) {
-      f32x4 g = *(const f32x4*)(gate + ((int64_t)b * C4 + c4) * 4);
-      v = v * g + rr;
-    } else {
-      v = v + rr;
+// y = a * gate[b][c] + r, NHWC.  r and y may be channel slices of wider tensors (row strides ldr / ldy: a skip
+// tensor that already lives in the buffer of the concat it will be part of).  seg != nullptr: the kernel also
+// leaves the GroupNorm partials of y for the layer that reads it - per image, 16-channel segment and pixel chunk
+// one (sum, sum of squares) in fp64, [B][C/16][gridDim.x][2], summed in a fixed order (launch_gn_fold_seg), so
+// the next GroupNorm needs no statistics pass over y.
+__global__ __launch_bounds__(256) void gate_add_kernel(const float* __restrict__ a, const float* __restrict__ gate,
+                                                       const float* __restrict__ r, int ldr, float* __restrict__ y,
+                                                       int ldy, double* __restrict__ seg, int HW, int C, int rpb) {
+  __shared__ double sh[2][64];
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int C4 = C >> 2;
+  const int Wd = C4 < 256 ? C4 : 256;
+  const int RP = 256 / Wd;
+  const int rsub = threadIdx.x / Wd, col = threadIdx.x - rsub * Wd;
+  const bool active = rsub < RP;
+  const int p0 = chunk * rpb, p1 = min(HW, p0 + rpb);
+  const int nseg = C >> 4, segw = Wd >> 2;
+  for (int c4b = 0; c4b < C4; c4b += Wd) {
+    const int c4 = c4b + col;
+    double s1 = 0.0, s2 = 0.0;
+    if (active && c4 < C4) {
+      f32x4 g = {1.f, 1.f, 1.f, 1.f};
+      if (gate) g = *(const f32x4*)(gate + ((int64_t)b * C4 + c4) * 4);
+      for (int row = p0 + rsub; row < p1; row += RP) {
+        const int64_t pix = (int64_t)b * HW + row;
+        f32x4 v = *(const f32x4*)(a + (pix * C4 + c4) * 4);
+        const f32x4 rr = *(const f32x4*)(r + pix * ldr + c4 * 4);
+        v = v * g + rr;
+        *(f32x4*)(y + pix * ldy + c4 * 4) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double d = (double)v[e];
+          s1 += d;
+          s2 += d * d;
+        }
+      }
     }
-    *(f32x4*)(y + idx * 4) = v;
+    if (seg) {   // (block-uniform)
+      s1 += __shfl_xor(s1, 1, 64);
+      s2 += __shfl_xor(s2, 1, 64);
+      s1 += __shfl_xor(s1, 2, 64);
+      s2 += __shfl_xor(s2, 2, 64);
+      if (active && (col & 3) == 0) {
+        sh[0][rsub * segw + (col >> 2)] = s1;
+        sh[1][rsub * segw + (col >> 2)] = s2;
+      }
+      __syncthreads();
+      const int sg = (c4b >> 2) + threadIdx.x;
+      if (threadIdx.x < segw && sg < nseg) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int q = 0; q < RP; ++q) {
+          t1 += sh[0][q * segw + threadIdx.x];
+          t2 += sh[1][q * segw + threadIdx.x];
+        }
+        double* o = seg + (((int64_t)b * nseg + sg) * nchunk + chunk) * 2;
+        o[0] = t1;
+        o[1] = t2;
+      }
+      __syncthreads();
+    }
   }
 }
-int launch_gate_add(const float* a, const float* gate, const float* r, float* y, int B, int HW, int C,
-                    hipStream_t s) {
-  KD_REQUIRE(C % 4 == 0, "gate_add needs C % 4 == 0");
-  int64_t total = (int64_t)B * HW * (C / 4);
-  hipLaunchKernelGGL(gate_add_kernel, dim3(grid_for(total)), dim3(256), 0, s, a, gate, r, y, (int64_t)HW, C / 4,
-                     total);
+// pixel rows per workgroup of launch_gate_add: the partial layout of `seg` has gate_add_chunks(B, HW) chunks
+static inline int gate_add_rpb(int B, int HW) {
+  int rpb = (int)(((int64_t)B * HW + 2047) / 2048);
+  return rpb < 8 ? 8 : (rpb > 64 ? 64 : rpb);
+}
+int gate_add_chunks(int B, int HW) {
+  const int rpb = gate_add_rpb(B, HW);
+  return (HW + rpb - 1) / rpb;
+}
+int launch_gate_add(const float* a, const float* gate, const float* r, int ldr, float* y, int ldy, double* seg, int B,
+                    int HW, int C, hipStream_t s) {
+  KD_REQUIRE(C % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0, "gate_add needs C % 4 == 0");
+  KD_REQUIRE(!seg || C % 16 == 0, "gate_add: segment statistics need C % 16 == 0");
+  const int rpb = gate_add_rpb(B, HW);
+  hipLaunchKernelGGL(gate_add_kernel, dim3((HW + rpb - 1) / rpb, B), dim3(256), 0, s, a, gate, r, ldr, y, ldy, seg, HW, C,
+                     rpb);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// GroupNorm statistics from segment partials, and the per-(image, channel) affine the normalisation (+ FiLM)
+// folds to, in ONE launch (was gn_finalize + gn_fold).  The input of the GroupNorm is the channel concat of up
+// to two sources; source i covers channels [c0, c0 + 16 nseg) and is seen by the layer as `scale` * x (skip
+// connections enter scaled by 2^-1/2).  If the consuming kernel reads the UNSCALED source, `ab_mul` = scale
+// moves the factor into the affine (A x' + B with x' = ab_mul x), else ab_mul = 1.  One workgroup per
+// (group, image): the partials are summed thread-strided and folded pairwise - a fixed order.
+__global__ __launch_bounds__(256) void gn_fold_seg_kernel(SegSrc s0, SegSrc s1, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ scale_shift, int ld_ss,
+                                                          float* __restrict__ ab, float* __restrict__ stats, int C, int G,
+                                                          double count, float eps) {
+  __shared__ double sh[2][256];
+  const int g = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const int Cg = C / G, c_lo = g * Cg, c_hi = c_lo + Cg;
+  double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const SegSrc& sc = k ? s1 : s0;
+    if (!sc.partial) continue;
+    const int lo = max(c_lo, sc.c0), hi = min(c_hi, sc.c0 + 16 * sc.nseg);
+    if (lo >= hi) continue;
+    const int sa = (lo - sc.c0) >> 4, se = (hi - sc.c0) >> 4;
+    const int64_t n = (int64_t)(se - sa) * sc.nchunk;
+    const double* base = sc.partial + (((int64_t)b * sc.nseg + sa) * sc.nchunk) * 2;
+    double l1 = 0.0, l2 = 0.0;
+    for (int64_t i = t; i < n; i += 256) {
+      l1 += base[2 * i];
+      l2 += base[2 * i + 1];
+    }
+    a1 += (double)sc.scale * l1;
+    a2 += (double)sc.scale * (double)sc.scale * l2;
+  }
+  sh[0][t] = a1;
+  sh[1][t] = a2;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) {
+      sh[0][t] += sh[0][t + w];
+      sh[1][t] += sh[1][t + w];
+    }
+    __syncthreads();
+  }
+  const double mean_d = sh[0][0] / count;
+  double var = sh[1][0] / count - mean_d * mean_d;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (stats && t == 0) {
+    stats[(b * G + g) * 2] = mean;
+    stats[(b * G + g) * 2 + 1] = rstd;
+  }
+  if (!ab) return;
+  for (int c = c_lo + t; c < c_hi; c += 256) {
+    float a = rstd * gamma[c];
+    float bb = beta[c] - mean * a;
+    if (scale_shift) {
+      const float sc = scale_shift[(int64_t)b * ld_ss + c] + 1.0f;
+      const float sft = scale_shift[(int64_t)b * ld_ss + C + c];
+      a *= sc;
+      bb = bb * sc + sft;
+    }
+    const float m = (s1.partial && c >= s1.c0 && c < s1.c0 + 16 * s1.nseg) ? s1.ab_mul : s0.ab_mul;
+    ab[2 * ((int64_t)b * C + c)] = a * m;
+    ab[2 * ((int64_t)b * C + c) + 1] = bb;
+  }
+}
+int launch_gn_fold_seg(SegSrc s0, SegSrc s1, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
+                       float* ab, float* stats, int B, int C, int G, double count, float eps, hipStream_t s) {
+  KD_REQUIRE(s0.partial && C % G == 0 && (C / G) % 16 == 0, "gn_fold_seg: groups must be multiples of 16 channels");
+  KD_REQUIRE(s0.c0 == 0 && s0.c0 + 16 * s0.nseg + (s1.partial ? 16 * s1.nseg : 0) == C &&
+                 (!s1.partial || s1.c0 == 16 * s0.nseg),
+             "gn_fold_seg: the sources must tile the channels");
+  hipLaunchKernelGGL(gn_fold_seg_kernel, dim3(G, B), dim3(256), 0, s, s0, s1, gamma, beta, scale_shift, ld_ss, ab, stats, C,
+                     G, count, eps);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

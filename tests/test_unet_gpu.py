@@ -467,8 +467,8 @@ def test_qk_norm_attention_variants_match_oracle(device, mode):
     # (a) ultra-res base UNet: self-attention with context at three levels + cross-attention in the res-blocks
     kw = dict(H.UNET_KW["ultra1"])
     ou = H.randomize_(R.Unet(**kw, cond_on_text=False, text_embed_dim=None, attn_qk_norm=mode), 31).eval()
-    plain = {k: v for k, v in ou._locals.items() if k != "attn_qk_norm"}
-    pu = ip.Unet(**plain, **({"cosine_sim_attn": True} if mode == 1 else {}))   # mode 2 comes from the key set
+    plain = {k: v for k, v in ou._locals.items() if k not in ("attn_qk_norm", "cosine_sim_attn")}
+    pu = ip.Unet(**plain, cosine_sim_attn=mode == 1)   # the library kwarg gives mode 1; mode 2 comes from the key set
     pu.load_state_dict(ou.state_dict(), strict=True)
     assert pu.attn_qk_norm == mode
     pu = pu.to(device)
