@@ -113,8 +113,8 @@ int launch_gn_fold(const float* stats, const float* gamma, const float* beta, co
                    float* ab, int B, int C, int G, hipStream_t s);
 // out_partial != nullptr: the kernel also leaves (sum, sum of squares) partials of y per (image, group of
 // out_groups) in launch_gn_finalize's layout, wino_fused_out_stats_chunks(H, W, N, G) entries per (image, group)
-int launch_wino_fused_gn(const float* x, const float* ab, const float* U, const float* bias, const float* res, int ldres,
-                         float* y, int B, int H, int W, int C, int N, double* out_partial, int out_groups,
+int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* U, const float* bias, const float* res,
+                         int ldres, float* y, int B, int H, int W, int C, int N, double* out_partial, int out_groups,
                          hipStream_t s);
 size_t wino_fused_out_stats_chunks(int H, int W, int N, int G);
 // stats[b][g] = (mean, rstd) from `chunks` (sum, sum of squares) partials per (b, g), summed in index order
@@ -129,8 +129,11 @@ int launch_gn_apply_silu(const float* x, int ldx, const float* stats, const floa
                          const float* scale_shift /*row b: [scale(C) | shift(C)], row stride ld_ss; or null*/,
                          int ld_ss, float* y, int B, int HW, int C, int G, hipStream_t s);
 // y = LN(x)*g (+beta) (+res)
-int launch_layernorm(const float* x, const float* g, const float* beta, const float* res, float* y, int rows,
-                     int C, float eps, hipStream_t s);
+int launch_layernorm(const float* x, int ldx, const float* g, const float* beta, const float* res, int ldres, float* y,
+                     int rows, int C, float eps, hipStream_t s);
+// dst[row][0..C) = src[row][0..C) * scale, row strides ld_src / ld_dst (dst may be src)
+int launch_copy_scale_rows(const float* src, int ld_src, float* dst, int ld_dst, int C, float scale, int64_t rows,
+                           hipStream_t s);
 // y[row] = [a[row] | b[row] * scale_b]; a == nullptr: only the b half is written (a's producer wrote in place)
 int launch_concat2(const float* a, int Ca, const float* b, int Cb, float scale_b, float* y, int64_t rows,
                    hipStream_t s);

@@ -120,11 +120,16 @@ struct Arena {  // plan-time activation allocator with reuse (single in-order st
   }
 };
 
-struct T {  // NHWC tensor in the workspace
-  size_t off = 0;
+struct T {  // NHWC tensor in the workspace, or a channel slice of one (a skip tensor living in its concat buffer)
+  size_t off = 0;  // arena block: what the reference counts key on
   int B = 0, H = 0, W = 0, C = 0;
+  int ld = 0;      // row stride in floats; 0 = dense (C)
+  int coff = 0;    // first channel inside the block's rows
   int64_t rows() const { return (int64_t)B * H * W; }
   int HW() const { return H * W; }
+  int LD() const { return ld ? ld : C; }
+  size_t at() const { return off + (size_t)coff * sizeof(float); }  // byte offset of (row 0, channel 0)
+  bool dense() const { return LD() == C; }
 };
 
 }  // namespace kd
@@ -286,7 +291,7 @@ struct Builder {
     if (--it->second == 0) {
       refs.erase(it);
       arena.release(t.off);
-      drop_seg(t.off);
+      drop_seg_block(t.off);
     }
   }
   // ---- GroupNorm partials handed from the kernel that writes a map to the layer that normalises it (SegSrc,
@@ -297,29 +302,54 @@ struct Builder {
     int nseg = 0, nchunk = 0, c0 = 0;
     float scale = 1.0f, ab_mul = 1.0f;
   };
-  std::unordered_map<size_t, std::vector<SegPart>> seg_of;
+  struct SegList {
+    size_t block = 0;   // arena block of the tensor: the partials die with it
+    std::vector<SegPart> parts;
+  };
+  std::unordered_map<size_t, SegList> seg_of;   // key: T::at() - a slice and its buffer have different keys
   const bool seg_on = !(getenv("KD_SEG_STATS") && atoi(getenv("KD_SEG_STATS")) == 0);
-  void drop_seg(size_t tensor_off) {
-    auto it = seg_of.find(tensor_off);
+  void drop_seg_block(size_t block) {
+    for (auto it = seg_of.begin(); it != seg_of.end();) {
+      if (it->second.block == block) {
+        for (auto& sp : it->second.parts) arena.release(sp.off);
+        it = seg_of.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+  // a skip slice joins the concat that holds it: its partials become channels [c0, ..) of the whole buffer `to`
+  void move_seg(const T& from, const T& to, int c0, float scale, float ab_mul) {
+    auto it = seg_of.find(from.at());
     if (it == seg_of.end()) return;
-    for (auto& sp : it->second) arena.release(sp.off);
+    SegList moved = it->second;
     seg_of.erase(it);
+    SegList& dst = seg_of[to.at()];
+    dst.block = to.off;
+    for (auto sp : moved.parts) {
+      sp.c0 += c0;
+      sp.scale *= scale;
+      sp.ab_mul *= ab_mul;
+      dst.parts.push_back(sp);
+    }
   }
   // reserves the partial buffer of channels [c0, c0 + 16 nseg) of tensor t; returns its workspace offset
   size_t add_seg(const T& t, int c0, int nseg, int nchunk, float scale = 1.0f, float ab_mul = 1.0f) {
     SegPart sp;
     sp.off = arena.alloc((size_t)t.B * nseg * nchunk * 2 * sizeof(double));
     sp.nseg = nseg; sp.nchunk = nchunk; sp.c0 = c0; sp.scale = scale; sp.ab_mul = ab_mul;
-    seg_of[t.off].push_back(sp);
+    SegList& l = seg_of[t.at()];
+    l.block = t.off;
+    l.parts.push_back(sp);
     return sp.off;
   }
   // the sources covering ALL C channels of x in order (at most two), or false
   bool seg_sources(const T& x, SegPart (&out)[2], int& n) const {
     n = 0;
     if (!seg_on || x.C % cfg.resnet_groups || (x.C / cfg.resnet_groups) % 16) return false;
-    auto it = seg_of.find(x.off);
+    auto it = seg_of.find(x.at());
     if (it == seg_of.end()) return false;
-    std::vector<SegPart> v = it->second;
+    std::vector<SegPart> v = it->second.parts;
     std::sort(v.begin(), v.end(), [](const SegPart& a, const SegPart& b) { return a.c0 < b.c0; });
     int c = 0;
     for (auto& sp : v) {
@@ -352,9 +382,10 @@ struct Builder {
       return has_ab;
     }
     if (gn_partial_bytes(Bx, HW, C, G) > gn_partial_max) throw std::runtime_error("gn partial scratch too small");
-    const size_t xo = x.off, po = gn_partial_t.off;
+    const size_t xo = x.at(), po = gn_partial_t.off;
+    const int ldx = x.LD();
     emit([=](hipStream_t s) {
-      return launch_gn_stats(uu->P(xo), C, uu->P(so), (double*)uu->P(po), Bx, HW, C, G, 1e-5f, s);
+      return launch_gn_stats(uu->P(xo), ldx, uu->P(so), (double*)uu->P(po), Bx, HW, C, G, 1e-5f, s);
     }, "gn stats HW" + std::to_string(HW) + " C" + std::to_string(C));
     return false;
   }
@@ -410,7 +441,7 @@ struct Builder {
     }
     ConvParams p{};
     p.w = w; p.bias = bias;
-    p.B = x.B; p.Hi = x.H; p.Wi = x.W; p.Cin = x.C; p.ldx = x.C;
+    p.B = x.B; p.Hi = x.H; p.Wi = x.W; p.Cin = x.C; p.ldx = x.LD();
     p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
     p.KH = K; p.KW = K; p.stride = stride; p.pad = pad;
     if (o.rowrun) {  // weights packed [KH][Cout][KW*C]: a kernel row is one contiguous K run (kernels_conv.hip)
@@ -421,15 +452,15 @@ struct Builder {
     p.wz_rows = o.wz_rows;
     p.wz_count = o.wz_rows > 0 ? 16 : 0;
     p.act = o.act; p.out_mode = o.out_mode;
-    p.ldy = (o.out_mode == OUT_NHWC || o.out_mode == OUT_PIXSHUF) ? y.C : 0;
-    p.yoff = o.yoff;
-    p.ldres = o.res ? o.res->C : 0;
-    p.ldgs = o.gate_src ? o.gate_src->C : 0;
-    size_t xo = x.off, yo = y.off;
+    p.ldy = (o.out_mode == OUT_NHWC || o.out_mode == OUT_PIXSHUF) ? y.LD() : 0;
+    p.yoff = y.coff + o.yoff;   // (a slice destination: channels count from the slice's first)
+    p.ldres = o.res ? o.res->LD() : 0;
+    p.ldgs = o.gate_src ? o.gate_src->LD() : 0;
+    size_t xo = x.at(), yo = y.off;
     bool has_res = o.res != nullptr, has_gs = o.gate_src != nullptr, ext = o.out_external;
-    size_t ro = has_res ? o.res->off : 0, gso = has_gs ? o.gate_src->off : 0, go = has_gs ? o.gate->off : 0;
+    size_t ro = has_res ? o.res->at() : 0, gso = has_gs ? o.gate_src->at() : 0, go = has_gs ? o.gate->off : 0;
     kd_unet* uu = u;
-    const int res_coff = o.res_coff;
+    const int res_coff = o.res_coff, o_yoff = o.yoff;
     // small-M layers (batch-1 patches): split-K scratch, released right after the launch is recorded
     // (one in-order stream: the next op that reuses the block runs after the reduction)
     const int ks = conv_ksplit(p);
@@ -442,18 +473,18 @@ struct Builder {
     int seg_nseg = 0, seg_c0 = 0;
     if (o.want_seg && seg_on && !ext && !to_text && !to_static && ks == 1) {
       const int cw = o.out_mode == OUT_PIXSHUF ? Cout / 4 : Cout;
-      seg_c0 = o.seg_c0 >= 0 ? o.seg_c0 : o.yoff;
+      seg_c0 = o.seg_c0 >= 0 ? o.seg_c0 : o.yoff;   // in channels of the tensor y (a slice counts from its own first)
       const int span = o.seg_c0 >= 0 ? o.seg_cn : cw;
       ConvParams probe = p;
       probe.res = has_res ? (const float*)16 : nullptr;
       probe.gate_src = has_gs ? (const float*)16 : nullptr;
-      probe.seg_c0 = seg_c0;
+      probe.seg_c0 = y.coff + seg_c0;
       const int nchunk = conv_seg_chunks(probe);
       if (nchunk > 0 && cw % 16 == 0 && span % 16 == 0 && o.yoff >= seg_c0 && o.yoff + cw <= seg_c0 + span) {
         SegPart* have = nullptr;
-        auto it = seg_of.find(y.off);
+        auto it = seg_of.find(y.at());
         if (it != seg_of.end())
-          for (auto& sp : it->second)
+          for (auto& sp : it->second.parts)
             if (sp.c0 == seg_c0 && sp.nseg == span / 16 && sp.nchunk == nchunk) have = &sp;
         seg_nseg = span / 16;
         sego = have ? have->off : add_seg(y, seg_c0, seg_nseg, nchunk);
@@ -470,7 +501,7 @@ struct Builder {
       if (seg_nseg) {
         q.seg_partial = (double*)uu->P(sego);
         q.seg_nseg = seg_nseg;
-        q.seg_c0 = seg_c0;
+        q.seg_c0 = p.yoff - o_yoff + seg_c0;   // block channel of the partial buffer's segment 0
       }
       return launch_conv_igemm(q, s);
     });
@@ -494,16 +525,23 @@ struct Builder {
     return y;
   }
   // token GEMM y[M,N] = x[M,K] @ w[N,K]^T
-  T linear(const T& x, const float* w, const float* bias, int N, int act = ACT_NONE, const T* res = nullptr) {
+  // `dst`: write into this tensor (a slice of a wider buffer: a skip tensor in its concat slot) instead of a new one
+  T linear(const T& x, const float* w, const float* bias, int N, int act = ACT_NONE, const T* res = nullptr,
+           const T* dst = nullptr) {
     T xf = x;
     xf.B = 1; xf.H = 1; xf.W = (int)x.rows();
     ConvOpt o;
     o.act = act;
-    T rf;
+    T rf, df;
     if (res) {
       rf = *res;
       rf.B = 1; rf.H = 1; rf.W = (int)res->rows();
       o.res = &rf;
+    }
+    if (dst) {
+      df = *dst;
+      df.B = 1; df.H = 1; df.W = (int)dst->rows();
+      o.dst = &df;
     }
     T y = conv(xf, w, bias, N, 1, 1, 0, o);
     y.B = x.B; y.H = x.H; y.W = x.W;
@@ -521,12 +559,12 @@ struct Builder {
 
   T layernorm(const T& x, const float* g, const float* beta, const T* res = nullptr) {
     T y = alloc(x.B, x.H, x.W, x.C);
-    size_t xo = x.off, yo = y.off, ro = res ? res->off : 0;
+    size_t xo = x.at(), yo = y.off, ro = res ? res->at() : 0;
     bool hr = res != nullptr;
-    int rows = (int)x.rows(), C = x.C;
+    int rows = (int)x.rows(), C = x.C, ldx = x.LD(), ldres = res ? res->LD() : 0;
     kd_unet* uu = u;
     emit([=](hipStream_t s) {
-      return launch_layernorm(uu->P(xo), g, beta, hr ? uu->P(ro) : nullptr, uu->P(yo), rows, C, 1e-5f, s);
+      return launch_layernorm(uu->P(xo), ldx, g, beta, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), rows, C, 1e-5f, s);
     }, "ln rows" + std::to_string(rows) + " C" + std::to_string(C));
     return y;
   }
@@ -539,12 +577,12 @@ struct Builder {
     int G = cfg.resnet_groups;
     T y = alloc(x.B, x.H, x.W, x.C);
     emit_gn_stats(x, gamma, beta, ss_col, nullptr);
-    size_t xo = x.off, yo = y.off, so = gn_stats_t.off, sso = t_ss.off;
-    int Bx = x.B, HW = x.HW(), C = x.C, ld = tmlp_total;
+    size_t xo = x.at(), yo = y.off, so = gn_stats_t.off, sso = t_ss.off;
+    int Bx = x.B, HW = x.HW(), C = x.C, ld = tmlp_total, ldx = x.LD();
     kd_unet* uu = u;
     emit([=](hipStream_t s) {
       const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
-      return launch_gn_apply_silu(uu->P(xo), C, uu->P(so), gamma, beta, ssp, ld, uu->P(yo), Bx, HW, C, G, s);
+      return launch_gn_apply_silu(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(yo), Bx, HW, C, G, s);
     }, "gn apply HW" + std::to_string(HW) + " C" + std::to_string(C));
     return y;
   }
@@ -611,7 +649,7 @@ struct Builder {
   }
 
   // TransformerBlock (depth 1): x = attn(x, ctx) + x ; x = ff(x) + x.
-  T transformer(const T& x, const std::string& pre, const T* ctx) {
+  T transformer(const T& x, const std::string& pre, const T* ctx, const T* dst = nullptr) {
     int H = cfg.attn_heads, D = cfg.attn_dim_head, inner = H * D, dim = x.C;
     std::string a = pre + ".layers.0.0", f = pre + ".layers.0.1";
     T xn = layernorm(x, P(a + ".norm.g", dim), nullptr);
@@ -660,7 +698,7 @@ struct Builder {
     free(h0);
     T h2 = layernorm(h1, P(f + ".3.g", hidden), nullptr);
     free(h1);
-    T y = linear(h2, P(f + ".4.weight", (int64_t)dim * hidden), nullptr, dim, ACT_NONE, &x1);
+    T y = linear(h2, P(f + ".4.weight", (int64_t)dim * hidden), nullptr, dim, ACT_NONE, &x1, dst);
     free(h2);
     free(x1);
     return y;
@@ -741,12 +779,12 @@ struct Builder {
     for (int64_t t0 = 0; t0 < Mt; t0 += nt_slice) {
       const int64_t nt = std::min(nt_slice, Mt - t0);
       {
-        size_t xo = x.off, vo = V.off, so = gn_stats_t.off, sso = t_ss.off;
-        int ld = tmlp_total;
+        size_t xo = x.at(), vo = V.off, so = gn_stats_t.off, sso = t_ss.off;
+        int ld = tmlp_total, ldx = x.LD();
         kd_unet* uu = u;
         emit([=](hipStream_t s) {
           const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
-          return launch_wino_in(uu->P(xo), Cin, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, t0, nt,
+          return launch_wino_in(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, t0, nt,
                                 s);
         }, "wino_in" + shape);
       }
@@ -760,9 +798,9 @@ struct Builder {
       conv(Vs, U, nullptr, Cout, 1, 1, 0, o);
       if (!to_text && !to_static) u->op_label.back() = "wino gemm" + shape;
       {
-        size_t d_o = D.off, yo = y.off, ro = res ? res->off : 0;
+        size_t d_o = D.off, yo = y.off, ro = res ? res->at() : 0;
         bool hr = res != nullptr;
-        int ldres = res ? res->C : 0;
+        int ldres = res ? res->LD() : 0;
         kd_unet* uu = u;
         emit([=](hipStream_t s) {
           return launch_wino_out(uu->P(d_o), bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W, Cout, t0, nt,
@@ -791,10 +829,11 @@ struct Builder {
     const float* wsrc = raw(conv_prefix + ".weight", (int64_t)Cout * Cin * 9);
     float* U = cached("winof:" + conv_prefix, (size_t)16 * Cout * Cin,
                       [&](float* dst) { KD_THROW_IF(launch_wino_fused_pack(wsrc, dst, Cout, Cin, 0)); });
+    if (!x.dense()) throw std::runtime_error("plan: fwino_conv needs a dense input");
     T y = alloc(Bx, H, W, Cout);
-    size_t xo = x.off, yo = y.off, ro = res ? res->off : 0;
+    size_t xo = x.off, yo = y.off, ro = res ? res->at() : 0;
     const bool hr = res != nullptr;
-    const int ldres = res ? res->C : 0;
+    const int ldres = res ? res->LD() : 0;
     kd_unet* uu = u;
     const int64_t m = (int64_t)Bx * H * W * Cout * Cin * 9;
     emit([=](hipStream_t s) {
@@ -816,7 +855,8 @@ struct Builder {
   // gn_apply_silu pass (A/B, read per plan).
   bool fwino_gn_ok(const T& x, int cout) const {
     const bool on = !getenv("KD_FWINO_GN") || atoi(getenv("KD_FWINO_GN")) != 0;
-    return on && x.C <= 512 && x.C % cfg.resnet_groups == 0 && fwino_ok(x, cout);
+    return on && x.C <= 512 && x.C % cfg.resnet_groups == 0 && fwino_ok(x, cout) &&
+           (int64_t)x.H * x.W * x.LD() * 4 < 0x7fffffff;
   }
   T fwino_gn_conv(const T& x, const std::string& gn_prefix, int ss_col, const std::string& conv_prefix, int Cout,
                   const T* res) {
@@ -842,12 +882,12 @@ struct Builder {
     // the epilogue leaves the partials of y for whichever GroupNorm reads it next (block2, or the next block)
     const bool so_ = seg_on && Cout % 16 == 0 && !(getenv("KD_FWINO_STATS") && atoi(getenv("KD_FWINO_STATS")) == 0);
     const size_t pout = so_ ? add_seg(y, 0, Cout / 16, (int)wino_fused_out_stats_chunks(H, W, Cout, Cout / 16)) : 0;
-    size_t xo = x.off, yo = y.off, ro = res ? res->off : 0, abo = ab.off;
+    size_t xo = x.at(), yo = y.off, ro = res ? res->at() : 0, abo = ab.off;
     const bool hr = res != nullptr;
-    const int ldres = res ? res->C : 0;
+    const int ldres = res ? res->LD() : 0, ldx = x.LD();
     const int64_t m = (int64_t)Bx * H * W * Cout * Cin * 9;
     emit([=](hipStream_t s) {
-      return launch_wino_fused_gn(uu->P(xo), uu->P(abo), U, bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W,
+      return launch_wino_fused_gn(uu->P(xo), ldx, uu->P(abo), U, bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W,
                                   Cin, Cout, so_ ? (double*)uu->P(pout) : nullptr, so_ ? Cout / 16 : 0, s);
     }, "wino fused M" + std::to_string((int64_t)Bx * H * W) + " Cin" + std::to_string(Cin) + " Cout" +
            std::to_string(Cout), m);
@@ -865,7 +905,13 @@ struct Builder {
   // ct: the buffer of the skip concat that follows this block ([B,H,W,dim_out + skip channels]); when the
   // block ends in its 1x1 skip conv, that conv writes the block output straight into the first dim_out
   // channels of ct and ct is returned (concat_skip then only adds the skip half); otherwise ct is ignored
-  T resnet(const T& x, const std::string& pre, int dim_out, const T* ctx, bool use_gca, const T* ct = nullptr) {
+  // out_slot: a channel slice (of the concat buffer this block's output will later be part of as the skip half);
+  // a block that ends in gate_add writes its output there and returns the slice; otherwise out_slot is ignored.
+  // skip_c0 >= 0: x is a concat whose channels [skip_c0, ..) hold an UNSCALED skip tensor that the layer must see
+  // scaled by skip_scale: the GroupNorm gets it through the partials' scale (SegPart), the 1x1 skip conv through
+  // weights whose columns were scaled at plan build.
+  T resnet(const T& x, const std::string& pre, int dim_out, const T* ctx, bool use_gca, const T* ct = nullptr,
+           const T* out_slot = nullptr, int skip_c0 = -1, float skip_scale = 1.0f) {
     bool has_cross = has(pre + ".cross_attn.to_q.weight");
     if (has_cross && !ctx) throw std::runtime_error("cross-attention block without conditioning tokens: " + pre);
     int dim_in = x.C;
@@ -914,6 +960,19 @@ struct Builder {
       free(y2);
     }
     if (!use_gca && !has_res_conv) return h2;
+    if (skip_c0 >= 0 && !has_res_conv) throw std::runtime_error("plan: folded skip scale without a skip conv: " + pre);
+    const float* w_res = nullptr;
+    if (has_res_conv) {
+      w_res = P(pre + ".res_conv.weight", (int64_t)dim_out * dim_in);
+      if (skip_c0 >= 0) {   // columns of the skip channels times skip_scale
+        const float* src = w_res;
+        w_res = cached("res_conv_skipscaled:" + pre + ":" + std::to_string(skip_c0), (size_t)dim_out * dim_in, [&](float* dst) {
+          KD_THROW_IF(launch_copy_scale_rows(src, dim_in, dst, dim_in, dim_in, 1.0f, dim_out, 0));
+          KD_THROW_IF(launch_copy_scale_rows(dst + skip_c0, dim_in, dst + skip_c0, dim_in, dim_in - skip_c0, skip_scale,
+                                             dim_out, 0));
+        });
+      }
+    }
     T out;
     if (use_gca) {
       T gate = gca(h2, pre + ".gca");
@@ -923,17 +982,17 @@ struct Builder {
         o.gate = &gate;
         o.want_seg = true;
         if (ct) o.dst = ct;
-        out = conv(x, P(pre + ".res_conv.weight", (int64_t)dim_out * dim_in), P(pre + ".res_conv.bias", dim_out),
-                   dim_out, 1, 1, 0, o);
+        out = conv(x, w_res, P(pre + ".res_conv.bias", dim_out), dim_out, 1, 1, 0, o);
       } else {
-        out = alloc(x.B, x.H, x.W, dim_out);
-        size_t ao = h2.off, go = gate.off, ro = x.off, yo = out.off;
-        int Bx = x.B, HW = x.HW();
+        out = out_slot ? *out_slot : alloc(x.B, x.H, x.W, dim_out);
+        if (out.C != dim_out) throw std::runtime_error("plan: output slot of the wrong width: " + pre);
+        size_t ao = h2.off, go = gate.off, ro = x.at(), yo = out.at();
+        int Bx = x.B, HW = x.HW(), ldr = x.LD(), ldy = out.LD();
         const bool sg = seg_on && dim_out % 16 == 0;   // GroupNorm partials of `out` for the block that reads it
         const size_t sgo = sg ? add_seg(out, 0, dim_out / 16, gate_add_chunks(Bx, HW)) : 0;
         kd_unet* uu = u;
         emit([=](hipStream_t s) {
-          return launch_gate_add(uu->P(ao), uu->P(go), uu->P(ro), dim_out, uu->P(yo), dim_out,
+          return launch_gate_add(uu->P(ao), uu->P(go), uu->P(ro), ldr, uu->P(yo), ldy,
                                  sg ? (double*)uu->P(sgo) : nullptr, Bx, HW, dim_out, s);
         }, "gate_add HW" + std::to_string(HW) + " C" + std::to_string(dim_out));
       }
@@ -943,8 +1002,7 @@ struct Builder {
       o.res = &h2;
       o.want_seg = true;
       if (ct) o.dst = ct;
-      out = conv(x, P(pre + ".res_conv.weight", (int64_t)dim_out * dim_in), P(pre + ".res_conv.bias", dim_out),
-                 dim_out, 1, 1, 0, o);
+      out = conv(x, w_res, P(pre + ".res_conv.bias", dim_out), dim_out, 1, 1, 0, o);
     }
     free(h2);
     return out;
@@ -978,22 +1036,44 @@ struct Builder {
   }
   T concat_skip(const T& x, const T& skip, float scale) {
     T y = alloc(x.B, x.H, x.W, x.C + skip.C);
-    size_t ao = x.off, bo = skip.off, yo = y.off;
-    int Ca = x.C, Cb = skip.C;
+    size_t ao = x.at(), bo = skip.at(), yo = y.off;
+    int Ca = x.C, Cb = skip.C, lda = x.LD(), ldb = skip.LD();
     int64_t rows = x.rows();
     kd_unet* uu = u;
-    emit([=](hipStream_t s) { return launch_concat2(uu->P(ao), Ca, uu->P(bo), Cb, scale, uu->P(yo), rows, s); },
-         "concat rows" + std::to_string(rows) + " C" + std::to_string(Ca + Cb));
+    emit([=](hipStream_t s) {
+      if (launch_copy_scale_rows(uu->P(ao), lda, uu->P(yo), Ca + Cb, Ca, 1.0f, rows, s)) return 1;
+      return launch_copy_scale_rows(uu->P(bo), ldb, uu->P(yo) + Ca, Ca + Cb, Cb, scale, rows, s);
+    }, "concat rows" + std::to_string(rows) + " C" + std::to_string(Ca + Cb));
     return y;
   }
   // the same when x's producer already wrote its Ca channels into y (resnet / upsample with ct = &y)
   void concat_skip_tail(const T& y, int Ca, const T& skip, float scale) {
-    size_t bo = skip.off, yo = y.off;
-    int Cb = skip.C;
+    size_t bo = skip.at(), yo = y.off;
+    int Cb = skip.C, ldb = skip.LD(), ldy = y.LD();
     int64_t rows = y.rows();
     kd_unet* uu = u;
-    emit([=](hipStream_t s) { return launch_concat2(nullptr, Ca, uu->P(bo), Cb, scale, uu->P(yo), rows, s); },
-         "concat rows" + std::to_string(rows) + " C" + std::to_string(Ca + Cb));
+    emit([=](hipStream_t s) {
+      return launch_copy_scale_rows(uu->P(bo), ldb, uu->P(yo) + Ca, ldy, Cb, scale, rows, s);
+    }, "concat tail rows" + std::to_string(rows) + " C" + std::to_string(Ca + Cb));
+  }
+  // x into the first x.C channels of the concat buffer ct (whose skip half is already there)
+  void concat_head(const T& ct, const T& x) {
+    size_t ao = x.at(), yo = ct.off;
+    int Ca = x.C, lda = x.LD(), ldy = ct.LD();
+    int64_t rows = x.rows();
+    kd_unet* uu = u;
+    emit([=](hipStream_t s) { return launch_copy_scale_rows(uu->P(ao), lda, uu->P(yo), ldy, Ca, 1.0f, rows, s); },
+         "concat head rows" + std::to_string(rows) + " C" + std::to_string(Ca));
+  }
+  // in place: channels [c0, c0 + n) of t times scale (a skip half whose consumer cannot fold the scale)
+  void scale_slice(const T& t, int c0, int n, float scale) {
+    size_t o = t.off;
+    int ld = t.LD();
+    int64_t rows = t.rows();
+    kd_unet* uu = u;
+    emit([=](hipStream_t s) {
+      return launch_copy_scale_rows(uu->P(o) + c0, ld, uu->P(o) + c0, ld, n, scale, rows, s);
+    }, "scale slice rows" + std::to_string(rows) + " C" + std::to_string(n));
   }
 
   void collect_time_mlps() {

@@ -217,14 +217,15 @@ int launch_gn_apply_silu(const float* x, int ldx, const float* stats, const floa
 }
 
 // ------------------------------------------------------------------------- LayerNorm (one wave per row)
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx,
+                                                        const float* __restrict__ g,
                                                         const float* __restrict__ beta,
-                                                        const float* __restrict__ res, float* __restrict__ y,
-                                                        int rows, int C, float eps) {
+                                                        const float* __restrict__ res, int ldres,
+                                                        float* __restrict__ y, int rows, int C, float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
-  const float* xr = x + (int64_t)row * C;
+  const float* xr = x + (int64_t)row * ldx;
   float* yr = y + (int64_t)row * C;
   const int C4 = C >> 2;
   float s = 0.f;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       for (int e = 0; e < 4; ++e) o[e] += bb[e];
     }
     if (res) {
-      f32x4 rr = *(const f32x4*)(res + (int64_t)row * C + c4 * 4);
+      f32x4 rr = *(const f32x4*)(res + (int64_t)row * ldres + c4 * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] += rr[e];
     }
@@ -264,10 +265,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
-int launch_layernorm(const float* x, const float* g, const float* beta, const float* res, float* y, int rows,
-                     int C, float eps, hipStream_t s) {
-  KD_REQUIRE(C % 4 == 0, "LayerNorm needs C % 4 == 0");
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, beta, res, y, rows, C, eps);
+int launch_layernorm(const float* x, int ldx, const float* g, const float* beta, const float* res, int ldres, float* y,
+                     int rows, int C, float eps, hipStream_t s) {
+  KD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && (!res || ldres % 4 == 0), "LayerNorm needs C % 4 == 0");
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, g, beta, res, ldres, y, rows, C,
+                     eps);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -479,6 +481,28 @@ int launch_gn_fold_seg(SegSrc s0, SegSrc s1, const float* gamma, const float* be
              "gn_fold_seg: the sources must tile the channels");
   hipLaunchKernelGGL(gn_fold_seg_kernel, dim3(G, B), dim3(256), 0, s, s0, s1, gamma, beta, scale_shift, ld_ss, ab, stats, C,
                      G, count, eps);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// dst[row][0..C) = src[row][0..C) * scale with row strides (concat head copy; in-place scaling of a skip slice)
+__global__ void copy_scale_rows_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int C4,
+                                       float scale, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / C4;
+    const int c4 = (int)(idx - row * C4);
+    f32x4 v = *(const f32x4*)(src + row * lds_ + c4 * 4);
+    v *= scale;
+    *(f32x4*)(dst + row * ldd + c4 * 4) = v;
+  }
+}
+int launch_copy_scale_rows(const float* src, int ld_src, float* dst, int ld_dst, int C, float scale, int64_t rows,
+                           hipStream_t s) {
+  KD_REQUIRE(C % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0, "copy_scale_rows needs multiples of 4 channels");
+  const int64_t total = rows * (C / 4);
+  hipLaunchKernelGGL(copy_scale_rows_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, ld_src, dst, ld_dst, C / 4, scale,
+                     total);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

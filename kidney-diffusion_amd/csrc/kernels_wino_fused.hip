@@ -324,7 +324,8 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restr
 // activation as well.
 constexpr int WG_MAXC = 512;   // channels of the affine table kept in LDS
 
-__global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __restrict__ x, const float* __restrict__ ab,
+__global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __restrict__ x, int ldx,
+                                                               const float* __restrict__ ab,
                                                                const float* __restrict__ U,
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ res, int ldres,
@@ -363,8 +364,9 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
   float2 abv = make_float2(0.f, 0.f);
   if (tid < C) abv = ((const float2*)ab)[(int64_t)b * C + tid];
 
-  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)b * H * W * C), 0,
-                                                                       (int)((int64_t)H * W * C * 4), 0x00020000);
+  // x may be a channel slice of a wider map (row stride ldx >= C): a skip tensor inside its concat buffer
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)b * H * W * ldx), 0,
+                                                                       (int)((int64_t)H * W * ldx * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsU =
       __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, (int)((int64_t)16 * N * C * 4), 0x00020000);
 
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
   {
     int iy, ix;
     const bool ok = slot_pixel(tid, iy, ix);
-    voffX = ok ? (uint32_t)(((iy * W + ix) * C) * 4) : OOB_OFF;
+    voffX = ok ? (uint32_t)(((iy * W + ix) * ldx) * 4) : OOB_OFF;
   }
   // activation: values tid, tid + 512, tid + 1024 of the 324 x 4 patch floats; channel tid & 3, slots (tid >> 2) + 128 i
   bool aok[3];
@@ -673,15 +675,17 @@ size_t wino_fused_out_stats_chunks(int H, int W, int N, int G) {
   return (size_t)(N / G / 16) * (H / 16) * (W / 16) * 4;
 }
 
-int launch_wino_fused_gn(const float* x, const float* ab, const float* U, const float* bias, const float* res, int ldres,
-                         float* y, int B, int H, int W, int C, int N, double* out_partial, int out_groups,
+int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* U, const float* bias, const float* res,
+                         int ldres, float* y, int B, int H, int W, int C, int N, double* out_partial, int out_groups,
                          hipStream_t s) {
+  KD_REQUIRE(ldx >= C && ldx % 4 == 0 && (int64_t)H * W * ldx * 4 < 0x7fffffff && ((uintptr_t)x & 15) == 0,
+             "GroupNorm-fused Winograd conv: bad input row stride");
   KD_REQUIRE(wino_fused_ok(B, H, W, C, N) && C <= WG_MAXC,
              "GroupNorm-fused Winograd conv needs H, W % 16 == 0, Cin % 4 == 0, Cin <= 512, Cout % 64 == 0");
   KD_REQUIRE(!out_partial || (out_groups > 0 && N % out_groups == 0 && (N / out_groups) % 16 == 0),
              "output statistics need groups of a multiple of 16 channels");
   const unsigned grid = (unsigned)((int64_t)B * (H / 16) * (W / 16) * (N / 64));
-  hipLaunchKernelGGL(wino_fused_gn_kernel, dim3(grid), dim3(512), 0, s, x, ab, U, bias, res, ldres, y, B, H, W, C, N,
+  hipLaunchKernelGGL(wino_fused_gn_kernel, dim3(grid), dim3(512), 0, s, x, ldx, ab, U, bias, res, ldres, y, B, H, W, C, N,
                      out_partial, out_groups);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
