@@ -307,9 +307,13 @@ def grid_workload(args, world, rank, device, distributed, barrier):
 
     slab_dev = device if (not distributed or dist.get_backend() == "nccl") else torch.device("cpu")
 
+    # deal order inside a generalised wave: batch-1 step times per stage (profiles/README.md) x this run's timesteps
+    stage_cost = {1: 9.7 * T, 2: 7.5 * T, 3: 68.0 * T}
+
     def run(positions, cond_images, canvases):
         out = D.sample_grids(sample_fn, (1, 2, 3), [positions] * canvases, [cond_images] * canvases, 0.25,
-                             [n] * canvases, patch_width=geom.patch_width, device=slab_dev)
+                             [n] * canvases, patch_width=geom.patch_width, device=slab_dev,
+                             pipeline=not args.no_pipeline, stage_cost=stage_cost)
         sub = G.GridGeometry(geom.patch_width, geom.patch_dist, n, geom.out_patch_dist,
                              1024 + (n - 1) * geom.out_patch_dist)
         return [G.stitch_canvas(o, positions, sub, background=zoomed.to(o[0].device)) for o in out]
@@ -355,7 +359,11 @@ def grid_workload(args, world, rank, device, distributed, barrier):
                                f"timesteps ({T},{T},{T}) [reference default (1024,256,256)], inpaint_resample {R}, "
                                f"stage-1/2 patches per sample() call <= {args.grid_batch}, random-init weights",
                    "patches": len(pos) * ncan, "schedule_slots": D.schedule_length(waves, world),
-                   "parallelism": f"{world} rank(s): anti-diagonal waves dealt round-robin, one all-gather per wave"},
+                   "pipeline_steps": len(D.stage_waves([pos] * ncan, [G.choose_orientation(pos)] * ncan, (1, 2, 3),
+                                                       not args.no_pipeline)),
+                   "parallelism": f"{world} rank(s): anti-diagonal waves of the three stages pipelined (a patch's "
+                                  "stage s starts once its stage s-1 and its neighbours' stage s are done), dealt "
+                                  "heaviest first with column affinity, one all-gather per stage and wave"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
                      "kernel": f"whole patch pipeline per GPU: {flop_patch / 1e12:.2f} TFLOP algorithmic per patch "
@@ -378,6 +386,8 @@ def main():
     ap.add_argument("--canvases", type=int, default=1)
     ap.add_argument("--grid-steps", type=int, default=8, help="timesteps per stage for --workload grid")
     ap.add_argument("--grid-resample", type=int, default=1, help="inpaint_resample_times for --workload grid")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="--workload grid: keep the reference's barrier between the stages")
     ap.add_argument("--grid-batch", type=int, default=1,
                     help="--workload grid: patches of a wave per sample() call in stages 1-2 (1 = the reference's way)")
     args = ap.parse_args()

@@ -301,6 +301,7 @@ struct Builder {
     size_t off = 0;   // partial buffer [B][nseg][nchunk][2] doubles
     int nseg = 0, nchunk = 0, c0 = 0;
     float scale = 1.0f, ab_mul = 1.0f;
+    bool owned = true;   // false: the buffer belongs to another tensor's list (a copied skip tensor) that outlives this one
   };
   struct SegList {
     size_t block = 0;   // arena block of the tensor: the partials die with it
@@ -311,12 +312,22 @@ struct Builder {
   void drop_seg_block(size_t block) {
     for (auto it = seg_of.begin(); it != seg_of.end();) {
       if (it->second.block == block) {
-        for (auto& sp : it->second.parts) arena.release(sp.off);
+        for (auto& sp : it->second.parts)
+          if (sp.owned) arena.release(sp.off);
         it = seg_of.erase(it);
       } else {
         ++it;
       }
     }
+  }
+  // `to` is a copy of `from` that dies first: it may use from's partials
+  void share_seg(const T& from, const T& to) {
+    auto it = seg_of.find(from.at());
+    if (it == seg_of.end()) return;
+    SegList l = it->second;
+    l.block = to.off;
+    for (auto& sp : l.parts) sp.owned = false;
+    seg_of[to.at()] = l;
   }
   // a skip slice joins the concat that holds it: its partials become channels [c0, ..) of the whole buffer `to`
   void move_seg(const T& from, const T& to, int c0, float scale, float ab_mul) {

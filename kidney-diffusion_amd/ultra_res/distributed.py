@@ -12,7 +12,14 @@ patch's three neighbours are done and publish results through a `Manager().dict(
   * several canvases can be scheduled together: their waves are merged, which is what lifts the
     8x8-grid bound of 64/15 = 4.27x on 8 GPUs.
 
-Stages run 1 -> 2 -> 3 with a barrier between them, as the reference does (:264-270).
+The reference runs the stages 1 -> 2 -> 3 with a barrier (and a model reload) between them (:264-270).
+Here a patch's stage s only waits for what it needs - its own stage s-1 output and the stage-s outputs
+of its three neighbours - so the stages are PIPELINED: generalised wave g holds the stage-s tasks of
+patch wave g - (s - 1) for every stage (`stage_waves`), 2n+1 steps for an n x n grid through three
+stages instead of 3 (2n - 1), and the light stage-1/2 tasks fill ranks that the anti-diagonal leaves idle.
+Inside a generalised wave the tasks are dealt to the ranks heaviest first with column affinity (a patch's
+`above` neighbour was sampled on the same rank when the deal is balanced; `assign_tasks`).
+
 `sample_fn(stage, idxs, lowres, cond, inpaint_patch, inpaint_mask) -> (n,3,S,S)` does the actual
 sampling (the HIP engine through `Imagen.sample` in production, a deterministic stub in the tests).
 """
@@ -51,19 +58,72 @@ def schedule_length(waves: Sequence[Sequence[Task]], world: int) -> int:
     return sum(-(-len(w) // world) for w in waves)
 
 
-def _all_gather_patches(mine: torch.Tensor, counts: List[int], group) -> List[torch.Tensor]:
-    """All-gather of per-rank patch slabs with unequal counts (padded to the max count)."""
+STask = Tuple[int, int, int, int]  # (stage, canvas, i, j)
+# relative cost of one patch per stage (batch-1 step time on MI355X x the reference's default timesteps
+# 1024 / 256 / 256, profiles/README.md); only the ORDER of the deal depends on it
+DEFAULT_STAGE_COST = {1: 38.8, 2: 7.5, 3: 68.0}
+
+
+def stage_waves(per_canvas_pos: Sequence[Sequence[G.Pos]], orientations: Sequence[int], stages: Sequence[int],
+                pipeline: bool = True) -> List[List[STask]]:
+    """Generalised waves over (stage, canvas, patch).  A task needs its own previous-stage output and the same-stage
+    outputs of its neighbours, so stage number k (0-based within `stages`) of patch wave w can run at step w + k.
+    pipeline=False gives the reference's order: all waves of a stage, then the next stage."""
+    waves = merged_waves(per_canvas_pos, orientations)
+    out: List[List[STask]] = []
+    if not pipeline:
+        for st in stages:
+            out.extend([[(st, c, i, j) for (c, i, j) in w] for w in waves])
+        return out
+    for g in range(len(waves) + len(stages) - 1):
+        cur: List[STask] = []
+        for k, st in enumerate(stages):
+            if 0 <= g - k < len(waves):
+                cur.extend((st, c, i, j) for (c, i, j) in waves[g - k])
+        out.append(cur)
+    return out
+
+
+def assign_tasks(wave: Sequence[STask], world: int, stage_cost: Optional[Dict[int, float]] = None) -> List[List[STask]]:
+    """Deal of one generalised wave: heaviest tasks first, each to the least-loaded rank, preferring rank
+    (j + canvas) % world (column affinity: the patch above sat on the same rank).  Deterministic on every rank."""
+    cost = dict(DEFAULT_STAGE_COST)
+    cost.update(stage_cost or {})
+    order = sorted(wave, key=lambda t: (-cost.get(t[0], 1.0), t[1], t[2], t[3]))
+    load = [0.0] * world
+    out: List[List[STask]] = [[] for _ in range(world)]
+    for t in order:
+        pref = (t[3] + t[1]) % world
+        best = min(load)
+        r = pref if load[pref] <= best + 1e-9 else load.index(best)
+        out[r].append(t)
+        load[r] += cost.get(t[0], 1.0)
+    return out
+
+
+def _all_gather_start(mine: torch.Tensor, counts: List[int], group):
+    """All-gather of per-rank patch slabs with unequal counts (padded to the max count), started asynchronously:
+    returns a function that waits and gives the per-rank slabs."""
     world = len(counts)
     if world == 1:
-        return [mine]
+        return lambda: [mine]
     mx = max(counts)
     shape = (mx,) + tuple(mine.shape[1:])
     send = torch.zeros(shape, device=mine.device, dtype=mine.dtype)
     if mine.shape[0]:
         send[: mine.shape[0]] = mine
     recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
-    return [r[:c] for r, c in zip(recv, counts)]
+    work = dist.all_gather(recv, send, group=group, async_op=True)
+
+    def finish():
+        work.wait()
+        return [r[:c] for r, c in zip(recv, counts)]
+
+    return finish
+
+
+def _all_gather_patches(mine: torch.Tensor, counts: List[int], group) -> List[torch.Tensor]:
+    return _all_gather_start(mine, counts, group)()
 
 
 def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence[Sequence[G.Pos]],
@@ -71,52 +131,63 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
                  num_patches_width: Sequence[int], orientations: Optional[Sequence[int]] = None,
                  lowres: Optional[Sequence[Optional[torch.Tensor]]] = None,
                  patch_width: Optional[int] = None, group=None,
-                 device: Optional[torch.device] = None) -> List[List[torch.Tensor]]:
+                 device: Optional[torch.device] = None, pipeline: bool = True,
+                 stage_cost: Optional[Dict[int, float]] = None) -> List[List[torch.Tensor]]:
     """Runs `stages` (e.g. (1,2,3)) over one or more canvases and returns, on every rank,
     `out[c][idx]` = (3,S,S) final-stage patch `idx` of canvas c (index order of patch_pos[c]).
 
     cond_images[c]: (N_c, Cc, 1024, 1024) or None; lowres[c]: optional (N_c,3,s,s) start images for
-    the first stage in `stages` (the reference's --ignore_unet_1 path, sample_ultra_res.py:417-420)."""
+    the first stage in `stages` (the reference's --ignore_unet_1 path, sample_ultra_res.py:417-420).
+    pipeline=False keeps the reference's barrier between the stages (same results: every task sees the same
+    inputs in either order)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     ncanvas = len(patch_pos)
+    stages = list(stages)
     orientations = list(orientations) if orientations is not None else [G.choose_orientation(p) for p in patch_pos]
     index = [{p: n for n, p in enumerate(pos)} for pos in patch_pos]
-    waves = merged_waves(patch_pos, orientations)
-    prev: List[Optional[List[torch.Tensor]]] = [None] * ncanvas
-    if lowres is not None:
-        prev = [None if l is None else [t for t in l] for l in lowres]
+    start_low = [None] * ncanvas if lowres is None else [None if l is None else list(l) for l in lowres]
+    # done[stage][canvas][(i, j)] = finished (3,S,S) patch, identical on every rank after the wave's exchange
+    done: Dict[int, List[Dict[G.Pos, torch.Tensor]]] = {st: [dict() for _ in range(ncanvas)] for st in stages}
+    prev_stage = {st: (stages[k - 1] if k > 0 else None) for k, st in enumerate(stages)}
 
-    for stage in stages:
-        S = G.PATCH_SIZES[stage]
-        done: List[Dict[G.Pos, torch.Tensor]] = [dict() for _ in range(ncanvas)]
-        for wave in waves:
-            parts = assign(wave, world)
-            mine = parts[rank]
-            outs = []
-            if mine:
-                lows, conds, ips, ims = [], [], [], []
-                for (c, i, j) in mine:
-                    idx = index[c][(i, j)]
-                    cond = None if cond_images[c] is None else cond_images[c][idx]
-                    ip, im = G.assemble_inpaint((i, j), patch_pos[c], done[c], S, overlap, orientations[c],
-                                                num_patches_width[c], cond_image=cond, patch_width=patch_width)
-                    lows.append(None if prev[c] is None else prev[c][idx])
-                    conds.append(cond)
-                    ips.append(ip)
-                    ims.append(im)
-                res = sample_fn(stage, mine, lows, conds, ips, ims)
-                outs = [r for r in res]
+    for wave in stage_waves(patch_pos, orientations, stages, pipeline):
+        parts = assign_tasks(wave, world, stage_cost)
+        mine = parts[rank]
+        wave_stages = sorted({t[0] for t in wave})
+        results: Dict[int, List[torch.Tensor]] = {}
+        for st in sorted({t[0] for t in mine}, reverse=True):   # heaviest stage first
+            S = G.PATCH_SIZES[st]
+            tasks = [t for t in mine if t[0] == st]
+            lows, conds, ips, ims = [], [], [], []
+            for (_, c, i, j) in tasks:
+                idx = index[c][(i, j)]
+                cond = None if cond_images[c] is None else cond_images[c][idx]
+                ip, im = G.assemble_inpaint((i, j), patch_pos[c], done[st][c], S, overlap, orientations[c],
+                                            num_patches_width[c], cond_image=cond, patch_width=patch_width)
+                ps = prev_stage[st]
+                low = done[ps][c][(i, j)] if ps is not None else (None if start_low[c] is None else start_low[c][idx])
+                lows.append(low)
+                conds.append(cond)
+                ips.append(ip)
+                ims.append(im)
+            results[st] = list(sample_fn(st, [(c, i, j) for (_, c, i, j) in tasks], lows, conds, ips, ims))
+        # one all-gather per stage present in the wave, all in flight together
+        pending = []
+        for st in wave_stages:
+            S = G.PATCH_SIZES[st]
+            outs = results.get(st, [])
             dev = device if device is not None else (outs[0].device if outs else torch.device("cpu"))
             slab = torch.stack(outs).to(dev) if outs else torch.zeros((0, 3, S, S), device=dev)
-            gathered = _all_gather_patches(slab.float().contiguous(), [len(p) for p in parts], group)
-            for r, tasks in enumerate(parts):
-                for n, (c, i, j) in enumerate(tasks):
-                    done[c][(i, j)] = gathered[r][n]
-        prev = [[done[c][p] for p in patch_pos[c]] for c in range(ncanvas)]
-        if dist.is_initialized() and world > 1:
-            dist.barrier(group=group)
-    return prev  # type: ignore[return-value]
+            per_rank = [[t for t in p if t[0] == st] for p in parts]
+            pending.append((st, per_rank, _all_gather_start(slab.float().contiguous(), [len(p) for p in per_rank], group)))
+        for st, per_rank, finish in pending:
+            gathered = finish()
+            for r, tasks in enumerate(per_rank):
+                for n, (_, c, i, j) in enumerate(tasks):
+                    done[st][c][(i, j)] = gathered[r][n]
+    last = stages[-1]
+    return [[done[last][c][p] for p in patch_pos[c]] for c in range(ncanvas)]
 
 
 def outpaint_canvas(sample_fn: Callable, num_patches_width: int, overlap: float = 0.25, canvases: int = 1,

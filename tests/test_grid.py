@@ -144,6 +144,83 @@ def test_two_rank_gloo_schedule_equals_single_process():
     assert single.shape == (2, 9, 3, 256, 256)
 
 
+def _run_grid3(world, rank=0, port=None, out=None, pipeline=True, canvases=3):
+    """3 canvases x 3 stages, 4x4 grids of mixed orientation - the shape of `bench.py --workload grid --canvases 3`."""
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    old = dict(G.PATCH_SIZES)
+    G.PATCH_SIZES.update({1: 8, 2: 16, 3: 32})
+    try:
+        n = 4
+        pos = [(i, j) for i in range(n) for j in range(n)]
+        g = torch.Generator().manual_seed(1)
+        conds = [torch.rand(n * n, 3, 8, 8, generator=g) for _ in range(canvases)]
+        res = D.sample_grids(_stub_sample_fn, (1, 2, 3), [pos] * canvases, conds, 0.25, [n] * canvases,
+                             orientations=[-1, 1, -1][:canvases], pipeline=pipeline)
+        flat = torch.stack([torch.stack(r) for r in res])
+        if out is not None:
+            out[rank] = flat
+        return flat
+    finally:
+        G.PATCH_SIZES.clear()
+        G.PATCH_SIZES.update(old)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+
+
+def _worker3(rank, world, port, out):
+    _run_grid3(world, rank, port, out)
+
+
+def test_four_rank_gloo_three_canvases_pipelined_equals_single_process_with_stage_barriers():
+    """world_size 4, --canvases 3, stages pipelined (a patch's stage s starts once its own stage s-1 and its
+    neighbours' stage s are done) against ONE process running the reference's order (stage barrier,
+    sample_ultra_res.py:264-270): bit-equal patches on every rank."""
+    single = _run_grid3(1, pipeline=False)
+    assert torch.equal(single, _run_grid3(1, pipeline=True))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = mp.Manager().dict()
+    mp.spawn(_worker3, args=(4, port, out), nprocs=4, join=True)
+    for r in range(4):
+        assert torch.equal(out[r], single), r
+    assert single.shape == (3, 16, 3, 32, 32)
+
+
+def test_stage_pipelining_and_the_deal_of_a_wave():
+    n = 8
+    pos = [(i, j) for i in range(n) for j in range(n)]
+    # one canvas, three stages: 2n - 1 patch waves -> 2n + 1 generalised waves instead of 3 (2n - 1)
+    gw = D.stage_waves([pos], [-1], (1, 2, 3))
+    assert len(gw) == 2 * n - 1 + 2 and len(D.stage_waves([pos], [-1], (1, 2, 3), pipeline=False)) == 3 * (2 * n - 1)
+    assert sorted(t for w in gw for t in w) == sorted((s, 0, i, j) for s in (1, 2, 3) for i, j in pos)
+    seen = set()
+    for w in gw:   # dependencies: previous stage of the same patch and same-stage neighbours are in EARLIER waves
+        for (s, c, i, j) in w:
+            assert s == 1 or (s - 1, c, i, j) in seen
+            for nb in ((i - 1, j), (i, j - 1), (i - 1, j - 1)):
+                assert nb[0] < 0 or nb[1] < 0 or (s, c) + nb in seen
+        seen.update(w)
+    # the single-stage slot bounds of SURVEY §8e are unchanged, and 3 canvases lift the 8-GPU bound past 6x
+    waves = D.merged_waves([pos], [-1])
+    assert [D.schedule_length(waves, g) for g in (1, 2, 4, 8)] == [64, 36, 22, 15]
+    w3 = D.merged_waves([pos] * 3, [-1] * 3)
+    assert 3 * 64 / D.schedule_length(w3, 8) > 6.0
+    # the deal: deterministic, heaviest first onto the least-loaded rank (weighted by the stage's cost), a column
+    # stays on its rank when the wave fits
+    wave = gw[9]
+    parts = D.assign_tasks(wave, 8)
+    assert sorted(t for p in parts for t in p) == sorted(wave) and parts == D.assign_tasks(list(reversed(wave)), 8)
+    cost = D.DEFAULT_STAGE_COST
+    load = [sum(cost[t[0]] for t in p) for p in parts]
+    assert max(load) <= sum(load) / 8 + max(cost.values()) and max(load) - min(load) <= max(cost.values())
+    assert [sum(1 for t in p if t[0] == 3) for p in parts] == [1] * 8      # the 8 stage-3 patches: one per rank
+    full = D.assign_tasks([(3, 0, i, 7 - i) for i in range(8)], 8)       # the longest anti-diagonal of stage 3
+    assert all(len(p) == 1 and p[0][3] % 8 == r for r, p in enumerate(full))
+
+
 def _np_rgb2hsv(arr):
     """skimage.color.rgb2hsv restated in numpy ((H,W,3) floats), the function the reference calls at
     sample_ultra_res.py:321."""
