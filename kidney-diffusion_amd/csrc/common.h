@@ -103,7 +103,12 @@ int launch_wino_out(const float* D, const float* bias, const float* res, int ldr
 // y = conv3x3(x) + bias (+ res): x dense NHWC [B][H][W][C] (already activated), y dense [B][H][W][N],
 // U from launch_wino_fused_pack (16*N*C floats).  wino_fused_ok states the shapes it takes.
 bool wino_fused_ok(int B, int H, int W, int C, int N);
-int launch_wino_fused_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s);
+int launch_wino_fused_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s, float scale = 1.0f);
+// wino_fused_gn_kernel evaluates SiLU as u / (1 + 2^u) on u = -log2(e) (A x + B): the affine of launch_gn_fold /
+// launch_gn_fold_seg carries WF_AB_SCALE and the weights packed for that kernel WF_U_SCALE = -ln 2 (the conv is
+// linear, so the factor left on the activated values moves into U)
+constexpr float WF_AB_SCALE = -1.4426950408889634f;
+constexpr float WF_U_SCALE = -0.6931471805599453f;
 int launch_wino_fused(const float* x, const float* U, const float* bias, const float* res, int ldres, float* y, int B,
                       int H, int W, int C, int N, hipStream_t s);
 

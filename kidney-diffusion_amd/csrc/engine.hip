@@ -876,8 +876,8 @@ struct Builder {
     const float* beta = P(gn_prefix + ".bias", Cin);
     const float* bias = P(conv_prefix + ".bias", Cout);
     const float* wsrc = raw(conv_prefix + ".weight", (int64_t)Cout * Cin * 9);
-    float* U = cached("winof:" + conv_prefix, (size_t)16 * Cout * Cin,
-                      [&](float* dst) { KD_THROW_IF(launch_wino_fused_pack(wsrc, dst, Cout, Cin, 0)); });
+    float* U = cached("winof_gn:" + conv_prefix, (size_t)16 * Cout * Cin,
+                      [&](float* dst) { KD_THROW_IF(launch_wino_fused_pack(wsrc, dst, Cout, Cin, 0, WF_U_SCALE)); });
     T ab = alloc_bytes((size_t)Bx * Cin * 2 * sizeof(float));
     T y = alloc(Bx, H, W, Cout);
     kd_unet* uu = u;

@@ -469,8 +469,8 @@ __global__ __launch_bounds__(256) void gn_fold_seg_kernel(SegSrc s0, SegSrc s1, 
       bb = bb * sc + sft;
     }
     const float m = (s1.partial && c >= s1.c0 && c < s1.c0 + 16 * s1.nseg) ? s1.ab_mul : s0.ab_mul;
-    ab[2 * ((int64_t)b * C + c)] = a * m;
-    ab[2 * ((int64_t)b * C + c) + 1] = bb;
+    ab[2 * ((int64_t)b * C + c)] = a * m * WF_AB_SCALE;   // (the fused kernel's activation form, common.h)
+    ab[2 * ((int64_t)b * C + c) + 1] = bb * WF_AB_SCALE;
   }
 }
 int launch_gn_fold_seg(SegSrc s0, SegSrc s1, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,

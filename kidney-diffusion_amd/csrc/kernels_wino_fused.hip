@@ -24,6 +24,8 @@
 // Result differs from the direct conv by re-association only.
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 namespace kd {
@@ -46,7 +48,7 @@ __host__ __device__ constexpr int64_t wf_uv_index(int64_t chunk, int p, int row,
 
 // OIHW 3x3 weights -> U = G g G^T in the order the kernel's DMA reads: [N/64][C/4] chunks of wf_uv_index
 __global__ __launch_bounds__(256) void wino_fused_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int N,
-                                                              int C) {
+                                                              int C, float scale) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)N * C) return;
   const int n = (int)(idx / C), c = (int)(idx % C);
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void wino_fused_pack_kernel(const float* __res
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int p = r * 4 + s;
-      U[wf_uv_index((int64_t)(n / 64) * nchunks + c / WF_K, p, n % 64, c % WF_K)] = u[s];
+      U[wf_uv_index((int64_t)(n / 64) * nchunks + c / WF_K, p, n % 64, c % WF_K)] = u[s] * scale;
     }
   }
 }
@@ -324,6 +326,13 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restr
 // activation as well.
 constexpr int WG_MAXC = 512;   // channels of the affine table kept in LDS
 
+// VAR: placement experiments of the chunk's three DMA pieces (KD_FWINO_VAR, profiles/README.md round 2):
+//   0 right behind the barrier (round 1); 1 waves 4-7 issue theirs behind their MFMAs; 2 every wave issues them
+//   between its two MFMA groups; 3 waves 0-3 between the groups, waves 4-7 behind the MFMAs
+//   V2: two V stages with compile-time indices instead of three with a run-time one (the single barrier per
+//   chunk already orders the last reads of V(c) before the first writes of V(c + 2))
+//   PEEL: steady-state loop iterations without the DMA liveness selects, interior patches without the padding mask
+template <int VAR, bool V2, bool PEEL>
 __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __restrict__ x, int ldx,
                                                                const float* __restrict__ ab,
                                                                const float* __restrict__ U,
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(1024))) float raw_0[WF_RAW], raw_1[WF_RAW], raw_2[WF_RAW], raw_3[WF_RAW];
   __shared__ __attribute__((aligned(1024))) float us_0[WF_UV], us_1[WF_UV], us_2[WF_UV], us_3[WF_UV];
-  __shared__ __attribute__((aligned(1024))) float vs[3 * WF_UV];
+  __shared__ __attribute__((aligned(1024))) float vs[(V2 ? 2 : 3) * WF_UV];
   __shared__ __attribute__((aligned(16))) float abl[2 * WG_MAXC];
   auto rawp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return raw_0; else if constexpr (decltype(S)::value == 1) return raw_1; else if constexpr (decltype(S)::value == 2) return raw_2; else return raw_3; };
   auto usp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return us_0; else if constexpr (decltype(S)::value == 1) return us_1; else if constexpr (decltype(S)::value == 2) return us_2; else return us_3; };
@@ -392,30 +401,36 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
     int iy, ix;
     aok[i] = slot_pixel((tid >> 2) + 128 * i, iy, ix);
   }
-  auto issue_raw = [&](int chunk, auto S) {
+  // LIVE (compile time): the chunk is known to exist - no select against the out-of-range offset that turns the
+  // DMA of a chunk past the end into zeros (the steady-state iterations of the loop)
+  auto issue_raw = [&](int chunk, auto S, auto LIVE) {
     __attribute__((address_space(3))) float* rb = (__attribute__((address_space(3))) float*)(rawp(S) + wave * 256);
     const uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t)(chunk * WF_K * 4));
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, rb, 16, chunk < nchunks ? voffX : OOB_OFF, sx, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, rb, 16, (decltype(LIVE)::value || chunk < nchunks) ? voffX : OOB_OFF, sx,
+                                             0, 0);
   };
-  auto issue_u = [&](int chunk, auto S) {
+  auto issue_u = [&](int chunk, auto S, auto LIVE) {
     __attribute__((address_space(3))) float* ub = (__attribute__((address_space(3))) float*)(usp(S) + wave * 256);
     const uint32_t su = __builtin_amdgcn_readfirstlane((uint32_t)(((nhalf * nchunks + chunk) * WF_UV) * 4));
-    const bool live = chunk < nchunks;
+    const bool live = decltype(LIVE)::value || chunk < nchunks;
 #pragma unroll
     for (int q = 0; q < 2; ++q)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, ub + q * 2048, 16, live ? (uint32_t)((q * 512 + tid) * 16) : OOB_OFF, su,
                                                0, 0);
   };
-  auto activate = [&](int chunk, auto S) {
-    const int cc = min(chunk, nchunks - 1) * WF_K + (tid & 3);
+  // MASK (compile time): the patch touches the image border, values of padding pixels are forced back to 0
+  auto activate = [&](int chunk, auto S, auto LIVE, auto MASK) {
+    const int cc = (decltype(LIVE)::value ? chunk : min(chunk, nchunks - 1)) * WF_K + (tid & 3);
     const float2 a2 = *(const float2*)(abl + 2 * cc);
     float* ap = rawp(S) + tid;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       if (i < 2 || tid < 324 * 4 - 1024) {
-        float v = ap[i * 512] * a2.x + a2.y;
-        v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));   // SiLU, hardware exp2 / reciprocal (about 1 ulp each)
-        ap[i * 512] = aok[i] ? v : 0.f;
+        // ab holds -log2(e) (A, B) (launch_gn_fold*), so u = -log2(e) v with v = A x + B, e^-v = 2^u, and
+        // u / (1 + 2^u) = -log2(e) SiLU(v): 5 VALU per value; the factor -ln 2 that is left sits in U (WF_U_SCALE)
+        const float u = ap[i * 512] * a2.x + a2.y;
+        const float v = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
+        ap[i * 512] = (!decltype(MASK)::value || aok[i]) ? v : 0.f;
       }
     }
   };
@@ -436,7 +451,9 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
   using S3 = std::integral_constant<int, 3>;
-  auto run = [&](auto HB) {
+  using LiveT = std::integral_constant<bool, true>;
+  using LiveF = std::integral_constant<bool, false>;
+  auto run = [&](auto HB, auto MASK) {
     constexpr int hb = decltype(HB)::value;
     const int roff = ((2 * tty + hb) * 18 + ttx) * 4 + tc;
     const int voffA = (int)wf_uv_index(0, (hb ? 3 : 0) * 4, tt, tc);
@@ -450,25 +467,52 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
 #pragma unroll
         for (int s = 0; s < 4; ++s) e[i][s] = rp[(i * 18 + RS[s]) * 4];
     };
-    auto write_v = [&](float* vst, const float (&e)[3][4]) {
+    // the four store addresses of a V stage (two positions each, 2 KB apart: beyond ds_write2's offset field).
+    // With static stages they are loop invariants; the empty asm keeps hipcc from re-deriving them with a
+    // v_add_u32 per store pair and chunk (4 VALU per chunk = 0.4 ms per step: every VALU slot in this loop is
+    // taken from the fp32 MFMA pipe)
+    typedef __attribute__((address_space(3))) float lds_float;
+    lds_float* vaddr[2][4];
+    if constexpr (V2) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        vaddr[st][0] = (lds_float*)(vs + st * WF_UV + voffA);
+        vaddr[st][1] = (lds_float*)(vs + st * WF_UV + voffA + VJ[2]);
+        vaddr[st][2] = (lds_float*)(vs + st * WF_UV + voffB);
+        vaddr[st][3] = (lds_float*)(vs + st * WF_UV + voffB + VJ[2]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(vaddr[st][q]));
+      }
+    }
+    auto write_v = [&](float* vst, const float (&e)[3][4], int vstage) {
       float ua[4], ub[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         ua[s] = e[0][s] - e[2][s];
         ub[s] = hb ? e[1][s] - e[0][s] : e[1][s] + e[2][s];
       }
-      float* va = vst + voffA;
-      float* vb = vst + voffB;
-      va[VJ[0]] = ua[0] - ua[2];
-      va[VJ[1]] = ua[1] + ua[2];
-      va[VJ[2]] = ua[2] - ua[1];
-      va[VJ[3]] = ua[1] - ua[3];
-      vb[VJ[0]] = ub[0] - ub[2];
-      vb[VJ[1]] = ub[1] + ub[2];
-      vb[VJ[2]] = ub[2] - ub[1];
-      vb[VJ[3]] = ub[1] - ub[3];
+      lds_float *va0, *va1, *vb0, *vb1;
+      if constexpr (V2) {
+        va0 = vstage ? vaddr[1][0] : vaddr[0][0];
+        va1 = vstage ? vaddr[1][1] : vaddr[0][1];
+        vb0 = vstage ? vaddr[1][2] : vaddr[0][2];
+        vb1 = vstage ? vaddr[1][3] : vaddr[0][3];
+      } else {
+        va0 = (lds_float*)(vst + voffA);
+        va1 = va0 + VJ[2];
+        vb0 = (lds_float*)(vst + voffB);
+        vb1 = vb0 + VJ[2];
+      }
+      va0[0] = ua[0] - ua[2];
+      va0[2] = ua[1] + ua[2];
+      va1[0] = ua[2] - ua[1];
+      va1[2] = ua[1] - ua[3];
+      vb0[0] = ub[0] - ub[2];
+      vb0[2] = ub[1] + ub[2];
+      vb1[0] = ub[2] - ub[1];
+      vb1[2] = ub[1] - ub[3];
     };
-    auto mfmas = [&](auto S, const float* vst) {
+    auto mfmas = [&](auto S, const float* vst, auto between) {
       const float* va = vst + aoff;
       const float* ub = usp(S) + boff;
       float4 a4[4], b4[4];
@@ -482,6 +526,7 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
         acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[i].x, acc[2 * i], 0, 0, 0);
         acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[i].z, acc[2 * i + 1], 0, 0, 0);
       }
+      between();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[i].y, acc[2 * i], 0, 0, 0);
@@ -491,58 +536,89 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
     // iteration c (stages of chunk j: raw j % 4, U j % 4, V j % 3): raw(c+2) and U(c) have landed (issued two
     // iterations ago), barrier, issue raw(c+4) and U(c+2), activate raw(c+2), MFMAs of chunk c, transform of
     // raw(c+1) (activated one iteration ago) into V(c+1)
-    int vcur = 0;   // V stage of chunk c
-    auto body = [&](int c, auto Sc, auto Sc1, auto Sc2) {
+    int vcur = 0;   // V stage of chunk c (run-time index form)
+    // where this half of the workgroup issues the chunk's DMA pieces: 0 behind the barrier, 1 between the two MFMA
+    // groups, 2 behind the MFMAs (the target stages were consumed before the barrier in every case)
+    constexpr int DMA_AT = VAR == 0 ? 0 : VAR == 1 ? (hb ? 2 : 0) : VAR == 2 ? 1 : (hb ? 2 : 1);
+    auto body = [&](int c, auto Sc, auto Sc1, auto Sc2, auto LIVE) {
       asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      issue_raw(c + 4, Sc);
-      issue_u(c + 2, Sc2);
-      const int vnext = vcur == 2 ? 0 : vcur + 1;
+      auto dma = [&]() {
+        issue_raw(c + 4, Sc, LIVE);
+        issue_u(c + 2, Sc2, LIVE);
+      };
+      if constexpr (DMA_AT == 0) dma();
+      if constexpr (V2) vcur = decltype(Sc)::value & 1;   // chunk c sits in raw / U stage c % 4: its parity is c's
+      const int vnext = V2 ? (vcur ^ 1) : (vcur == 2 ? 0 : vcur + 1);
       float e[3][4];
       load_raw(Sc1, e);
-      mfmas(Sc, vs + vcur * WF_UV);
-      activate(c + 2, Sc2);
-      write_v(vs + vnext * WF_UV, e);
+      mfmas(Sc, vs + vcur * WF_UV, [&]() {
+        if constexpr (DMA_AT == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          dma();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      if constexpr (DMA_AT == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        dma();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      activate(c + 2, Sc2, LIVE, MASK);
+      write_v(vs + vnext * WF_UV, e, vnext);
       vcur = vnext;
     };
     {
       float e[3][4];
       load_raw(S0{}, e);
-      write_v(vs, e);
+      write_v(vs, e, 0);
     }
-    for (int c = 0; c < nchunks; c += 4) {
-      body(c, S0{}, S1{}, S2{});
-      body(c + 1, S1{}, S2{}, S3{});
-      body(c + 2, S2{}, S3{}, S0{});
-      body(c + 3, S3{}, S0{}, S1{});
+    int c = 0;
+    if constexpr (PEEL) {
+      for (; c + 8 <= nchunks; c += 4) {   // steady state: every chunk these four bodies prefetch exists
+        body(c, S0{}, S1{}, S2{}, LiveT{});
+        body(c + 1, S1{}, S2{}, S3{}, LiveT{});
+        body(c + 2, S2{}, S3{}, S0{}, LiveT{});
+        body(c + 3, S3{}, S0{}, S1{}, LiveT{});
+      }
+    }
+    for (; c < nchunks; c += 4) {
+      body(c, S0{}, S1{}, S2{}, LiveF{});
+      body(c + 1, S1{}, S2{}, S3{}, LiveF{});
+      body(c + 2, S2{}, S3{}, S0{}, LiveF{});
+      body(c + 3, S3{}, S0{}, S1{}, LiveF{});
     }
   };
   // prologue: the first five pieces stand in for "two iterations ago", the last three for "one iteration ago"
-  issue_raw(0, S0{});
-  issue_u(0, S0{});
-  issue_raw(1, S1{});
-  issue_raw(2, S2{});
-  issue_raw(3, S3{});
-  issue_u(1, S1{});
+  issue_raw(0, S0{}, LiveF{});
+  issue_u(0, S0{}, LiveF{});
+  issue_raw(1, S1{}, LiveF{});
+  issue_raw(2, S2{}, LiveF{});
+  issue_raw(3, S3{}, LiveF{});
+  issue_u(1, S1{}, LiveF{});
   if (tid < C) *(float2*)(abl + 2 * tid) = abv;
   asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // raw(0), U(0), raw(1) landed
   __builtin_amdgcn_s_barrier();
-  activate(0, S0{});
-  activate(1, S1{});
+  activate(0, S0{}, LiveF{}, LiveT{});
+  activate(1, S1{}, LiveF{}, LiveT{});
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  // interior patches (the whole 18 x 18 halo inside the image) run the loop without the padding mask
+  const bool border = !PEEL || y0 == 0 || x0 == 0 || y0 + 16 >= H || x0 + 16 >= W;
   if (ph == 0) {
-    run(std::integral_constant<int, 0>{});
+    if (border) run(std::integral_constant<int, 0>{}, LiveT{});
+    else run(std::integral_constant<int, 0>{}, LiveF{});
   } else {
     __builtin_amdgcn_s_setprio(1);
-    run(std::integral_constant<int, 1>{});
+    if (border) run(std::integral_constant<int, 1>{}, LiveT{});
+    else run(std::integral_constant<int, 1>{}, LiveF{});
     __builtin_amdgcn_s_setprio(0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   const int pair = wm * 2 + wn;
-  float4* ex = (float4*)(pair < 3 ? vs + pair * WF_UV : us_0);
+  float4* ex = (float4*)(pair < (V2 ? 2 : 3) ? vs + pair * WF_UV : (V2 && pair == 2) ? us_1 : us_0);
   float4 part[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -622,10 +698,11 @@ bool wino_fused_ok(int B, int H, int W, int C, int N) {
          (int64_t)B * (H / 16) * (W / 16) * (N / 64) < 0x7fffffff;
 }
 
-int launch_wino_fused_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s) {
+int launch_wino_fused_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s, float scale) {
   KD_REQUIRE(O % 64 == 0 && I % WF_K == 0, "fused Winograd weights need Cout % 64 == 0 and Cin % 4 == 0");
   const int64_t total = (int64_t)O * I;
-  hipLaunchKernelGGL(wino_fused_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oihw, U, O, I);
+  hipLaunchKernelGGL(wino_fused_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oihw, U, O, I,
+                     scale);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -658,8 +735,8 @@ __global__ __launch_bounds__(256) void gn_fold_kernel(const float* __restrict__ 
     a *= sc;
     bb = bb * sc + sh;
   }
-  ab[2 * idx] = a;
-  ab[2 * idx + 1] = bb;
+  ab[2 * idx] = a * WF_AB_SCALE;   // the fused kernel's activation works on -log2(e) (A x + B)
+  ab[2 * idx + 1] = bb * WF_AB_SCALE;
 }
 
 int launch_gn_fold(const float* stats, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
@@ -685,8 +762,19 @@ int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* 
   KD_REQUIRE(!out_partial || (out_groups > 0 && N % out_groups == 0 && (N / out_groups) % 16 == 0),
              "output statistics need groups of a multiple of 16 channels");
   const unsigned grid = (unsigned)((int64_t)B * (H / 16) * (W / 16) * (N / 64));
-  hipLaunchKernelGGL(wino_fused_gn_kernel, dim3(grid), dim3(512), 0, s, x, ldx, ab, U, bias, res, ldres, y, B, H, W, C, N,
-                     out_partial, out_groups);
+  // default: two static V stages + peeled steady-state loop (round 2: -1.0 ms per step against the round-1 loop);
+  // KD_FWINO_VAR (read once) selects the other forms measured in profiles/README.md: 100 = round-1 loop,
+  // 1 / 2 = DMA pieces issued later in the chunk, 10 = static V stages only
+  static const int var = getenv("KD_FWINO_VAR") ? atoi(getenv("KD_FWINO_VAR")) : 20;
+#define KD_WFGN(V, T2, PL)                                                                                               \
+  hipLaunchKernelGGL((wino_fused_gn_kernel<V, T2, PL>), dim3(grid), dim3(512), 0, s, x, ldx, ab, U, bias, res, ldres, y, B, H, \
+                     W, C, N, out_partial, out_groups)
+  if (var == 1) KD_WFGN(1, false, false);
+  else if (var == 2) KD_WFGN(2, false, false);
+  else if (var == 10) KD_WFGN(0, true, false);
+  else if (var == 100) KD_WFGN(0, false, false);
+  else KD_WFGN(0, true, true);
+#undef KD_WFGN
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

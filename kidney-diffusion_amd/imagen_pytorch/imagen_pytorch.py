@@ -562,7 +562,8 @@ class Unet(nn.Module):
         hid = torch.empty(b, self.time_cond_dim, device=device)
         E.check(E.load().kd_unet_text_cond(handle, E.ptr(text_embeds), E.ptr(mask), L, int(bool(drop)), E.ptr(tok),
                                            E.ptr(hid), E.current_stream()))
-        torch.cuda.current_stream().synchronize()  # text_embeds / mask temporaries may be released now
+        # no host synchronisation: the launches are on torch's current stream, and torch's caching allocator
+        # hands the memory of text_embeds / mask to later allocations of the SAME stream only (stream-ordered reuse)
         return tok, hid
 
     def forward_with_cond_scale(self, *args, cond_scale=1.0, **kwargs):
@@ -899,7 +900,9 @@ class Imagen(nn.Module):
                 E.check(lib.kd_sample_finalize(h, C.byref(args), E.ptr(img), E.current_stream()))
             else:
                 E.check(lib.kd_sample_loop(h, C.byref(sc), C.byref(args), E.ptr(img), E.current_stream()))
-            torch.cuda.current_stream().synchronize()  # host tables / noise buffers must outlive the launches
+            # No host synchronisation here: the engine copies the schedule tables into its own staging buffer inside
+            # the call, and the injected-noise tensors in `keep` are device memory of torch's current stream - the
+            # caching allocator re-uses it for later allocations of that stream only, i.e. after these launches.
             del keep
-            img = img.clone()  # the stable buffer is overwritten by the next call
+            img = img.clone()  # the stable buffer is overwritten by the next call (stream-ordered copy)
         return img
