@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Files one run of profiles/collect.sh under profiles/ and writes profiles/current.json, the profile-derived
+numbers bench.py quotes next to its live measurements (rocprofv3's average launch duration of the dominant
+kernel, PMC traffic per launch / per step).
+
+    python3 profiles/make_current.py gpurun_out/prof_<tag> <tag>
+"""
+import csv
+import json
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+DOMINANT = "wino_fused_gn_kernel"
+
+
+def main():
+    src, tag = Path(sys.argv[1]), sys.argv[2]
+    for name in ("kernel_stats.csv", "pmc_fetch.csv", "pmc_write.csv", "sq_summary.json", "stats_bench.json"):
+        shutil.copy(src / name, HERE / f"{tag}_{name}")
+    out = subprocess.run([sys.executable, str(HERE / "reduce_pmc.py"), str(src / "pmc_fetch.csv"), str(src / "pmc_write.csv"), "4"],
+                         capture_output=True, text=True, check=True).stdout
+    traffic = json.loads(out)
+    shutil.copy(HERE / "hbm_traffic.json", HERE / f"{tag}_hbm_traffic.json")
+    rows = list(csv.DictReader(open(src / "kernel_stats.csv")))
+    dom = next(r for r in rows if DOMINANT in r["Name"])
+    steps = 7  # collect.sh: --steps 5 --warmup 2
+    launches_per_step = int(dom["Calls"]) / steps
+    dom_bytes = next(v for k, v in traffic["by_kernel_GB_per_step"].items() if DOMINANT in k) * 1e9
+    sq = json.loads((src / "sq_summary.json").read_text())
+    dom_sq = next(k for k in sq["kernels"] if DOMINANT in k["kernel"])
+    cur = {
+        "tag": tag,
+        "dominant_kernel": dom["Name"].split("(")[0],
+        "dominant_avg_us": float(dom["AverageNs"]) / 1e3,
+        "dominant_launches_per_step": launches_per_step,
+        "dominant_share_of_kernel_time": float(dom["Percentage"]) / 100.0,
+        "dominant_bytes_per_launch": dom_bytes / launches_per_step,
+        "dominant_mfma_util": dom_sq["mfma_util"],
+        "bytes_per_step": traffic["bytes_per_step"],
+        "source": f"profiles/{tag}_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 2 "
+                  f"--no-cpu-baseline --no-kernel-classes`), profiles/{tag}_pmc_fetch.csv + {tag}_pmc_write.csv (separate "
+                  "--pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md), "
+                  f"profiles/{tag}_sq_summary.json (SQ_VALU_MFMA_BUSY_CYCLES pass)",
+    }
+    (HERE / "current.json").write_text(json.dumps(cur, indent=1) + "\n")
+    print(json.dumps(cur, indent=1))
+
+
+if __name__ == "__main__":
+    main()
