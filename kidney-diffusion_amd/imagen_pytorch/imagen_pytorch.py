@@ -441,9 +441,12 @@ class Unet(nn.Module):
         d["_engines"], d["_io_buffers"], d["_engines_fingerprint"] = {}, {}, None
         return d
 
-    def _apply(self, fn, *a, **k):  # .to()/.cuda()/.float() move parameters: packed copies are stale
-        self.invalidate_engine()
-        return super()._apply(fn, *a, **k)
+    def _apply(self, fn, *a, **k):  # .to()/.cuda()/.float(): packed copies are stale iff a parameter really moved
+        before = self._weights_fingerprint() if self._engines else None
+        out = super()._apply(fn, *a, **k)
+        if before is not None and before != self._weights_fingerprint():
+            self.invalidate_engine()
+        return out
 
     def __del__(self):
         try:

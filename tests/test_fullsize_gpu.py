@@ -212,6 +212,41 @@ def test_unet3_on_a_256_crop_forward_matches_oracle(device):
     assert abs(gmac - 376.7) / 376.7 < 0.01, gmac
 
 
+def test_c4_full_size_cascade_64_256_1024_matches_oracle(device):
+    """BASELINE configs[3]: the full 3-stage cascade 64 -> 256 -> 1024 at the reference's dims
+    (train_ultra_res.py:29-60), one sample() call through all three UNets with the hipGraph-replayed inner loop,
+    against the oracle: batch 1, two timesteps per stage (26 TFLOP on the host cores).  The batch-8 run of the
+    same cascade is checked through properties below (the oracle cannot run it in a test)."""
+    import imagen_pytorch as ip
+
+    u1 = dict(dim=256, dim_mults=(1, 2, 4, 8), num_resnet_blocks=3, layer_attns=(F_, T_, T_, T_),
+              layer_cross_attns=(F_, T_, T_, T_), cond_images_channels=3)   # train_ultra_res.py:29-36
+    ous = [H.randomize_(R.Unet(**u1, cond_on_text=False, text_embed_dim=None), 81).eval(), _oracle("ultra2", True, 82),
+           _oracle("ultra3", True, 83)]
+    kw = dict(image_sizes=(64, 256, 1024), timesteps=(2, 2, 2), pred_objectives=("noise", "noise", "noise"),
+              condition_on_text=False)
+    oim = RS.Imagen(ous, **kw)
+    pim = ip.Imagen([ip.Unet(**u._locals) for u in oim.unets], random_crop_sizes=(None, None, 256), **kw)
+    pim.load_state_dict(oim.state_dict(), strict=True)
+    del ous
+    pim = pim.to(device)
+    g = torch.Generator().manual_seed(14)
+    cond = torch.rand(1, 3, 1024, 1024, generator=g)
+    nf = RS.generator_noise_fn(7)
+    ref = oim.sample(noise_fn=nf, batch_size=1, cond_images=cond, return_all_unet_outputs=True)
+    got = pim.sample(noise_fn=nf, batch_size=1, cond_images=cond.to(device), return_all_unet_outputs=True, device=device)
+    for stage, (a, b) in enumerate(zip(got, ref), 1):
+        err = float((a.cpu() - b).abs().max())
+        print(f"C4 cascade stage {stage}: max|diff| {err:.3e}")
+        assert err < SAMPLE_ABS * stage, (stage, err)
+    del oim, ref
+    # batch 8 (configs[3]'s batch) on the engine: seeded, deterministic, in range; every sample differs
+    a = pim.sample(batch_size=8, cond_images=cond.to(device).expand(8, -1, -1, -1), seed=3, device=device)
+    b = pim.sample(batch_size=8, cond_images=cond.to(device).expand(8, -1, -1, -1), seed=3, device=device)
+    assert a.shape == (8, 3, 1024, 1024) and torch.equal(a, b) and a.min() >= 0 and a.max() <= 1
+    assert all(not torch.equal(a[0], a[i]) for i in range(1, 8))
+
+
 # ------------------------------------------------------------------------------- 3-stage cascade, chained
 def test_three_stage_cascade_chained_matches_oracle(device):
     """BASELINE configs[3] structure (64 -> 256 -> 1024 cascade, one sample() call through all three UNets,
