@@ -697,7 +697,8 @@ static bool fast_shape_ok(const ConvParams& p) {
 int conv_ksplit(const ConvParams& p) {
   if (!fast_shape_ok(p) || p.wz_rows > 0 || p.Cout < 64 || (p.Cout & 3)) return 1;
   const int64_t M = (int64_t)p.B * p.Ho * p.Wo;
-  const int64_t tiles = ((M + 127) / 128) * ((p.Cout + 63) / 64);
+  // (M <= 64 runs 64 x 128 tiles, see launch_conv_igemm: half as many tiles as 128 x 64 counts here)
+  const int64_t tiles = M <= 64 ? (p.Cout + 127) / 128 : ((M + 127) / 128) * ((p.Cout + 63) / 64);
   const int nchunks = p.KH * p.KW * (p.Cin / BK);
   if (tiles >= 256 || nchunks < 16) return 1;
   const int want = (int)((768 + tiles - 1) / tiles);
@@ -739,8 +740,15 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     KD_REQUIRE(((uintptr_t)p.partial & 15) == 0, "split-K partial buffer must be 16-B aligned");
     ConvParams q = p;
     q.ksplit = ks;
-    dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 63) / 64, ks);
-    hipLaunchKernelGGL((conv_buf_kernel<128, 64, 2, 2, 3>), grid, dim3(256), 0, s, q);
+    if (M <= 64) {
+      // an 8x8 map of a batch-1 patch: 64-row tiles (a 128-row tile would spend half its MFMAs on padding and
+      // these launches, K up to 9 x 3072, were bound by exactly that: 124 us for 226 MB of weights), 128 columns
+      dim3 grid(1, (p.Cout + 127) / 128, ks);
+      hipLaunchKernelGGL((conv_buf_kernel<64, 128, 1, 4, 3>), grid, dim3(256), 0, s, q);
+    } else {
+      dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 63) / 64, ks);
+      hipLaunchKernelGGL((conv_buf_kernel<128, 64, 2, 2, 3>), grid, dim3(256), 0, s, q);
+    }
     const int64_t total = M * (p.Cout / 4);
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, q, M);
     KD_HIP_CHECK(hipGetLastError());

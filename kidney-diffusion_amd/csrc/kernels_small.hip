@@ -26,12 +26,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 // v_mfma_f32_32x32x2_f32 keeps the arithmetic exact fp32 and leaves the VALU to the activation.
 constexpr int SKM_UNROLL = 8;
 
-__global__ __launch_bounds__(64) void linear_skinny_mfma_kernel(const float* __restrict__ x, int ldx,
-                                                               const float* __restrict__ w,
-                                                               const float* __restrict__ bias,
-                                                               float* __restrict__ y, int ldy, int M, int K, int N,
-                                                               int in_act, int act) {
-  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+// KW waves per workgroup split K between them (wave w takes a contiguous K range) and wave 0 adds the partial
+// tiles through LDS in wave order: 4x the loads in flight for the same 32 output columns.  A batch-1 patch streams
+// 228 MB of time-MLP weights through N/32 = 1744 single-wave workgroups otherwise (2 TB/s), and a GlobalContext FC
+// of 2048 -> 1024 through 32 of them (0.13 TB/s).
+template <int KW>
+__global__ __launch_bounds__(64 * KW) void linear_skinny_mfma_kernel(const float* __restrict__ x, int ldx,
+                                                                    const float* __restrict__ w,
+                                                                    const float* __restrict__ bias,
+                                                                    float* __restrict__ y, int ldy, int M, int K, int N,
+                                                                    int in_act, int act) {
+  __shared__ float part[KW > 1 ? (KW - 1) * 16 * 64 : 1];
+  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int kw = threadIdx.x >> 6;
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
   const int n = min(n0 + i, N - 1);  // clamped: rows past N are computed and dropped
   const int m = m0 + i;
@@ -42,12 +49,14 @@ __global__ __launch_bounds__(64) void linear_skinny_mfma_kernel(const float* __r
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < K; k0 += 8 * SKM_UNROLL) {
+  const int kper = KW > 1 ? ((K + KW * 8 * SKM_UNROLL - 1) / (KW * 8 * SKM_UNROLL)) * (8 * SKM_UNROLL) : K;
+  const int k_lo = kw * kper, k_hi = min(K, k_lo + kper);
+  for (int k0 = k_lo; k0 < k_hi; k0 += 8 * SKM_UNROLL) {
     f32x4 a[SKM_UNROLL], b[SKM_UNROLL];
 #pragma unroll
     for (int u = 0; u < SKM_UNROLL; ++u) {
       int k = k0 + 8 * u + 4 * h;
-      bool ok = k < K;  // K % 4 == 0, so a 4-wide slice is either fully inside or outside
+      bool ok = k < k_hi;  // K % 4 == 0 and kper % 64 == 0, so a 4-wide slice is either fully inside or outside
       a[u] = ok ? *(const f32x4*)(wp + k0 + 8 * u) : z;
       b[u] = (ok && m_ok) ? *(const f32x4*)(xp + k0 + 8 * u) : z;
     }
@@ -60,6 +69,18 @@ __global__ __launch_bounds__(64) void linear_skinny_mfma_kernel(const float* __r
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][s], b[u][s], acc, 0, 0, 0);
     }
+  }
+  if (KW > 1) {   // fixed-order sum of the K ranges
+    if (kw > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[((kw - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kw > 0) return;
+#pragma unroll
+    for (int q = 0; q < KW - 1; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += part[(q * 16 + r) * 64 + lane];
   }
   // D[i=n][j=m]: col = lane&31 = m, row = (r&3) + 8*(r>>2) + 4*h
   if (!m_ok) return;
@@ -91,7 +112,10 @@ int launch_linear_skinny(const float* x, int ldx, const float* w, const float* b
   const bool mfma_ok = (K & 3) == 0 && (ldx & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)w) & 15) == 0;
   if (!mfma_ok) return launch_linear_skinny_valu(x, ldx, w, bias, y, ldy, M, K, N, in_act, act, s);
   dim3 grid((N + 31) / 32, (M + 31) / 32);
-  hipLaunchKernelGGL(linear_skinny_mfma_kernel, grid, dim3(64), 0, s, x, ldx, w, bias, y, ldy, M, K, N, in_act, act);
+  if (K >= 512)
+    hipLaunchKernelGGL(linear_skinny_mfma_kernel<4>, grid, dim3(256), 0, s, x, ldx, w, bias, y, ldy, M, K, N, in_act, act);
+  else
+    hipLaunchKernelGGL(linear_skinny_mfma_kernel<1>, grid, dim3(64), 0, s, x, ldx, w, bias, y, ldy, M, K, N, in_act, act);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
