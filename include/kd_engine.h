@@ -246,6 +246,11 @@ int kd_gn_conv3x3_winograd_fused_nhwc(const float* d_x, const float* d_gamma, co
 /* (d_out_stats, may be NULL: [B, G, 2] = (mean, rstd) of y per image and group of Cout / G channels, reduced
  * from the partial sums the kernel's epilogue leaves for the GroupNorm of the next layer; needs
  * (Cout / G) % 16 == 0.) */
+/* The UNet's initial cross-embed convolution (three stride-1 convs k = 3 / 7 / 15) over a 3-plane NCHW
+ * image in the plan's one-kernel form: y NHWC [B][S][S][n3+n7+n15] = cat(conv3, conv7, conv15)(x) + bias.
+ * d_w3 / d_w7 / d_w15: OIHW [n][3][k][k].  Needs S % 32 == 0 and n3 <= 64, n7 <= 32, n15 <= 32. */
+int kd_init_conv_nchw(const float* d_x, const float* d_w3, const float* d_w7, const float* d_w15,
+                      const float* d_bias, float* d_y, int B, int S, int n3, int n7, int n15, void* stream);
 /* GroupNorm(G) + optional FiLM (scale+1, shift: [B,2C] = [scale | shift]) + SiLU, NHWC. */
 int kd_groupnorm_silu_nhwc(const float* d_x, const float* d_gamma, const float* d_beta,
                            const float* d_scale_shift, float* d_y, int B, int HW, int C, int G,

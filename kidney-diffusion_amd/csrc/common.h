@@ -196,6 +196,17 @@ size_t gca_scratch_floats(int B, int HW, int C);
 // time embedding: out[b][0]=t, [1..h]=sin(t*w*2pi), [h+1..2h]=cos
 int launch_sinu_emb(const float* t, const float* w, float* out, int B, int half, hipStream_t s);
 
+// ---- the init cross-embed convs over x's 3 planes in one kernel (kernels_init.hip)
+bool init_conv_fused_ok(int S, int n3, int n7, int n15);
+size_t init_conv_weight_floats(int n3, int n7, int n15);
+// w3 / w7 / w15: OIHW weights over Itot input channels, of which c0 .. c0 + 2 are x's planes
+int launch_init_conv_pack(const float* w3, const float* w7, const float* w15, float* out, int n3, int n7, int n15, int Itot,
+                          int c0, hipStream_t s);
+// y[b][py][px][0 .. n3+n7+n15) (row stride ldy) = cat(conv3, conv7, conv15)(x) + (bias | res); seg: GroupNorm partials
+// [B][C/16][S*S/32][2] or nullptr
+int launch_init_conv(const float* x_nchw, const float* wp, const float* bias, const float* res, float* y, int ldy,
+                     double* seg, int B, int S, int n3, int n7, int n15, hipStream_t s);
+
 // ---- final conv to 3 channels (kernels_final.hip)
 int launch_pack_final(const float* w_oihw, float* w_packed, int Ctot, int C, hipStream_t s);
 int launch_final_static(const float* lowres, const float* w_oihw, const float* bias, float* stat, int Ctot, int c0,

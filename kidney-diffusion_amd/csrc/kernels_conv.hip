@@ -15,6 +15,8 @@
 // summation label, so the pairing is consistent.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace kd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -761,7 +763,15 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     // prologue/epilogue; short-K 1x1 convs run as two 128x128 workgroups per CU, which overlap one
     // tile's epilogue with the other's loop (measured in the step: 3x3 Cin=128 layers still prefer 256x128)
     const int k_chunks = p.KH * p.KW * (p.Cin / BK);
-    if (p.KH * p.KW == 1 && k_chunks <= 8 && p.wz_rows == 0) {
+    static const int shortk = getenv("KD_SHORTK_TILE") ? atoi(getenv("KD_SHORTK_TILE")) : 0;   // experiment switch
+    if (p.KH * p.KW == 1 && k_chunks <= 8 && p.wz_rows == 0 && shortk == 1 &&
+        ((M + 127) / 128) * ((p.Cout + 127) / 128) >= 256) {
+      dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 127) / 128);
+      hipLaunchKernelGGL((conv_buf_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, s, p);
+    } else if (p.KH * p.KW == 1 && k_chunks <= 8 && p.wz_rows == 0 && shortk == 2 && tiles256 >= 256) {
+      dim3 grid((unsigned)((M + 255) / 256), (p.Cout + 127) / 128);
+      hipLaunchKernelGGL((conv_buf_kernel<256, 128, 4, 2, 2>), grid, dim3(512), 0, s, p);
+    } else if (p.KH * p.KW == 1 && k_chunks <= 8 && p.wz_rows == 0) {
       // 1x1 convs with K <= 256 (ResnetBlock skip convs with the gate epilogue, pixel-shuffle upsamples)
       // move as many bytes as they compute: three 128x64 workgroups per CU keep more loads in flight
       // (measured -12..16 % on them; the Winograd GEMMs of the same K lose 4 % with this shape)

@@ -539,10 +539,15 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
     int vcur = 0;   // V stage of chunk c (run-time index form)
     // where this half of the workgroup issues the chunk's DMA pieces: 0 behind the barrier, 1 between the two MFMA
     // groups, 2 behind the MFMAs (the target stages were consumed before the barrier in every case)
-    constexpr int DMA_AT = VAR == 0 ? 0 : VAR == 1 ? (hb ? 2 : 0) : VAR == 2 ? 1 : (hb ? 2 : 1);
+    constexpr int DMA_AT = (VAR == 0 || VAR >= 4) ? 0 : VAR == 1 ? (hb ? 2 : 0) : VAR == 2 ? 1 : (hb ? 2 : 1);
     auto body = [&](int c, auto Sc, auto Sc1, auto Sc2, auto LIVE) {
       asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      // VAR 4 / 5: timing ablations with WRONG results (races): every other barrier / no barrier in the loop
+      if constexpr (VAR == 4) {
+        if constexpr ((decltype(Sc)::value & 1) == 0) __builtin_amdgcn_s_barrier();
+      } else if constexpr (VAR != 5) {
+        __builtin_amdgcn_s_barrier();
+      }
       auto dma = [&]() {
         issue_raw(c + 4, Sc, LIVE);
         issue_u(c + 2, Sc2, LIVE);
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
     }
     gs1 += __shfl_xor(gs1, 32, 64);
     gs2 += __shfl_xor(gs2, 32, 64);
-    if ((lane & 47) == 0 || (lane & 47) == 16) {   // lanes 0 and 16: channel segments 0 and 1 of this wave
+    if ((lane & 47) == 0) {   // lanes 0 and 16: channel segments 0 and 1 of this wave
       const int Cg = N / oG;
       const int cabs = n0 + wn * 32 + (lane & 16);
       const int g = cabs / Cg, cseg = (cabs - g * Cg) >> 4;
@@ -771,6 +776,8 @@ int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* 
                      W, C, N, out_partial, out_groups)
   if (var == 1) KD_WFGN(1, false, false);
   else if (var == 2) KD_WFGN(2, false, false);
+  else if (var == 4) KD_WFGN(4, true, true);
+  else if (var == 5) KD_WFGN(5, true, true);
   else if (var == 10) KD_WFGN(0, true, false);
   else if (var == 100) KD_WFGN(0, false, false);
   else KD_WFGN(0, true, true);

@@ -80,6 +80,37 @@ def test_conv_igemm(lib, device, B, H, W, Cin, Cout, K, stride, pad, act):
     assert err <= max(3 * err_cpu, CONV_REL), (err, err_cpu)
 
 
+@pytest.mark.parametrize("B,S,n3,n7,n15", [
+    (2, 64, 64, 32, 32),      # dim 128: the SR UNets' init conv (two 32-row tiles for the k = 3 conv)
+    (1, 32, 16, 8, 8),        # dim 32 (test UNets): partial 32-row tiles
+    (3, 96, 32, 16, 16),      # dim 64, S not a power of two, tiles cross image borders on every side
+])
+def test_init_cross_embed_conv_fused(lib, device, B, S, n3, n7, n15):
+    """The three init convs (k = 3 / 7 / 15, zero padding k // 2) over a 3-plane NCHW image in one persistent
+    kernel, against torch conv2d in fp64."""
+    E = _E()
+    x = torch.randn(B, 3, S, S, generator=g(1))
+    ws = [torch.randn(n, 3, k, k, generator=g(10 + k)) * (3 * k * k) ** -0.5 for n, k in ((n3, 3), (n7, 7), (n15, 15))]
+    b = torch.randn(n3 + n7 + n15, generator=g(4))
+    parts64 = [F.conv2d(x.double(), w.double(), padding=w.shape[-1] // 2) for w in ws]
+    ref = torch.cat(parts64, 1) + b.double()[None, :, None, None]
+    ref32 = torch.cat([F.conv2d(x, w, padding=w.shape[-1] // 2) for w in ws], 1) + b[None, :, None, None]
+    xd, bd = x.to(device), b.to(device)
+    wd = [w.to(device) for w in ws]
+    y = torch.full((B, S, S, n3 + n7 + n15), float("nan"), device=device)
+    E.check(lib.kd_init_conv_nchw(E.ptr(xd), E.ptr(wd[0]), E.ptr(wd[1]), E.ptr(wd[2]), E.ptr(bd), E.ptr(y), B, S, n3, n7,
+                                  n15, E.current_stream()))
+    got = y.permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    err = float((got.double() - ref).norm() / ref.norm())
+    err_cpu = float((ref32.double() - ref).norm() / ref.norm())
+    assert err <= max(3 * err_cpu, CONV_REL), (err, err_cpu)
+    # per conv: nothing leaks between the channel groups
+    for sl, p64 in zip((slice(0, n3), slice(n3, n3 + n7), slice(n3 + n7, None)), parts64):
+        e = float((got[:, sl].double() - (p64 + b.double()[None, sl, None, None])).norm() / p64.norm())
+        assert e <= max(3 * err_cpu, CONV_REL), (sl, e)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [
     (2, 64, 64, 128, 512),    # register epilogue: Co = 128, Wo = 64 (the SR UNet's 128 -> 256 upsample, scaled down)
     (1, 32, 96, 64, 128),     # register epilogue, Co = 32 (one lane group per (i, j)), H != W
