@@ -326,13 +326,11 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restr
 // activation as well.
 constexpr int WG_MAXC = 512;   // channels of the affine table kept in LDS
 
-// VAR: placement experiments of the chunk's three DMA pieces (KD_FWINO_VAR, profiles/README.md round 2):
-//   0 right behind the barrier (round 1); 1 waves 4-7 issue theirs behind their MFMAs; 2 every wave issues them
-//   between its two MFMA groups; 3 waves 0-3 between the groups, waves 4-7 behind the MFMAs
-//   V2: two V stages with compile-time indices instead of three with a run-time one (the single barrier per
-//   chunk already orders the last reads of V(c) before the first writes of V(c + 2))
-//   PEEL: steady-state loop iterations without the DMA liveness selects, interior patches without the padding mask
-template <int VAR, bool V2, bool PEEL>
+// Two V stages with compile-time indices (the single barrier per chunk already orders the last reads of V(c) before
+// the first writes of V(c + 2)); the steady-state loop iterations run without the DMA liveness selects, interior
+// patches without the padding mask.  (Measured and dropped, profiles/README.md: the chunk's DMA pieces issued later
+// in the body; three V stages with a run-time index; every other / no barrier in the loop - a timing ablation with
+// wrong results - changed the time by -2 % / 0 %: the loop does not wait for its barriers.)
 __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __restrict__ x, int ldx,
                                                                const float* __restrict__ ab,
                                                                const float* __restrict__ U,
@@ -343,7 +341,7 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(1024))) float raw_0[WF_RAW], raw_1[WF_RAW], raw_2[WF_RAW], raw_3[WF_RAW];
   __shared__ __attribute__((aligned(1024))) float us_0[WF_UV], us_1[WF_UV], us_2[WF_UV], us_3[WF_UV];
-  __shared__ __attribute__((aligned(1024))) float vs[(V2 ? 2 : 3) * WF_UV];
+  __shared__ __attribute__((aligned(1024))) float vs[2 * WF_UV];
   __shared__ __attribute__((aligned(16))) float abl[2 * WG_MAXC];
   auto rawp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return raw_0; else if constexpr (decltype(S)::value == 1) return raw_1; else if constexpr (decltype(S)::value == 2) return raw_2; else return raw_3; };
   auto usp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return us_0; else if constexpr (decltype(S)::value == 1) return us_1; else if constexpr (decltype(S)::value == 2) return us_2; else return us_3; };
@@ -473,36 +471,26 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
     // taken from the fp32 MFMA pipe)
     typedef __attribute__((address_space(3))) float lds_float;
     lds_float* vaddr[2][4];
-    if constexpr (V2) {
 #pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        vaddr[st][0] = (lds_float*)(vs + st * WF_UV + voffA);
-        vaddr[st][1] = (lds_float*)(vs + st * WF_UV + voffA + VJ[2]);
-        vaddr[st][2] = (lds_float*)(vs + st * WF_UV + voffB);
-        vaddr[st][3] = (lds_float*)(vs + st * WF_UV + voffB + VJ[2]);
+    for (int st = 0; st < 2; ++st) {
+      vaddr[st][0] = (lds_float*)(vs + st * WF_UV + voffA);
+      vaddr[st][1] = (lds_float*)(vs + st * WF_UV + voffA + VJ[2]);
+      vaddr[st][2] = (lds_float*)(vs + st * WF_UV + voffB);
+      vaddr[st][3] = (lds_float*)(vs + st * WF_UV + voffB + VJ[2]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(vaddr[st][q]));
-      }
+      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(vaddr[st][q]));
     }
-    auto write_v = [&](float* vst, const float (&e)[3][4], int vstage) {
+    auto write_v = [&](const float (&e)[3][4], int vstage) {
       float ua[4], ub[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         ua[s] = e[0][s] - e[2][s];
         ub[s] = hb ? e[1][s] - e[0][s] : e[1][s] + e[2][s];
       }
-      lds_float *va0, *va1, *vb0, *vb1;
-      if constexpr (V2) {
-        va0 = vstage ? vaddr[1][0] : vaddr[0][0];
-        va1 = vstage ? vaddr[1][1] : vaddr[0][1];
-        vb0 = vstage ? vaddr[1][2] : vaddr[0][2];
-        vb1 = vstage ? vaddr[1][3] : vaddr[0][3];
-      } else {
-        va0 = (lds_float*)(vst + voffA);
-        va1 = va0 + VJ[2];
-        vb0 = (lds_float*)(vst + voffB);
-        vb1 = vb0 + VJ[2];
-      }
+      lds_float* va0 = vstage ? vaddr[1][0] : vaddr[0][0];
+      lds_float* va1 = vstage ? vaddr[1][1] : vaddr[0][1];
+      lds_float* vb0 = vstage ? vaddr[1][2] : vaddr[0][2];
+      lds_float* vb1 = vstage ? vaddr[1][3] : vaddr[0][3];
       va0[0] = ua[0] - ua[2];
       va0[2] = ua[1] + ua[2];
       va1[0] = ua[2] - ua[1];
@@ -512,7 +500,7 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
       vb1[0] = ub[2] - ub[1];
       vb1[2] = ub[1] - ub[3];
     };
-    auto mfmas = [&](auto S, const float* vst, auto between) {
+    auto mfmas = [&](auto S, const float* vst) {
       const float* va = vst + aoff;
       const float* ub = usp(S) + boff;
       float4 a4[4], b4[4];
@@ -526,66 +514,38 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
         acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[i].x, acc[2 * i], 0, 0, 0);
         acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[i].z, acc[2 * i + 1], 0, 0, 0);
       }
-      between();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[i].y, acc[2 * i], 0, 0, 0);
         acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[i].w, acc[2 * i + 1], 0, 0, 0);
       }
     };
-    // iteration c (stages of chunk j: raw j % 4, U j % 4, V j % 3): raw(c+2) and U(c) have landed (issued two
+    // iteration c (stages of chunk j: raw j % 4, U j % 4, V j % 2): raw(c+2) and U(c) have landed (issued two
     // iterations ago), barrier, issue raw(c+4) and U(c+2), activate raw(c+2), MFMAs of chunk c, transform of
     // raw(c+1) (activated one iteration ago) into V(c+1)
-    int vcur = 0;   // V stage of chunk c (run-time index form)
-    // where this half of the workgroup issues the chunk's DMA pieces: 0 behind the barrier, 1 between the two MFMA
-    // groups, 2 behind the MFMAs (the target stages were consumed before the barrier in every case)
-    constexpr int DMA_AT = (VAR == 0 || VAR >= 4) ? 0 : VAR == 1 ? (hb ? 2 : 0) : VAR == 2 ? 1 : (hb ? 2 : 1);
     auto body = [&](int c, auto Sc, auto Sc1, auto Sc2, auto LIVE) {
       asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-      // VAR 4 / 5: timing ablations with WRONG results (races): every other barrier / no barrier in the loop
-      if constexpr (VAR == 4) {
-        if constexpr ((decltype(Sc)::value & 1) == 0) __builtin_amdgcn_s_barrier();
-      } else if constexpr (VAR != 5) {
-        __builtin_amdgcn_s_barrier();
-      }
-      auto dma = [&]() {
-        issue_raw(c + 4, Sc, LIVE);
-        issue_u(c + 2, Sc2, LIVE);
-      };
-      if constexpr (DMA_AT == 0) dma();
-      if constexpr (V2) vcur = decltype(Sc)::value & 1;   // chunk c sits in raw / U stage c % 4: its parity is c's
-      const int vnext = V2 ? (vcur ^ 1) : (vcur == 2 ? 0 : vcur + 1);
+      __builtin_amdgcn_s_barrier();
+      issue_raw(c + 4, Sc, LIVE);
+      issue_u(c + 2, Sc2, LIVE);
+      constexpr int vcur = decltype(Sc)::value & 1;   // chunk c sits in raw / U stage c % 4: its parity is c's
       float e[3][4];
       load_raw(Sc1, e);
-      mfmas(Sc, vs + vcur * WF_UV, [&]() {
-        if constexpr (DMA_AT == 1) {
-          __builtin_amdgcn_sched_barrier(0);
-          dma();
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      });
-      if constexpr (DMA_AT == 2) {
-        __builtin_amdgcn_sched_barrier(0);
-        dma();
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      mfmas(Sc, vs + vcur * WF_UV);
       activate(c + 2, Sc2, LIVE, MASK);
-      write_v(vs + vnext * WF_UV, e, vnext);
-      vcur = vnext;
+      write_v(e, vcur ^ 1);
     };
     {
       float e[3][4];
       load_raw(S0{}, e);
-      write_v(vs, e, 0);
+      write_v(e, 0);
     }
     int c = 0;
-    if constexpr (PEEL) {
-      for (; c + 8 <= nchunks; c += 4) {   // steady state: every chunk these four bodies prefetch exists
-        body(c, S0{}, S1{}, S2{}, LiveT{});
-        body(c + 1, S1{}, S2{}, S3{}, LiveT{});
-        body(c + 2, S2{}, S3{}, S0{}, LiveT{});
-        body(c + 3, S3{}, S0{}, S1{}, LiveT{});
-      }
+    for (; c + 8 <= nchunks; c += 4) {   // steady state: every chunk these four bodies prefetch exists
+      body(c, S0{}, S1{}, S2{}, LiveT{});
+      body(c + 1, S1{}, S2{}, S3{}, LiveT{});
+      body(c + 2, S2{}, S3{}, S0{}, LiveT{});
+      body(c + 3, S3{}, S0{}, S1{}, LiveT{});
     }
     for (; c < nchunks; c += 4) {
       body(c, S0{}, S1{}, S2{}, LiveF{});
@@ -609,7 +569,7 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   // interior patches (the whole 18 x 18 halo inside the image) run the loop without the padding mask
-  const bool border = !PEEL || y0 == 0 || x0 == 0 || y0 + 16 >= H || x0 + 16 >= W;
+  const bool border = y0 == 0 || x0 == 0 || y0 + 16 >= H || x0 + 16 >= W;
   if (ph == 0) {
     if (border) run(std::integral_constant<int, 0>{}, LiveT{});
     else run(std::integral_constant<int, 0>{}, LiveF{});
@@ -623,7 +583,7 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
   __builtin_amdgcn_s_barrier();
 
   const int pair = wm * 2 + wn;
-  float4* ex = (float4*)(pair < (V2 ? 2 : 3) ? vs + pair * WF_UV : (V2 && pair == 2) ? us_1 : us_0);
+  float4* ex = (float4*)(pair < 2 ? vs + pair * WF_UV : pair == 2 ? us_1 : us_0);
   float4 part[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -697,6 +657,408 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same kernel as SIXTEEN waves (four per SIMD, 64 accumulator registers each, <= 128 VGPRs).  With two waves
+// per SIMD the matrix pipe idles whenever both have a non-MFMA instruction at the head of their (in-order)
+// streams - a DMA piece being issued, an LDS instruction waiting for its queue, an operand not back yet; removing
+// the loop's barriers altogether changed nothing (KD_FWINO_VAR 4 / 5), so it is not the synchronisation.  Four
+// waves make that coincidence rare.  Wave (pr, wm, wn) owns transformed ROW pr (positions 4 pr .. 4 pr + 3) of
+// 32 tiles x 32 channels; thread = (tile, channel, row pr) of the input transform (8 patch reads, 8 VALU, 4 V
+// stores); waves 0-7 (rows 0, 1) issue the raw-patch DMA, every wave one piece of U.  The output transform
+// combines the four rows of a (wm, wn) tile through LDS: each wave finishes 4 of the 16 accumulator elements.
+//
+// PERSISTENT: the grid is one workgroup per CU and a workgroup walks the items (patch x 64-channel slab) id =
+// blockIdx.x + k gridDim.x (gridDim.x % 8 == 0 keeps a workgroup's items on its XCD's share of the patch order).
+// Behind the main loop's last barrier the raw-patch stages are free: the next item's first four raw chunks are
+// fetched while this item's output transform, exchange and stores run; its U chunks 0 / 1 follow once the exchange
+// (which lives in the U and V stages) has been read.  What a one-item workgroup pays per item - dispatch, descriptor
+// set-up, the HBM latency of the first patch chunks - was 6.5 chunk times per item (17 % of a Cin = 128 layer).
+__global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __restrict__ x, int ldx,
+                                                               const float* __restrict__ ab,
+                                                               const float* __restrict__ U,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ res, int ldres,
+                                                               float* __restrict__ y, int B, int H, int W, int C,
+                                                               int N, double* __restrict__ opart, int oG) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(1024))) float raw_0[WF_RAW], raw_1[WF_RAW], raw_2[WF_RAW], raw_3[WF_RAW];
+  __shared__ __attribute__((aligned(1024))) float us_0[WF_UV], us_1[WF_UV], us_2[WF_UV], us_3[WF_UV];
+  __shared__ __attribute__((aligned(1024))) float vs[2 * WF_UV];
+  __shared__ __attribute__((aligned(16))) float abl[2 * WG_MAXC];
+  auto rawp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return raw_0; else if constexpr (decltype(S)::value == 1) return raw_1; else if constexpr (decltype(S)::value == 2) return raw_2; else return raw_3; };
+  auto usp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return us_0; else if constexpr (decltype(S)::value == 1) return us_1; else if constexpr (decltype(S)::value == 2) return us_2; else return us_3; };
+
+  // tq / lq: the thread and lq index as the loader, the activation and the transform see them.  They are re-made
+  // opaque (empty asm) at the top of every item: whatever hipcc derives from them (slot coordinates, LDS addresses)
+  // is then re-derived per item instead of being carried - as a loop invariant of the ITEM loop - through the
+  // epilogue, where the registers are needed (it spilled 30 of them)
+  int tq = threadIdx.x, lq = tq & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tq >> 6);
+  const int pr = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int pw = W / 16, ph_ = H / 16;
+  const int nh = N / 64;
+  const int npatch = B * pw * ph_;
+  const int nitems = npatch * nh;
+  const int nchunks = C / WF_K;
+  const __amdgpu_buffer_rsrc_t rsU =
+      __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, (int)((int64_t)16 * N * C * 4), 0x00020000);
+
+  // ---- per-item state (the item being LOADED: during an item's epilogue this is already the next item)
+  int b, prem, y0, x0, nhalf;
+  uint32_t voffX;
+  bool aok[2];
+  __amdgpu_buffer_rsrc_t rsX;
+  auto image_of = [&](int id) {
+    const int bpatch = (npatch & 7) == 0 ? (id / (8 * nh)) * 8 + (id & 7) : id / nh;
+    return bpatch / (pw * ph_);
+  };
+  auto slot_pixel = [&](int slot, int& iy, int& ix) {
+    int py = slot / 18, pq = slot - py * 18;
+    int px = pq < 9 ? 2 * pq : 2 * (pq - 9) + 1;
+    iy = y0 - 1 + py;
+    ix = x0 - 1 + px;
+    return slot < 324 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+  };
+  auto setup = [&](int id) {
+    int bpatch;
+    if ((npatch & 7) == 0) {   // the N/64 items of one patch back to back on ONE XCD
+      bpatch = (id / (8 * nh)) * 8 + (id & 7);
+      nhalf = (id >> 3) % nh;
+    } else {
+      bpatch = id / nh;
+      nhalf = id % nh;
+    }
+    b = bpatch / (pw * ph_);
+    prem = bpatch - b * pw * ph_;
+    y0 = (prem / pw) * 16;
+    x0 = (prem % pw) * 16;
+    rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)b * H * W * ldx), 0, (int)((int64_t)H * W * ldx * 4),
+                                            0x00020000);
+    // (the empty asm makes the thread index opaque here: otherwise hipcc hoists the slot -> (row, column) divisions
+    // of all three slots out of the item loop and carries them through the main loop in registers it does not have)
+    int t_ = tq;
+    asm volatile("" : "+v"(t_));
+    int iy, ix;
+    const bool ok = slot_pixel(t_, iy, ix);
+    voffX = ok ? (uint32_t)(((iy * W + ix) * ldx) * 4) : OOB_OFF;
+    // activation: values tq and tq + 1024 of the 324 x 4 patch floats; channel tq & 3, slots (tq >> 2) + 256 i
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aok[i] = slot_pixel((t_ >> 2) + 256 * i, iy, ix);
+  };
+  auto issue_raw = [&](int chunk, auto S, auto LIVE) {   // waves 0-7 only: 512 pixel slots
+    __attribute__((address_space(3))) float* rb = (__attribute__((address_space(3))) float*)(rawp(S) + wave * 256);
+    const uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t)(chunk * WF_K * 4));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, rb, 16, (decltype(LIVE)::value || chunk < nchunks) ? voffX : OOB_OFF, sx,
+                                             0, 0);
+  };
+  auto issue_u_at = [&](int chunk, auto S, auto LIVE, uint32_t toff) {   // every wave: 1 KB of the 16 KB chunk
+    __attribute__((address_space(3))) float* ub = (__attribute__((address_space(3))) float*)(usp(S) + wave * 256);
+    const uint32_t su = __builtin_amdgcn_readfirstlane((uint32_t)(((nhalf * nchunks + chunk) * WF_UV) * 4));
+    const bool live = decltype(LIVE)::value || chunk < nchunks;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, ub, 16, live ? toff : OOB_OFF, su, 0, 0);
+  };
+  auto issue_u = [&](int chunk, auto S, auto LIVE) { issue_u_at(chunk, S, LIVE, (uint32_t)(tq * 16)); };
+  auto activate = [&](int chunk, auto S, auto LIVE, auto MASK) {
+    const int cc = (decltype(LIVE)::value ? chunk : min(chunk, nchunks - 1)) * WF_K + (tq & 3);
+    const float2 a2 = *(const float2*)(abl + 2 * cc);
+    float* ap = rawp(S) + tq;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i < 1 || tq < 324 * 4 - 1024) {
+        const float u = ap[i * 1024] * a2.x + a2.y;
+        const float v = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
+        ap[i * 1024] = (!decltype(MASK)::value || aok[i]) ? v : 0.f;
+      }
+    }
+  };
+  int tc, ttx, tty, tt;      // transform thread -> (channel, tile column, tile row, tile): set per item (derive)
+
+  f32x16 acc[4];
+  int aoff, boff;            // operand read offsets of this lane inside a V / U chunk: set per item (derive)
+  auto derive = [&]() {
+    tq = threadIdx.x;
+    asm volatile("" : "+v"(tq));
+    lq = tq & 63;
+    const int t8 = tq & 255;
+    tc = t8 & 3;
+    ttx = (t8 >> 2) & 7;
+    tty = t8 >> 5;
+    tt = tty * 8 + ttx;
+    const int frow = lq & 31, khalf = lq >> 5;
+    aoff = (int)wf_uv_index(0, pr * 4, wm * 32 + frow, khalf * 2);
+    boff = (int)wf_uv_index(0, pr * 4, wn * 32 + frow, khalf * 2);
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  using S3 = std::integral_constant<int, 3>;
+  using LiveT = std::integral_constant<bool, true>;
+  using LiveF = std::integral_constant<bool, false>;
+  using R0 = std::integral_constant<int, 0>;
+  using R1 = std::integral_constant<int, 1>;
+  using R2 = std::integral_constant<int, 2>;
+  using R3 = std::integral_constant<int, 3>;
+  auto run = [&](auto RR, auto MASK) {
+    constexpr int R = decltype(RR)::value;           // transformed row of this wave's transform threads (= pr)
+    constexpr bool LOADER = R < 2;                   // waves 0-7 carry the raw-patch DMA
+    // row R of B^T d: d0 - d2 | d1 + d2 | d2 - d1 | d1 - d3
+    constexpr int IA = R == 0 ? 0 : R == 1 ? 1 : R == 2 ? 2 : 1;
+    constexpr int IB = R == 0 ? 2 : R == 1 ? 2 : R == 2 ? 1 : 3;
+    const int roff = (2 * tty * 18 + ttx) * 4 + tc;
+    const int voff = (int)wf_uv_index(0, R * 4, tt, tc);
+    constexpr int RS[4] = {0, 9, 1, 10};
+    auto load_raw = [&](auto S, float (&e)[2][4]) {
+      const float* rp = rawp(S) + roff;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        e[0][s] = rp[(IA * 18 + RS[s]) * 4];
+        e[1][s] = rp[(IB * 18 + RS[s]) * 4];
+      }
+    };
+    auto write_v = [&](int vstage, const float (&e)[2][4]) {
+      float u[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) u[s] = R == 1 ? e[0][s] + e[1][s] : e[0][s] - e[1][s];
+      float* v = vs + vstage * WF_UV + voff;
+      v[0] = u[0] - u[2];
+      v[2] = u[1] + u[2];
+      v[2 * 64 * 4] = u[2] - u[1];
+      v[2 * 64 * 4 + 2] = u[1] - u[3];
+    };
+    auto mfmas = [&](auto S, int vstage) {
+      const float* va = vs + vstage * WF_UV + aoff;
+      const float* ub = usp(S) + boff;
+      float4 a4[2], b4[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a4[i] = *(const float4*)(va + i * 2 * 64 * 4);
+        b4[i] = *(const float4*)(ub + i * 2 * 64 * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[i].x, acc[2 * i], 0, 0, 0);
+        acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[i].z, acc[2 * i + 1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[i].y, acc[2 * i], 0, 0, 0);
+        acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[i].w, acc[2 * i + 1], 0, 0, 0);
+      }
+    };
+    // iteration c (stages of chunk j: raw j % 4, U j % 4, V j % 2): raw(c+2) and U(c) have landed (issued two
+    // iterations ago: a loader wave issues 2 pieces per iteration, the others 1), barrier, issue raw(c+4) and
+    // U(c+2), MFMAs of chunk c, activate raw(c+2), transform raw(c+1) (activated one iteration ago) into V(c+1)
+    auto body = [&](int c, auto Sc, auto Sc1, auto Sc2, auto LIVE) {
+      if constexpr (LOADER) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if constexpr (LOADER) issue_raw(c + 4, Sc, LIVE);
+      issue_u(c + 2, Sc2, LIVE);
+      constexpr int vcur = decltype(Sc)::value & 1;
+      float e[2][4];
+      load_raw(Sc1, e);
+      mfmas(Sc, vcur);
+      activate(c + 2, Sc2, LIVE, MASK);
+      write_v(vcur ^ 1, e);
+    };
+    {
+      float e[2][4];
+      load_raw(S0{}, e);
+      write_v(0, e);
+    }
+    int c = 0;
+    for (; c + 8 <= nchunks; c += 4) {   // steady state: every chunk these four bodies prefetch exists
+      body(c, S0{}, S1{}, S2{}, LiveT{});
+      body(c + 1, S1{}, S2{}, S3{}, LiveT{});
+      body(c + 2, S2{}, S3{}, S0{}, LiveT{});
+      body(c + 3, S3{}, S0{}, S1{}, LiveT{});
+    }
+    for (; c < nchunks; c += 4) {
+      body(c, S0{}, S1{}, S2{}, LiveF{});
+      body(c + 1, S1{}, S2{}, S3{}, LiveF{});
+      body(c + 2, S2{}, S3{}, S0{}, LiveF{});
+      body(c + 3, S3{}, S0{}, S1{}, LiveF{});
+    }
+  };
+
+  // exchange messages of the output transform: (group g = wm * 2 + wn, source row sr, destination index dd among the
+  // other three rows) -> 2 KB (two float4 per lq); 48 messages fill the V stages (16) and the four U stages (8 each)
+  const int g = wm * 2 + wn;
+  auto exmsg = [&](int sr, int dd) -> float4* {
+    const int m = (g * 4 + sr) * 3 + dd;
+    float* base = m < 16 ? vs + m * 512
+                         : m < 24 ? us_0 + (m - 16) * 512
+                                  : m < 32 ? us_1 + (m - 24) * 512 : m < 40 ? us_2 + (m - 32) * 512 : us_3 + (m - 40) * 512;
+    return (float4*)base;
+  };
+
+  int item = blockIdx.x;
+  derive();
+  setup(item);
+  // first item: the classic prologue
+  if (wave < 8) {
+    issue_raw(0, S0{}, LiveF{});
+    issue_u(0, S0{}, LiveF{});
+    issue_raw(1, S1{}, LiveF{});
+    issue_raw(2, S2{}, LiveF{});
+    issue_raw(3, S3{}, LiveF{});
+    issue_u(1, S1{}, LiveF{});
+  } else {
+    issue_u(0, S0{}, LiveF{});
+    issue_u(1, S1{}, LiveF{});
+  }
+  float2 abv = make_float2(0.f, 0.f);
+  if (tq < C) abv = ((const float2*)ab)[(int64_t)b * C + tq];
+  bool first = true;
+  while (true) {
+    // ---- top of an item: its first raw chunks (and U chunks 0 / 1) are in flight or have landed
+    if (!first) derive();
+    if (tq < C) *(float2*)(abl + 2 * tq) = abv;
+    // first item: everything of the prologue.  Later items: at least the 16 output stores of the previous item are
+    // younger than the U pieces issued behind its exchange - all but 16 operations done means raw 0-3, U 0 and U 1 landed
+    if (first) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int next = item + (int)gridDim.x;
+    const bool has_next = next < nitems;
+    activate(0, S0{}, LiveF{}, LiveT{});
+    activate(1, S1{}, LiveF{}, LiveT{});
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool border = y0 == 0 || x0 == 0 || y0 + 16 >= H || x0 + 16 >= W;
+    if (pr == 0) {
+      if (border) run(R0{}, LiveT{}); else run(R0{}, LiveF{});
+    } else if (pr == 1) {
+      if (border) run(R1{}, LiveT{}); else run(R1{}, LiveF{});
+    } else if (pr == 2) {
+      if (border) run(R2{}, LiveT{}); else run(R2{}, LiveF{});
+    } else {
+      if (border) run(R3{}, LiveT{}); else run(R3{}, LiveF{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (out-of-range, zero) DMAs still write LDS
+    __builtin_amdgcn_s_barrier();
+
+    // ---- this item's coordinates for the epilogue; the loader state moves on to the next item, whose first four
+    // raw chunks start now (the raw stages take no part in the exchange)
+    const int eb = b, eprem = prem, ey0 = y0, ex0 = x0, en0 = nhalf * 64;
+    int l_ = threadIdx.x & 63;   // opaque per item: the epilogue's addresses must not be hoisted over the main loop (registers)
+    asm volatile("" : "+v"(l_));
+    if (has_next && wave * 64 + l_ < C) abv = ((const float2*)ab)[(int64_t)image_of(next) * C + wave * 64 + l_];
+    // The 16 outputs of a lq: tile row wm * 4 + pr, tile columns i + 4 (lq >> 5), channel n: pixel pix0 + 2 i (+ 1,
+    // + W, + W + 1)
+    const int n = en0 + wn * 32 + (l_ & 31);
+    const int64_t pix0 = ((int64_t)eb * H + ey0 + 2 * (wm * 4 + pr)) * W + ex0 + 8 * (l_ >> 5);
+    const float bv = bias ? bias[n] : 0.f;
+    if (has_next) {
+      setup(next);
+      if (wave < 8) {
+        issue_raw(0, S0{}, LiveF{});
+        issue_raw(1, S1{}, LiveF{});
+        issue_raw(2, S2{}, LiveF{});
+        issue_raw(3, S3{}, LiveF{});
+      }
+    }
+
+    // output transform Y = A^T m A.  Columns first, inside the wave: (q0, q1) = (a0 + a1 + a2, a1 - a2 - a3) of its
+    // row.  Rows across the four waves of the (wm, wn) tile: Yrow0 = Q0 + Q1 + Q2, Yrow1 = Q1 - Q2 - Q3.  Wave pr
+    // finishes the accumulator elements 4 pr .. 4 pr + 3 and hands the (q0, q1) of the other twelve to their owners
+    float2 q[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      q[r] = make_float2(acc[0][r] + acc[1][r] + acc[2][r], acc[1][r] - acc[2][r] - acc[3][r]);
+    double gs1 = 0.0, gs2 = 0.0;
+    auto finish = [&](auto PRR) {   // the wave's row as a compile-time constant: q[] stays in registers
+      constexpr int PR = decltype(PRR)::value;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        if (d == PR) continue;
+        float4* dst = exmsg(PR, PR < d ? d - 1 : d);   // index of d among the rows other than PR
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          dst[h * 64 + l_] = make_float4(q[4 * d + 2 * h].x, q[4 * d + 2 * h].y, q[4 * d + 2 * h + 1].x,
+                                           q[4 * d + 2 * h + 1].y);
+      }
+      __syncthreads();
+      float2 Q[4][4];   // [source row][element i]
+#pragma unroll
+      for (int sr = 0; sr < 4; ++sr) {
+        if (sr == PR) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) Q[sr][i] = q[4 * PR + i];
+        } else {
+          const float4* src = exmsg(sr, sr < PR ? PR - 1 : PR);   // index of PR among the rows other than sr
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float4 v = src[h * 64 + l_];
+            Q[sr][2 * h] = make_float2(v.x, v.y);
+            Q[sr][2 * h + 1] = make_float2(v.z, v.w);
+          }
+        }
+      }
+      if (has_next) {   // the exchange has been read by everybody: U chunks 0 / 1 of the next item may land on it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_u_at(0, S0{}, LiveF{}, (uint32_t)((wave * 64 + l_) * 16));   // (not the loop's tq * 16: see l_)
+        issue_u_at(1, S1{}, LiveF{}, (uint32_t)((wave * 64 + l_) * 16));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t pix = pix0 + 2 * i;
+        float o00 = Q[0][i].x + Q[1][i].x + Q[2][i].x + bv, o01 = Q[0][i].y + Q[1][i].y + Q[2][i].y + bv,
+              o10 = Q[1][i].x - Q[2][i].x - Q[3][i].x + bv, o11 = Q[1][i].y - Q[2][i].y - Q[3][i].y + bv;
+        if (res) {
+          o00 += res[pix * ldres + n];
+          o01 += res[(pix + 1) * ldres + n];
+          o10 += res[(pix + W) * ldres + n];
+          o11 += res[(pix + W + 1) * ldres + n];
+        }
+        y[pix * N + n] = o00;
+        y[(pix + 1) * N + n] = o01;
+        y[(pix + W) * N + n] = o10;
+        y[(pix + W + 1) * N + n] = o11;
+        if (opart) {
+          gs1 += ((double)o00 + (double)o01) + ((double)o10 + (double)o11);
+          gs2 += ((double)o00 * o00 + (double)o01 * o01) + ((double)o10 * o10 + (double)o11 * o11);
+        }
+      }
+    };
+    if (pr == 0) finish(R0{});
+    else if (pr == 1) finish(R1{});
+    else if (pr == 2) finish(R2{});
+    else finish(R3{});
+    if (opart) {   // 8 entries per patch and 16-channel segment: (wm, pr)
+#pragma unroll
+      for (int off = 1; off <= 8; off <<= 1) {
+        gs1 += __shfl_xor(gs1, off, 64);
+        gs2 += __shfl_xor(gs2, off, 64);
+      }
+      gs1 += __shfl_xor(gs1, 32, 64);
+      gs2 += __shfl_xor(gs2, 32, 64);
+      if ((l_ & 47) == 0) {   // l_s 0 and 16: channel segments 0 and 1 of this wave
+        int Cg = N / oG;
+        asm volatile("" : "+s"(Cg));   // (opaque: its reciprocal is not to be kept in a register across the items)
+        const int cabs = en0 + wn * 32 + (l_ & 16);
+        const int gg = cabs / Cg, cseg = (cabs - gg * Cg) >> 4;
+        const int npi = pw * ph_;
+        const int64_t chunks = (int64_t)(Cg >> 4) * npi * 8;
+        const int64_t entry = ((int64_t)cseg * npi + eprem) * 8 + (wm * 4 + pr);
+        double* op = opart + (((int64_t)eb * oG + gg) * chunks + entry) * 2;
+        op[0] = gs1;
+        op[1] = gs2;
+      }
+    }
+    if (!has_next) break;
+    item = next;
+    first = false;
+  }
+#endif
+}
+
 bool wino_fused_ok(int B, int H, int W, int C, int N) {
   return B > 0 && H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0 && C >= WF_K && C % WF_K == 0 && N >= 64 &&
          N % 64 == 0 && (int64_t)H * W * C * 4 < 0x7fffffff && (int64_t)16 * N * C * 4 < 0x7fffffff &&
@@ -753,8 +1115,16 @@ int launch_gn_fold(const float* stats, const float* gamma, const float* beta, co
   return 0;
 }
 
+// Which form launch_wino_fused_gn runs.  Default 16: sixteen waves, persistent workgroups.  KD_FWINO_VAR (read
+// once, for A/B measurements): 17 = sixteen waves, one item per workgroup; 8 = the eight-wave kernel.
+static int fwino_var() {
+  static const int var = getenv("KD_FWINO_VAR") ? atoi(getenv("KD_FWINO_VAR")) : 16;
+  return var;
+}
+static bool fwino_16() { return fwino_var() != 8; }
+
 size_t wino_fused_out_stats_chunks(int H, int W, int N, int G) {
-  return (size_t)(N / G / 16) * (H / 16) * (W / 16) * 4;
+  return (size_t)(N / G / 16) * (H / 16) * (W / 16) * (fwino_16() ? 8 : 4);
 }
 
 int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* U, const float* bias, const float* res,
@@ -767,21 +1137,24 @@ int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* 
   KD_REQUIRE(!out_partial || (out_groups > 0 && N % out_groups == 0 && (N / out_groups) % 16 == 0),
              "output statistics need groups of a multiple of 16 channels");
   const unsigned grid = (unsigned)((int64_t)B * (H / 16) * (W / 16) * (N / 64));
-  // default: two static V stages + peeled steady-state loop (round 2: -1.0 ms per step against the round-1 loop);
-  // KD_FWINO_VAR (read once) selects the other forms measured in profiles/README.md: 100 = round-1 loop,
-  // 1 / 2 = DMA pieces issued later in the chunk, 10 = static V stages only
-  static const int var = getenv("KD_FWINO_VAR") ? atoi(getenv("KD_FWINO_VAR")) : 20;
-#define KD_WFGN(V, T2, PL)                                                                                               \
-  hipLaunchKernelGGL((wino_fused_gn_kernel<V, T2, PL>), dim3(grid), dim3(512), 0, s, x, ldx, ab, U, bias, res, ldres, y, B, H, \
-                     W, C, N, out_partial, out_groups)
-  if (var == 1) KD_WFGN(1, false, false);
-  else if (var == 2) KD_WFGN(2, false, false);
-  else if (var == 4) KD_WFGN(4, true, true);
-  else if (var == 5) KD_WFGN(5, true, true);
-  else if (var == 10) KD_WFGN(0, true, false);
-  else if (var == 100) KD_WFGN(0, false, false);
-  else KD_WFGN(0, true, true);
-#undef KD_WFGN
+  const int var = fwino_var();
+  if (fwino_16()) {
+    static int cus = 0;
+    if (!cus) {
+      hipDeviceProp_t prop;
+      int dev = 0;
+      KD_HIP_CHECK(hipGetDevice(&dev));
+      KD_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+      cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount / 8 * 8 : 256;
+    }
+    const unsigned pgrid = var == 17 || grid < (unsigned)cus ? grid : (unsigned)cus;
+    hipLaunchKernelGGL(wino_fused_gn16_kernel, dim3(pgrid), dim3(1024), 0, s, x, ldx, ab, U, bias, res, ldres, y, B, H, W, C,
+                       N, out_partial, out_groups);
+    KD_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  hipLaunchKernelGGL(wino_fused_gn_kernel, dim3(grid), dim3(512), 0, s, x, ldx, ab, U, bias, res, ldres, y, B, H, W, C, N,
+                     out_partial, out_groups);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
