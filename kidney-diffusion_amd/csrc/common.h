@@ -122,6 +122,7 @@ int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* 
                          int ldres, float* y, int B, int H, int W, int C, int N, double* out_partial, int out_groups,
                          hipStream_t s);
 size_t wino_fused_out_stats_chunks(int H, int W, int N, int G);
+int wino_fused_gn_max_cin();   // largest Cin launch_wino_fused_gn takes (its affine table lives in LDS)
 // stats[b][g] = (mean, rstd) from `chunks` (sum, sum of squares) partials per (b, g), summed in index order
 int launch_gn_finalize(const double* partial, float* stats, int chunks, int B, int G, double count, float eps,
                        hipStream_t s);

@@ -752,10 +752,12 @@ struct Builder {
   bool wino_ok(const T& x, int cout) const {
     if (cfg.conv_algo == 1) return false;
     const int min_cin = cfg.conv_algo >= 32 ? cfg.conv_algo : 256;
-    // the fused kernel (fwino_ok) takes the layers up to Cin = 512 whose maps it can tile: measured on the
-    // 64->256 UNet, ms/step with the hand-over at Cin <= 0 / 256 / 512 / 1024 / all: 48.1 / 44.8 / 44.5 / 45.1 /
-    // 45.3 (KD_FWINO_MAX_CIN moves it for experiments, read per plan)
-    const int fw_max = getenv("KD_FWINO_MAX_CIN") ? atoi(getenv("KD_FWINO_MAX_CIN")) : 512;
+    // the fused kernel (fwino_ok) takes every layer whose map it can tile and whose launch fills the chip, up to the
+    // Cin its affine table holds.  Measured on the 64->256 UNet, ms/step with the hand-over at Cin <= 0 / 256 / 512 /
+    // 1024 / all: 48.1 / 44.8 / 44.5 / 45.1 / 45.3 with the eight-wave kernel of round 1 (its Cin = 1024 launches lost
+    // to the batched GEMMs), 37.59 / 37.36 / 37.40 at <= 512 / 1024 / 2048 with the persistent sixteen-wave kernel
+    // (300 us against 265 + 40 + 21 for GEMM + transforms).  KD_FWINO_MAX_CIN moves it for experiments, read per plan
+    const int fw_max = getenv("KD_FWINO_MAX_CIN") ? atoi(getenv("KD_FWINO_MAX_CIN")) : 2048;
     if (cfg.conv_algo < 32 && x.C <= fw_max && fwino_ok(x, cout)) return false;
     if ((x.H & 1) || (x.W & 1) || x.C < min_cin || x.C % 32 || cout <= 32 || cout % 4) return false;
     const int64_t Mt = (int64_t)x.B * (x.H / 2) * (x.W / 2);
@@ -866,7 +868,7 @@ struct Builder {
   // gn_apply_silu pass (A/B, read per plan).
   bool fwino_gn_ok(const T& x, int cout) const {
     const bool on = !getenv("KD_FWINO_GN") || atoi(getenv("KD_FWINO_GN")) != 0;
-    return on && x.C <= 512 && x.C % cfg.resnet_groups == 0 && fwino_ok(x, cout) &&
+    return on && x.C <= wino_fused_gn_max_cin() && x.C % cfg.resnet_groups == 0 && fwino_ok(x, cout) &&
            (int64_t)x.H * x.W * x.LD() * 4 < 0x7fffffff;
   }
   T fwino_gn_conv(const T& x, const std::string& gn_prefix, int ss_col, const std::string& conv_prefix, int Cout,

@@ -324,7 +324,8 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restr
 // 21 VALU + 6 LDS instructions per thread and chunk add 4 % to the kernel, the apply pass they replace was
 // 14 % of conv + apply.  Zero padding: the pixel's slot is known to be outside the image -> 0 after the
 // activation as well.
-constexpr int WG_MAXC = 512;   // channels of the affine table kept in LDS
+constexpr int WG_MAXC = 512;   // channels of the affine table kept in LDS (eight-wave kernel)
+constexpr int WG16_MAXC = 2048;   // ... sixteen-wave kernel
 
 // Two V stages with compile-time indices (the single barrier per chunk already orders the last reads of V(c) before
 // the first writes of V(c + 2)); the steady-state loop iterations run without the DMA liveness selects, interior
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __re
   __shared__ __attribute__((aligned(1024))) float raw_0[WF_RAW], raw_1[WF_RAW], raw_2[WF_RAW], raw_3[WF_RAW];
   __shared__ __attribute__((aligned(1024))) float us_0[WF_UV], us_1[WF_UV], us_2[WF_UV], us_3[WF_UV];
   __shared__ __attribute__((aligned(1024))) float vs[2 * WF_UV];
-  __shared__ __attribute__((aligned(16))) float abl[2 * WG_MAXC];
+  __shared__ __attribute__((aligned(16))) float abl[2 * WG16_MAXC];
   auto rawp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return raw_0; else if constexpr (decltype(S)::value == 1) return raw_1; else if constexpr (decltype(S)::value == 2) return raw_2; else return raw_3; };
   auto usp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return us_0; else if constexpr (decltype(S)::value == 1) return us_1; else if constexpr (decltype(S)::value == 2) return us_2; else return us_3; };
 
@@ -915,6 +916,8 @@ __global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __re
     // ---- top of an item: its first raw chunks (and U chunks 0 / 1) are in flight or have landed
     if (!first) derive();
     if (tq < C) *(float2*)(abl + 2 * tq) = abv;
+    if (tq + 1024 < C)   // Cin > 1024: the second half of the table comes straight from memory (items are long there)
+      *(float2*)(abl + 2 * (tq + 1024)) = ((const float2*)ab)[(int64_t)b * C + tq + 1024];
     // first item: everything of the prologue.  Later items: at least the 16 output stores of the previous item are
     // younger than the U pieces issued behind its exchange - all but 16 operations done means raw 0-3, U 0 and U 1 landed
     if (first) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1123,6 +1126,8 @@ static int fwino_var() {
 }
 static bool fwino_16() { return fwino_var() != 8; }
 
+int wino_fused_gn_max_cin() { return fwino_16() ? WG16_MAXC : WG_MAXC; }
+
 size_t wino_fused_out_stats_chunks(int H, int W, int N, int G) {
   return (size_t)(N / G / 16) * (H / 16) * (W / 16) * (fwino_16() ? 8 : 4);
 }
@@ -1132,8 +1137,8 @@ int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* 
                          hipStream_t s) {
   KD_REQUIRE(ldx >= C && ldx % 4 == 0 && (int64_t)H * W * ldx * 4 < 0x7fffffff && ((uintptr_t)x & 15) == 0,
              "GroupNorm-fused Winograd conv: bad input row stride");
-  KD_REQUIRE(wino_fused_ok(B, H, W, C, N) && C <= WG_MAXC,
-             "GroupNorm-fused Winograd conv needs H, W % 16 == 0, Cin % 4 == 0, Cin <= 512, Cout % 64 == 0");
+  KD_REQUIRE(wino_fused_ok(B, H, W, C, N) && C <= (fwino_16() ? WG16_MAXC : WG_MAXC),
+             "GroupNorm-fused Winograd conv needs H, W % 16 == 0, Cin % 4 == 0, Cin <= 2048, Cout % 64 == 0");
   KD_REQUIRE(!out_partial || (out_groups > 0 && N % out_groups == 0 && (N / out_groups) % 16 == 0),
              "output statistics need groups of a multiple of 16 channels");
   const unsigned grid = (unsigned)((int64_t)B * (H / 16) * (W / 16) * (N / 64));
