@@ -118,9 +118,12 @@ int launch_gn_fold(const float* stats, const float* gamma, const float* beta, co
                    float* ab, int B, int C, int G, hipStream_t s);
 // out_partial != nullptr: the kernel also leaves (sum, sum of squares) partials of y per (image, group of
 // out_groups) in launch_gn_finalize's layout, wino_fused_out_stats_chunks(H, W, N, G) entries per (image, group)
+// items: the table launch_wino_fused_items fills for this (B, H, W, N): wino_fused_items_count entries of 16 bytes
 int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* U, const float* bias, const float* res,
                          int ldres, float* y, int B, int H, int W, int C, int N, double* out_partial, int out_groups,
-                         hipStream_t s);
+                         const void* items, hipStream_t s);
+size_t wino_fused_items_count(int B, int H, int W, int N);
+int launch_wino_fused_items(void* items, int B, int H, int W, int N, hipStream_t s);
 size_t wino_fused_out_stats_chunks(int H, int W, int N, int G);
 int wino_fused_gn_max_cin();   // largest Cin launch_wino_fused_gn takes (its affine table lives in LDS)
 // stats[b][g] = (mean, rstd) from `chunks` (sum, sum of squares) partials per (b, g), summed in index order

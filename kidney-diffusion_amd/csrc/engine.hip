@@ -899,9 +899,14 @@ struct Builder {
     const bool hr = res != nullptr;
     const int ldres = res ? res->LD() : 0, ldx = x.LD();
     const int64_t m = (int64_t)Bx * H * W * Cout * Cin * 9;
+    // id -> (image, y0, x0, slab) of the kernel's work items: one table per map shape, shared by the layers
+    const float* items = cached("winof_items:" + std::to_string(Bx) + "x" + std::to_string(H) + "x" + std::to_string(W) + "x" +
+                                    std::to_string(Cout),
+                                wino_fused_items_count(Bx, H, W, Cout) * 4,
+                                [&](float* dst) { KD_THROW_IF(launch_wino_fused_items(dst, Bx, H, W, Cout, 0)); });
     emit([=](hipStream_t s) {
       return launch_wino_fused_gn(uu->P(xo), ldx, uu->P(abo), U, bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W,
-                                  Cin, Cout, so_ ? (double*)uu->P(pout) : nullptr, so_ ? Cout / 16 : 0, s);
+                                  Cin, Cout, so_ ? (double*)uu->P(pout) : nullptr, so_ ? Cout / 16 : 0, items, s);
     }, "wino fused M" + std::to_string((int64_t)Bx * H * W) + " Cin" + std::to_string(Cin) + " Cout" +
            std::to_string(Cout), m);
     free(ab);

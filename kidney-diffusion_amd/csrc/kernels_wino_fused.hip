@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <vector>
 
 namespace kd {
 
@@ -674,13 +675,15 @@ __global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __re
 // fetched while this item's output transform, exchange and stores run; its U chunks 0 / 1 follow once the exchange
 // (which lives in the U and V stages) has been read.  What a one-item workgroup pays per item - dispatch, descriptor
 // set-up, the HBM latency of the first patch chunks - was 6.5 chunk times per item (17 % of a Cin = 128 layer).
+template <bool STAMP>   // STAMP: diagnostic build that leaves s_memtime stamps of the item phases (KD_FWINO_STAMP)
 __global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __restrict__ x, int ldx,
                                                                const float* __restrict__ ab,
                                                                const float* __restrict__ U,
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ res, int ldres,
                                                                float* __restrict__ y, int B, int H, int W, int C,
-                                                               int N, double* __restrict__ opart, int oG) {
+                                                               int N, double* __restrict__ opart, int oG, const int4* __restrict__ items,
+                                                               long long* __restrict__ stamps) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(1024))) float raw_0[WF_RAW], raw_1[WF_RAW], raw_2[WF_RAW], raw_3[WF_RAW];
   __shared__ __attribute__((aligned(1024))) float us_0[WF_UV], us_1[WF_UV], us_2[WF_UV], us_3[WF_UV];
@@ -696,6 +699,13 @@ __global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __re
   int tq = threadIdx.x, lq = tq & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tq >> 6);
   const int pr = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  int stamp_item = 0;
+  auto stamp = [&](int k) {   // [block][wave 0 | 15][item < 8][phase k < 8]
+    if constexpr (STAMP) {
+      if ((wave == 0 || wave == 15) && (threadIdx.x & 63) == 0 && stamp_item < 8)
+        stamps[(((int64_t)blockIdx.x * 2 + (wave == 15)) * 8 + stamp_item) * 8 + k] = __builtin_amdgcn_s_memtime();
+    }
+  };
   const int pw = W / 16, ph_ = H / 16;
   const int nh = N / 64;
   const int npatch = B * pw * ph_;
@@ -709,10 +719,10 @@ __global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __re
   uint32_t voffX;
   bool aok[2];
   __amdgpu_buffer_rsrc_t rsX;
-  auto image_of = [&](int id) {
-    const int bpatch = (npatch & 7) == 0 ? (id / (8 * nh)) * 8 + (id & 7) : id / nh;
-    return bpatch / (pw * ph_);
-  };
+  // items[id] = (image, y0, x0, 64-channel slab) of item id, in the order that keeps the N/64 items of one patch back
+  // to back on ONE XCD (wino_fused_items_kernel): a table, because every one of the 16 waves decodes every item, and
+  // the five divisions by run-time values cost each of them ~150 VALU + ~250 SALU instructions per item
+  auto image_of = [&](int id) { return items[id].x; };
   auto slot_pixel = [&](int slot, int& iy, int& ix) {
     int py = slot / 18, pq = slot - py * 18;
     int px = pq < 9 ? 2 * pq : 2 * (pq - 9) + 1;
@@ -721,18 +731,12 @@ __global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __re
     return slot < 324 && iy >= 0 && iy < H && ix >= 0 && ix < W;
   };
   auto setup = [&](int id) {
-    int bpatch;
-    if ((npatch & 7) == 0) {   // the N/64 items of one patch back to back on ONE XCD
-      bpatch = (id / (8 * nh)) * 8 + (id & 7);
-      nhalf = (id >> 3) % nh;
-    } else {
-      bpatch = id / nh;
-      nhalf = id % nh;
-    }
-    b = bpatch / (pw * ph_);
-    prem = bpatch - b * pw * ph_;
-    y0 = (prem / pw) * 16;
-    x0 = (prem % pw) * 16;
+    const int4 it = items[id];
+    b = it.x;
+    y0 = it.y;
+    x0 = it.z;
+    nhalf = it.w;
+    prem = (y0 >> 4) * pw + (x0 >> 4);
     rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)b * H * W * ldx), 0, (int)((int64_t)H * W * ldx * 4),
                                             0x00020000);
     // (the empty asm makes the thread index opaque here: otherwise hipcc hoists the slot -> (row, column) divisions
@@ -884,13 +888,17 @@ __global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __re
   };
 
   // exchange messages of the output transform: (group g = wm * 2 + wn, source row sr, destination index dd among the
-  // other three rows) -> 2 KB (two float4 per lq); 48 messages fill the V stages (16) and the four U stages (8 each)
+  // other three rows) -> 2 KB (two float4 per lane); the 48 messages fill the V stages (16), U stages 2 and 3 (8
+  // each) and the four raw stages (4 each).  U stages 0 / 1 stay free: the next item's U chunks 0 / 1 land there
+  // while the exchange runs
   const int g = wm * 2 + wn;
   auto exmsg = [&](int sr, int dd) -> float4* {
     const int m = (g * 4 + sr) * 3 + dd;
     float* base = m < 16 ? vs + m * 512
-                         : m < 24 ? us_0 + (m - 16) * 512
-                                  : m < 32 ? us_1 + (m - 24) * 512 : m < 40 ? us_2 + (m - 32) * 512 : us_3 + (m - 40) * 512;
+                : m < 24 ? us_2 + (m - 16) * 512
+                : m < 32 ? us_3 + (m - 24) * 512
+                : m < 36 ? raw_0 + (m - 32) * 512
+                : m < 40 ? raw_1 + (m - 36) * 512 : m < 44 ? raw_2 + (m - 40) * 512 : raw_3 + (m - 44) * 512;
     return (float4*)base;
   };
 
@@ -914,15 +922,18 @@ __global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __re
   bool first = true;
   while (true) {
     // ---- top of an item: its first raw chunks (and U chunks 0 / 1) are in flight or have landed
+    stamp(0);
     if (!first) derive();
-    if (tq < C) *(float2*)(abl + 2 * tq) = abv;
-    if (tq + 1024 < C)   // Cin > 1024: the second half of the table comes straight from memory (items are long there)
-      *(float2*)(abl + 2 * (tq + 1024)) = ((const float2*)ab)[(int64_t)b * C + tq + 1024];
-    // first item: everything of the prologue.  Later items: at least the 16 output stores of the previous item are
-    // younger than the U pieces issued behind its exchange - all but 16 operations done means raw 0-3, U 0 and U 1 landed
+    if (first) {   // (later items: written behind the previous item's exchange, see there)
+      if (tq < C) *(float2*)(abl + 2 * tq) = abv;
+      if (tq + 1024 < C) *(float2*)(abl + 2 * (tq + 1024)) = ((const float2*)ab)[(int64_t)b * C + tq + 1024];
+    }
+    // first item: everything of the prologue.  Later items: the four 16-byte output stores of the previous item are
+    // the youngest operations of every wave - all but 4 done means its prefetched raw 0-3, U 0 and U 1 have landed
     if (first) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    stamp(1);
     const int next = item + (int)gridDim.x;
     const bool has_next = next < nitems;
     activate(0, S0{}, LiveF{}, LiveT{});
@@ -934,6 +945,7 @@ __global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __re
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const bool border = y0 == 0 || x0 == 0 || y0 + 16 >= H || x0 + 16 >= W;
+    stamp(2);
     if (pr == 0) {
       if (border) run(R0{}, LiveT{}); else run(R0{}, LiveF{});
     } else if (pr == 1) {
@@ -943,8 +955,10 @@ __global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __re
     } else {
       if (border) run(R3{}, LiveT{}); else run(R3{}, LiveF{});
     }
+    stamp(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (out-of-range, zero) DMAs still write LDS
     __builtin_amdgcn_s_barrier();
+    stamp(4);
 
     // ---- this item's coordinates for the epilogue; the loader state moves on to the next item, whose first four
     // raw chunks start now (the raw stages take no part in the exchange)
@@ -952,19 +966,10 @@ __global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __re
     int l_ = threadIdx.x & 63;   // opaque per item: the epilogue's addresses must not be hoisted over the main loop (registers)
     asm volatile("" : "+v"(l_));
     if (has_next && wave * 64 + l_ < C) abv = ((const float2*)ab)[(int64_t)image_of(next) * C + wave * 64 + l_];
-    // The 16 outputs of a lq: tile row wm * 4 + pr, tile columns i + 4 (lq >> 5), channel n: pixel pix0 + 2 i (+ 1,
-    // + W, + W + 1)
-    const int n = en0 + wn * 32 + (l_ & 31);
-    const int64_t pix0 = ((int64_t)eb * H + ey0 + 2 * (wm * 4 + pr)) * W + ex0 + 8 * (l_ >> 5);
-    const float bv = bias ? bias[n] : 0.f;
-    if (has_next) {
+    if (has_next) {   // U chunks 0 / 1 of the next item start now (their stages take no part in the exchange)
       setup(next);
-      if (wave < 8) {
-        issue_raw(0, S0{}, LiveF{});
-        issue_raw(1, S1{}, LiveF{});
-        issue_raw(2, S2{}, LiveF{});
-        issue_raw(3, S3{}, LiveF{});
-      }
+      issue_u_at(0, S0{}, LiveF{}, (uint32_t)((wave * 64 + l_) * 16));   // (not the loop's tq * 16: see l_)
+      issue_u_at(1, S1{}, LiveF{}, (uint32_t)((wave * 64 + l_) * 16));
     }
 
     // output transform Y = A^T m A.  Columns first, inside the wave: (q0, q1) = (a0 + a1 + a2, a1 - a2 - a3) of its
@@ -987,6 +992,7 @@ __global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __re
                                            q[4 * d + 2 * h + 1].y);
       }
       __syncthreads();
+      stamp(5);
       float2 Q[4][4];   // [source row][element i]
 #pragma unroll
       for (int sr = 0; sr < 4; ++sr) {
@@ -1003,49 +1009,89 @@ __global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __re
           }
         }
       }
-      if (has_next) {   // the exchange has been read by everybody: U chunks 0 / 1 of the next item may land on it
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        issue_u_at(0, S0{}, LiveF{}, (uint32_t)((wave * 64 + l_) * 16));   // (not the loop's tq * 16: see l_)
-        issue_u_at(1, S1{}, LiveF{}, (uint32_t)((wave * 64 + l_) * 16));
+      // the exchange has been read by everybody: the next item's first four raw chunks may land on it (raw stages;
+      // they arrive under the residual loads and the stores), and the V stages and U stages 2 / 3 become the waves'
+      // private turn-around tiles below
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stamp(6);
+      // the affine table of the next item's image: requested at the top of this epilogue, nobody reads the table
+      // before the next main loop (a wait for it at the top of the item would also wait for this item's stores)
+      if (has_next) {
+        const int ti = wave * 64 + l_;
+        if (ti < C) *(float2*)(abl + 2 * ti) = abv;
+        if (ti + 1024 < C) *(float2*)(abl + 2 * (ti + 1024)) = ((const float2*)ab)[(int64_t)b * C + ti + 1024];
       }
+      if (has_next && wave < 8) {
+        issue_raw(0, S0{}, LiveF{});
+        issue_raw(1, S1{}, LiveF{});
+        issue_raw(2, S2{}, LiveF{});
+        issue_raw(3, S3{}, LiveF{});
+      }
+      // The wave's 16 outputs per lane are tile row ty = wm * 4 + PR: pixel rows 2 ty, 2 ty + 1 x 16 pixels x 32
+      // channels, one channel per lane.  Stored like that they are 16 dword stores (+ 16 residual loads) per wave, 512
+      // narrow memory instructions per item whose ISSUE took ~6 chunk times per item, whatever the K (17 % of a
+      // Cin = 128 layer; MI355X guide T21).  So the wave turns the block through a private 4 KB of LDS - [pixel p =
+      // dy * 16 + x][channel], 16 ds_write_b32, 4 ds_read_b128, no barrier - and every lane finishes 4 consecutive
+      // channels of 4 pixels with 16-byte accesses: 4 stores (+ 4 loads) per wave.
+      float* sc = wave < 8 ? vs + wave * 1024 : wave < 12 ? us_2 + (wave - 8) * 1024 : us_3 + (wave - 12) * 1024;
+      {
+        float* sw = sc + (8 * (l_ >> 5)) * 32 + (l_ & 31);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t pix = pix0 + 2 * i;
-        float o00 = Q[0][i].x + Q[1][i].x + Q[2][i].x + bv, o01 = Q[0][i].y + Q[1][i].y + Q[2][i].y + bv,
-              o10 = Q[1][i].x - Q[2][i].x - Q[3][i].x + bv, o11 = Q[1][i].y - Q[2][i].y - Q[3][i].y + bv;
-        if (res) {
-          o00 += res[pix * ldres + n];
-          o01 += res[(pix + 1) * ldres + n];
-          o10 += res[(pix + W) * ldres + n];
-          o11 += res[(pix + W + 1) * ldres + n];
-        }
-        y[pix * N + n] = o00;
-        y[(pix + 1) * N + n] = o01;
-        y[(pix + W) * N + n] = o10;
-        y[(pix + W + 1) * N + n] = o11;
-        if (opart) {
-          gs1 += ((double)o00 + (double)o01) + ((double)o10 + (double)o11);
-          gs2 += ((double)o00 * o00 + (double)o01 * o01) + ((double)o10 * o10 + (double)o11 * o11);
+        for (int i = 0; i < 4; ++i) {
+          sw[(2 * i) * 32] = Q[0][i].x + Q[1][i].x + Q[2][i].x;
+          sw[(2 * i + 1) * 32] = Q[0][i].y + Q[1][i].y + Q[2][i].y;
+          sw[(16 + 2 * i) * 32] = Q[1][i].x - Q[2][i].x - Q[3][i].x;
+          sw[(17 + 2 * i) * 32] = Q[1][i].y - Q[2][i].y - Q[3][i].y;
         }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own writes have landed (nobody else reads them)
+      const int rq = l_ >> 3, c4 = (l_ & 7) * 4;
+      const int nb = en0 + wn * 32 + c4;
+      const float4 b4v = bias ? *(const float4*)(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // per-image base pointers (scalar) + 32-bit offsets inside the image (H W N 4 < 2^31, host check)
+      float* const yb = y + (int64_t)eb * H * W * N;
+      const float* const rb = res + (int64_t)eb * H * W * ldres;
+      const uint32_t pixr = (uint32_t)((ey0 + 2 * (wm * 4 + PR)) * W + ex0 + rq);
+      float fs1 = 0.f, fs2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {   // pixel p = rq + 8 k of the block: row p >> 4 = k >> 1, x = rq + 8 (k & 1)
+        const uint32_t pix = pixr + (uint32_t)((k >> 1) * W + 8 * (k & 1));
+        float4 v = *(const float4*)(sc + (rq + 8 * k) * 32 + c4);
+        v.x += b4v.x; v.y += b4v.y; v.z += b4v.z; v.w += b4v.w;
+        if (res) {
+          const float4 r4 = *(const float4*)(rb + (pix * (uint32_t)ldres + (uint32_t)nb));
+          v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        }
+        *(float4*)(yb + (pix * (uint32_t)N + (uint32_t)nb)) = v;
+        if (opart) {   // the lane's own 16 values in fp32 (31 operations at the fp32 rate), fp64 from there on
+          fs1 += (v.x + v.y) + (v.z + v.w);
+          fs2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fs2))));
+        }
+      }
+      gs1 = (double)fs1;
+      gs2 = (double)fs2;
     };
     if (pr == 0) finish(R0{});
     else if (pr == 1) finish(R1{});
     else if (pr == 2) finish(R2{});
     else finish(R3{});
     if (opart) {   // 8 entries per patch and 16-channel segment: (wm, pr)
+      // a lane holds 4 channels 4 (l & 7) ..: lanes with (l & 7) < 4 make up segment 0, the others segment 1
 #pragma unroll
-      for (int off = 1; off <= 8; off <<= 1) {
+      for (int off = 8; off <= 32; off <<= 1) {
         gs1 += __shfl_xor(gs1, off, 64);
         gs2 += __shfl_xor(gs2, off, 64);
       }
-      gs1 += __shfl_xor(gs1, 32, 64);
-      gs2 += __shfl_xor(gs2, 32, 64);
-      if ((l_ & 47) == 0) {   // l_s 0 and 16: channel segments 0 and 1 of this wave
+#pragma unroll
+      for (int off = 1; off <= 2; off <<= 1) {
+        gs1 += __shfl_xor(gs1, off, 64);
+        gs2 += __shfl_xor(gs2, off, 64);
+      }
+      if ((l_ & ~4) == 0) {   // lanes 0 and 4: channel segments 0 and 1 of this wave
         int Cg = N / oG;
         asm volatile("" : "+s"(Cg));   // (opaque: its reciprocal is not to be kept in a register across the items)
-        const int cabs = en0 + wn * 32 + (l_ & 16);
+        const int cabs = en0 + wn * 32 + 4 * (l_ & 4);
         const int gg = cabs / Cg, cseg = (cabs - gg * Cg) >> 4;
         const int npi = pw * ph_;
         const int64_t chunks = (int64_t)(Cg >> 4) * npi * 8;
@@ -1055,11 +1101,38 @@ __global__ __launch_bounds__(1024) void wino_fused_gn16_kernel(const float* __re
         op[1] = gs2;
       }
     }
+    stamp(7);
+    ++stamp_item;
     if (!has_next) break;
     item = next;
     first = false;
   }
 #endif
+}
+
+// the item table of the sixteen-wave kernel: id -> (image, y0, x0, slab)
+__global__ __launch_bounds__(256) void wino_fused_items_kernel(int4* __restrict__ out, int B, int H, int W, int N) {
+  const int pw = W / 16, ph = H / 16, nh = N / 64;
+  const int npatch = B * pw * ph;
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= npatch * nh) return;
+  int bpatch, nhalf;
+  if ((npatch & 7) == 0) {   // the N/64 items of one patch back to back on ONE XCD (ids go round-robin over the 8 XCDs)
+    bpatch = (id / (8 * nh)) * 8 + (id & 7);
+    nhalf = (id >> 3) % nh;
+  } else {
+    bpatch = id / nh;
+    nhalf = id % nh;
+  }
+  const int b = bpatch / (pw * ph), prem = bpatch - b * pw * ph;
+  out[id] = make_int4(b, (prem / pw) * 16, (prem % pw) * 16, nhalf);
+}
+size_t wino_fused_items_count(int B, int H, int W, int N) { return (size_t)B * (H / 16) * (W / 16) * (N / 64); }
+int launch_wino_fused_items(void* items, int B, int H, int W, int N, hipStream_t s) {
+  const size_t n = wino_fused_items_count(B, H, W, N);
+  hipLaunchKernelGGL(wino_fused_items_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (int4*)items, B, H, W, N);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 bool wino_fused_ok(int B, int H, int W, int C, int N) {
@@ -1134,7 +1207,7 @@ size_t wino_fused_out_stats_chunks(int H, int W, int N, int G) {
 
 int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* U, const float* bias, const float* res,
                          int ldres, float* y, int B, int H, int W, int C, int N, double* out_partial, int out_groups,
-                         hipStream_t s) {
+                         const void* items, hipStream_t s) {
   KD_REQUIRE(ldx >= C && ldx % 4 == 0 && (int64_t)H * W * ldx * 4 < 0x7fffffff && ((uintptr_t)x & 15) == 0,
              "GroupNorm-fused Winograd conv: bad input row stride");
   KD_REQUIRE(wino_fused_ok(B, H, W, C, N) && C <= (fwino_16() ? WG16_MAXC : WG_MAXC),
@@ -1144,6 +1217,11 @@ int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* 
   const unsigned grid = (unsigned)((int64_t)B * (H / 16) * (W / 16) * (N / 64));
   const int var = fwino_var();
   if (fwino_16()) {
+    KD_REQUIRE(((uintptr_t)y & 15) == 0 && ((uintptr_t)bias & 15) == 0 && ((uintptr_t)res & 15) == 0 && ldres % 4 == 0,
+               "GroupNorm-fused Winograd conv: output, bias and residual rows must be 16-byte aligned");
+    KD_REQUIRE(items != nullptr, "GroupNorm-fused Winograd conv: item table missing (launch_wino_fused_items)");
+    KD_REQUIRE((int64_t)H * W * N * 4 < 0x7fffffff && (!res || (int64_t)H * W * ldres * 4 < 0x7fffffff),
+               "GroupNorm-fused Winograd conv: output / residual images above 2 GB");
     static int cus = 0;
     if (!cus) {
       hipDeviceProp_t prop;
@@ -1153,8 +1231,43 @@ int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* 
       cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount / 8 * 8 : 256;
     }
     const unsigned pgrid = var == 17 || grid < (unsigned)cus ? grid : (unsigned)cus;
-    hipLaunchKernelGGL(wino_fused_gn16_kernel, dim3(pgrid), dim3(1024), 0, s, x, ldx, ab, U, bias, res, ldres, y, B, H, W, C,
-                       N, out_partial, out_groups);
+#ifdef KD_FWINO_STAMP_BUILD   // diagnostic library only (make EXTRA=-DKD_FWINO_STAMP_BUILD): not in the product build
+    static const bool stamping = getenv("KD_FWINO_STAMP") && atoi(getenv("KD_FWINO_STAMP")) != 0;
+    if (stamping) {   // diagnostic: per-phase cycle counts of the first items of every workgroup, printed to stderr
+      const size_t n = (size_t)pgrid * 2 * 8 * 8;
+      long long* d = nullptr;
+      KD_HIP_CHECK(hipMalloc((void**)&d, n * sizeof(long long)));
+      KD_HIP_CHECK(hipMemsetAsync(d, 0, n * sizeof(long long), s));
+      hipLaunchKernelGGL(wino_fused_gn16_kernel<true>, dim3(pgrid), dim3(1024), 0, s, x, ldx, ab, U, bias, res, ldres, y, B, H, W,
+                         C, N, out_partial, out_groups, (const int4*)items, d);
+      KD_HIP_CHECK(hipStreamSynchronize(s));
+      std::vector<long long> h(n);
+      KD_HIP_CHECK(hipMemcpy(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost));
+      (void)hipFree(d);
+      double acc[2][9] = {};
+      long cnt[2] = {};
+      for (unsigned blk = 0; blk < pgrid; ++blk)
+        for (int w = 0; w < 2; ++w)
+          for (int it = 1; it < 7; ++it) {   // items 1..6: steady state
+            const long long* t = &h[(((size_t)blk * 2 + w) * 8 + it) * 8];
+            const long long* tn = t + 8;
+            if (!t[0] || !t[7] || !tn[0]) continue;
+            for (int k = 0; k < 7; ++k) acc[w][k] += (double)(t[k + 1] - t[k]);
+            acc[w][7] += (double)(tn[0] - t[7]);
+            acc[w][8] += (double)(tn[0] - t[0]);
+            ++cnt[w];
+          }
+      for (int w = 0; w < 2; ++w)
+        if (cnt[w])
+          fprintf(stderr, "fwino16 stamps C=%d N=%d H=%d wave %d (n=%ld): top-wait %.0f | activate %.0f | loop %.0f | drain %.0f | "
+                          "q+exch-write %.0f | exch-read+B2 %.0f | turn+res+stores %.0f | to-next-top %.0f | item %.0f cycles\n",
+                  C, N, H, w ? 15 : 0, cnt[w], acc[w][0] / cnt[w], acc[w][1] / cnt[w], acc[w][2] / cnt[w], acc[w][3] / cnt[w],
+                  acc[w][4] / cnt[w], acc[w][5] / cnt[w], acc[w][6] / cnt[w], acc[w][7] / cnt[w], acc[w][8] / cnt[w]);
+      return 0;
+    }
+#endif
+    hipLaunchKernelGGL(wino_fused_gn16_kernel<false>, dim3(pgrid), dim3(1024), 0, s, x, ldx, ab, U, bias, res, ldres, y, B, H, W,
+                       C, N, out_partial, out_groups, (const int4*)items, nullptr);
     KD_HIP_CHECK(hipGetLastError());
     return 0;
   }
