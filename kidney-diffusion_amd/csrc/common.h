@@ -125,6 +125,15 @@ int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* 
 size_t wino_fused_items_count(int B, int H, int W, int N);
 int launch_wino_fused_items(void* items, int B, int H, int W, int N, hipStream_t s);
 size_t wino_fused_out_stats_chunks(int H, int W, int N, int G);
+// The same layer with items of 16 x 8 pixels x 128 output channels (kernels_wino_fused128.hip): half the activation /
+// transform work per MFMA.  Own weight packing and item table; statistics in the same layout and count.
+bool wino_fused128_use(int B, int H, int W, int C, int N);   // shape fits and not switched off (KD_FWINO_N128=0)
+int launch_wino_fused128_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s, float scale);
+size_t wino_fused128_items_count(int B, int H, int W, int N);
+int launch_wino_fused128_items(void* items, int B, int H, int W, int N, hipStream_t s);
+int launch_wino_fused_gn128(const float* x, int ldx, const float* ab, const float* U, const float* bias, const float* res,
+                            int ldres, float* y, int B, int H, int W, int C, int N, double* out_partial, int out_groups,
+                            const void* items, hipStream_t s);
 int wino_fused_gn_max_cin();   // largest Cin launch_wino_fused_gn takes (its affine table lives in LDS)
 // stats[b][g] = (mean, rstd) from `chunks` (sum, sum of squares) partials per (b, g), summed in index order
 int launch_gn_finalize(const double* partial, float* stats, int chunks, int B, int G, double count, float eps,

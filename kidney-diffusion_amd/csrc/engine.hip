@@ -878,8 +878,11 @@ struct Builder {
     const float* beta = P(gn_prefix + ".bias", Cin);
     const float* bias = P(conv_prefix + ".bias", Cout);
     const float* wsrc = raw(conv_prefix + ".weight", (int64_t)Cout * Cin * 9);
-    float* U = cached("winof_gn:" + conv_prefix, (size_t)16 * Cout * Cin,
-                      [&](float* dst) { KD_THROW_IF(launch_wino_fused_pack(wsrc, dst, Cout, Cin, 0, WF_U_SCALE)); });
+    const bool n128 = wino_fused128_use(Bx, H, W, Cin, Cout);   // items of 128 output channels where the shape allows
+    float* U = n128 ? cached("winof_gn128:" + conv_prefix, (size_t)16 * Cout * Cin,
+                             [&](float* dst) { KD_THROW_IF(launch_wino_fused128_pack(wsrc, dst, Cout, Cin, 0, WF_U_SCALE)); })
+                    : cached("winof_gn:" + conv_prefix, (size_t)16 * Cout * Cin,
+                             [&](float* dst) { KD_THROW_IF(launch_wino_fused_pack(wsrc, dst, Cout, Cin, 0, WF_U_SCALE)); });
     T ab = alloc_bytes((size_t)Bx * Cin * 2 * sizeof(float));
     T y = alloc(Bx, H, W, Cout);
     kd_unet* uu = u;
@@ -900,11 +903,16 @@ struct Builder {
     const int ldres = res ? res->LD() : 0, ldx = x.LD();
     const int64_t m = (int64_t)Bx * H * W * Cout * Cin * 9;
     // id -> (image, y0, x0, slab) of the kernel's work items: one table per map shape, shared by the layers
-    const float* items = cached("winof_items:" + std::to_string(Bx) + "x" + std::to_string(H) + "x" + std::to_string(W) + "x" +
-                                    std::to_string(Cout),
-                                wino_fused_items_count(Bx, H, W, Cout) * 4,
-                                [&](float* dst) { KD_THROW_IF(launch_wino_fused_items(dst, Bx, H, W, Cout, 0)); });
+    const std::string shape_key = std::to_string(Bx) + "x" + std::to_string(H) + "x" + std::to_string(W) + "x" + std::to_string(Cout);
+    const float* items =
+        n128 ? cached("winof128_items:" + shape_key, wino_fused128_items_count(Bx, H, W, Cout) * 4,
+                      [&](float* dst) { KD_THROW_IF(launch_wino_fused128_items(dst, Bx, H, W, Cout, 0)); })
+             : cached("winof_items:" + shape_key, wino_fused_items_count(Bx, H, W, Cout) * 4,
+                      [&](float* dst) { KD_THROW_IF(launch_wino_fused_items(dst, Bx, H, W, Cout, 0)); });
     emit([=](hipStream_t s) {
+      if (n128)
+        return launch_wino_fused_gn128(uu->P(xo), ldx, uu->P(abo), U, bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H,
+                                       W, Cin, Cout, so_ ? (double*)uu->P(pout) : nullptr, so_ ? Cout / 16 : 0, items, s);
       return launch_wino_fused_gn(uu->P(xo), ldx, uu->P(abo), U, bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W,
                                   Cin, Cout, so_ ? (double*)uu->P(pout) : nullptr, so_ ? Cout / 16 : 0, items, s);
     }, "wino fused M" + std::to_string((int64_t)Bx * H * W) + " Cin" + std::to_string(Cin) + " Cout" +

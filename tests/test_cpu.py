@@ -296,7 +296,7 @@ def test_kernels_with_counted_vmcnt_waits_use_no_scratch(tmp_path):
     if not Path(hipcc).exists():
         pytest.skip("hipcc not available")
     csrc = ROOT / "kidney-diffusion_amd" / "csrc"
-    for src in ("kernels_conv.hip", "kernels_wino_fused.hip"):
+    for src in ("kernels_conv.hip", "kernels_wino_fused.hip", "kernels_wino_fused128.hip"):
         out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", str(csrc / src),
                               f"-I{csrc}", f"-I{ROOT / 'include'}", "-Rpass-analysis=kernel-resource-usage",
                               "-o", str(tmp_path / "x.o")], capture_output=True, text=True, timeout=900)

@@ -212,7 +212,12 @@ def test_conv3x3_winograd_fused_matches_direct(lib, device, B, H, W, Cin, Cout, 
     (1, 16, 16, 128, 64, 8, False, True),     # one patch: every side is padding (must stay 0 after the activation)
     (3, 32, 48, 40, 192, 2, True, True),      # 10 chunks (padded to 12), 3 channel slabs, H != W
     (1, 48, 16, 8, 64, 2, False, False),      # 2 chunks
-    (2, 32, 32, 512, 128, 8, True, False),    # the largest affine table (512 channels)
+    (2, 32, 32, 512, 128, 8, True, False),    # 128 chunks, one 128-channel slab
+    (6, 64, 64, 64, 256, 8, True, True),      # 128-channel items: 384 items on 256 persistent workgroups (a second item per
+                                              # workgroup: prefetch under the epilogue, table written behind the exchange)
+    (1, 16, 32, 68, 128, 1, False, True),     # 17 chunks: one steady trip of 12 + a guarded remainder of 5; every patch a border
+    (1, 32, 32, 1056, 128, 8, True, False),   # affine table beyond 1024 channels (second half), 264 chunks
+    (20, 64, 64, 32, 64, 8, False, True),     # 64-channel items: 320 items on 256 persistent workgroups
 ])
 def test_gn_conv3x3_winograd_fused_matches_torch(lib, device, B, H, W, Cin, Cout, G, film, res):
     """ResnetBlock `Block` = conv3x3(SiLU(FiLM(GroupNorm(x)))) with the activation applied to the raw patch in
