@@ -237,7 +237,9 @@ int kd_conv3x3_winograd_fused_nhwc(const float* d_x, const float* d_w_oihw, cons
  * plan uses for those layers: statistics, a per-(image, channel) affine fold, and the fused Winograd kernel
  * with the activation applied to the raw patch in LDS (the activated map is never written).  d_scale_shift
  * ([B, 2 Cin] = [scale | shift]) and d_res may be NULL.  Shape rules of kd_conv3x3_winograd_fused_nhwc plus
- * Cin <= 512, Cin % G == 0. */
+ * Cin <= 2048, Cin % G == 0, (Cin / G) % 4 == 0, 16-byte aligned d_y / d_bias / d_res.  Runs the kernel the plan would
+ * pick for the shape: items of 16 x 8 pixels x 128 output channels where Cout % 128 == 0
+ * (kernels_wino_fused128.hip), 16 x 16 pixels x 64 channels otherwise (kernels_wino_fused.hip). */
 int kd_gn_conv3x3_winograd_fused_nhwc(const float* d_x, const float* d_gamma, const float* d_beta,
                                       const float* d_scale_shift, const float* d_w_oihw,
                                       const float* d_bias, const float* d_res, float* d_y, int B, int H,
@@ -248,7 +250,7 @@ int kd_gn_conv3x3_winograd_fused_nhwc(const float* d_x, const float* d_gamma, co
  * (Cout / G) % 16 == 0.) */
 /* The UNet's initial cross-embed convolution (three stride-1 convs k = 3 / 7 / 15) over a 3-plane NCHW
  * image in the plan's one-kernel form: y NHWC [B][S][S][n3+n7+n15] = cat(conv3, conv7, conv15)(x) + bias.
- * d_w3 / d_w7 / d_w15: OIHW [n][3][k][k].  Needs S % 32 == 0 and n3 <= 64, n7 <= 32, n15 <= 32. */
+ * d_w3 / d_w7 / d_w15: OIHW [n][3][k][k].  Needs S % 32 == 0, n3 <= 64, n7 <= 32, n15 <= 32, each a multiple of 4. */
 int kd_init_conv_nchw(const float* d_x, const float* d_w3, const float* d_w7, const float* d_w15,
                       const float* d_bias, float* d_y, int B, int S, int n3, int n7, int n15, void* stream);
 /* GroupNorm(G) + optional FiLM (scale+1, shift: [B,2C] = [scale | shift]) + SiLU, NHWC. */
