@@ -29,8 +29,8 @@ for p in (ROOT, ROOT / "kidney-diffusion_amd"):
 import torch  # noqa: E402
 
 BATCH, SIZE, T_SCHED = 16, 256, 250
-DOMINANT = ("wino_fused_gn16_kernel: fused Winograd F(2x2,3x3) 3x3 convs of the ResnetBlocks, GroupNorm/FiLM/SiLU applied "
-            "in the kernel (sixteen waves, persistent workgroups)")
+DOMINANT = ("wino_fused_gn128_kernel: fused Winograd F(2x2,3x3) 3x3 convs of the ResnetBlocks, GroupNorm/FiLM/SiLU applied "
+            "in the kernel (sixteen waves, persistent workgroups, items of 16x8 pixels x 128 output channels)")
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix = vector peak (v_mfma_f32_32x32x2_f32, exact fp32)
 SR_UNET_KW = dict(dim=128, dim_mults=(1, 2, 4, 8), num_resnet_blocks=2, memory_efficient=True,
                   layer_attns=(False, False, False, True), layer_cross_attns=(False, False, True, True),

@@ -13,7 +13,7 @@ import sys
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
-DOMINANT = "wino_fused_gn16_kernel"
+DOMINANT = "wino_fused_gn128_kernel"
 
 
 def main():
