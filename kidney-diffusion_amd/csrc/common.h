@@ -62,6 +62,7 @@ struct ConvParams {
   double* seg_partial;
   int seg_nseg;
   int seg_c0;  // channel of y that is segment 0 of seg_partial (several launches can fill slices of one buffer)
+  int wide_epilogue;  // set by launch_conv_igemm: 16-byte epilogue accesses (alignment checked there)
 };
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s);

@@ -14,6 +14,7 @@
 // k = 8j..8j+3 and lanes 32-63 read k = 8j+4..8j+7; A and B use the same map, and k is only a
 // summation label, so the pairing is consistent.
 #include "common.h"
+#include "epilogue.h"
 
 #include <stdlib.h>
 
@@ -244,6 +245,110 @@ __device__ __forceinline__ void store_tile_regs_pixshuf(const ConvParams& p,
         const int64_t b = mt / hw_o;
         seg_partial_store(p.seg_partial, p.seg_nseg, (int64_t)(hw_o >> 5) * 4, b, ((mt - b * hw_o) >> 5) * 4 + q,
                           p.yoff + c - p.seg_c0, n_ok, s1, s2);
+      }
+    }
+  }
+}
+
+// The same epilogue with 16-byte accesses (epilogue.h): each 32 x 32 accumulator tile goes through 4 KB of LDS private
+// to the wave and leaves as 4 stores (+ 4 loads per added map) instead of 16 (+ 16).  A workgroup's vector-memory
+// instructions - DMA pieces, epilogue loads and stores - share one address pipe per CU, and the short-K 1x1 convs
+// on the big maps are bound by it: a 128 x 64 x 256 tile is 48 DMA pieces and 64 four-byte epilogue instructions
+// per wave.  Needs full 32-row tiles inside one image, Cout % 4 == 0 and 16-byte aligned rows (conv_wide_ok).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STATS>
+__device__ __forceinline__ void store_tile_regs_wide(const ConvParams& p, float* lds,
+                                                     f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32], int64_t m0,
+                                                     int n0, int64_t M) {
+  constexpr int TM = BM / WAVES_M / 32;
+  constexpr int TN = BN / WAVES_N / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int hw_o = p.Ho * p.Wo;
+  float* scratch = lds + wave * 1024;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nc = n0 + (wn * TN + j) * 32;   // first column of the tile
+    if (nc >= p.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int64_t mt = m0 + (wm * TM + i) * 32;
+      if (mt >= M) continue;
+      WideEpilogue e;
+      e.y = p.y + mt * p.ldy + p.yoff + nc;
+      e.ldy = p.ldy;
+      e.bias = p.bias ? p.bias + nc : nullptr;
+      e.res = p.res ? p.res + mt * p.ldres + nc : nullptr;
+      e.ldres = p.ldres;
+      e.gate_src = p.gate_src ? p.gate_src + mt * p.ldgs + nc : nullptr;
+      e.ldgs = p.ldgs;
+      e.gate = p.gate_src ? p.gate + (mt / hw_o) * p.Cout + nc : nullptr;
+      e.rows = M - mt < 32 ? (int)(M - mt) : 32;
+      e.cols = p.Cout - nc < 32 ? p.Cout - nc : 32;
+      e.act = p.act;
+      double s1, s2;
+      store_tile32_wide<STATS>(*(const ep_f32x16*)&acc[i][j], scratch, e, s1, s2);
+      if (STATS) {
+        reduce_tile32_stats(s1, s2);
+        if ((lane & ~4) == 0 && 4 * (lane & 7) < e.cols) {   // lanes 0 and 4: columns 0-15 and 16-31 of the tile
+          const int64_t b = mt / hw_o;
+          const int ch = p.yoff + nc + 4 * (lane & 4) - p.seg_c0;
+          double* o = p.seg_partial + ((b * p.seg_nseg + (ch >> 4)) * (hw_o >> 5) + ((mt - b * hw_o) >> 5)) * 2;
+          o[0] = s1;
+          o[1] = s2;
+        }
+      }
+    }
+  }
+}
+
+// PixelShuffle(2) form of the 16-byte epilogue: the 32 rows of a tile are 32 consecutive input pixels of one image row
+// (Wo % 32 == 0) and its 32 columns one sub-position q = (i, j) x 32 consecutive channels (Co % 32 == 0), so the
+// tile is 32 output pixels two apart: the same turn with a row stride of 2 ldy.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STATS>
+__device__ __forceinline__ void store_tile_regs_pixshuf_wide(const ConvParams& p, float* lds,
+                                                             f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
+                                                             int64_t m0, int n0, int64_t M) {
+  constexpr int TM = BM / WAVES_M / 32;
+  constexpr int TN = BN / WAVES_N / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int Co = p.Cout >> 2;
+  const int hw_o = p.Ho * p.Wo;
+  float* scratch = lds + wave * 1024;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nc = n0 + (wn * TN + j) * 32;
+    if (nc >= p.Cout) continue;
+    const int q = nc / Co, c = nc - q * Co;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int64_t mt = m0 + (wm * TM + i) * 32;
+      if (mt >= M) continue;
+      const int64_t row = mt / p.Wo;                 // b * Ho + oy: the whole tile is in this image row
+      const int ox0 = (int)(mt - row * p.Wo);
+      WideEpilogue e;
+      e.y = p.y + ((2 * row + (q >> 1)) * (2 * p.Wo) + 2 * ox0 + (q & 1)) * (int64_t)p.ldy + p.yoff + c;
+      e.ldy = 2 * (int64_t)p.ldy;
+      e.bias = p.bias ? p.bias + nc : nullptr;
+      e.res = nullptr;
+      e.ldres = 0;
+      e.gate_src = nullptr;
+      e.ldgs = 0;
+      e.gate = nullptr;
+      e.rows = 32;
+      e.cols = 32;
+      e.act = p.act;
+      double s1, s2;
+      store_tile32_wide<STATS>(*(const ep_f32x16*)&acc[i][j], scratch, e, s1, s2);
+      if (STATS) {   // chunk = (input row tile) * 4 + sub-position
+        reduce_tile32_stats(s1, s2);
+        if ((lane & ~4) == 0) {
+          const int64_t b = mt / hw_o;
+          const int ch = p.yoff + c + 4 * (lane & 4) - p.seg_c0;
+          double* o = p.seg_partial + ((b * p.seg_nseg + (ch >> 4)) * ((int64_t)(hw_o >> 5) * 4) + ((mt - b * hw_o) >> 5) * 4 + q) * 2;
+          o[0] = s1;
+          o[1] = s2;
+        }
       }
     }
   }
@@ -637,8 +742,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
     q.out_mode = OUT_NHWC; q.ldy = p.Cout; q.yoff = 0;
     q.y = p.partial + (int64_t)blockIdx.z * M * p.Cout;
     store_tile_regs<BM, BN, WAVES_M, WAVES_N>(q, acc, m0, n0, M);
+  } else if (p.out_mode == OUT_NHWC && p.wide_epilogue && (!p.gate_src || (hw & 31) == 0)) {
+    if (p.seg_partial) store_tile_regs_wide<BM, BN, WAVES_M, WAVES_N, true>(p, lds, acc, m0, n0, M);
+    else store_tile_regs_wide<BM, BN, WAVES_M, WAVES_N, false>(p, lds, acc, m0, n0, M);
   } else if (p.out_mode == OUT_NHWC && (!p.gate_src || ((hw & 31) == 0 && !p.res && p.act == ACT_NONE))) {
     store_tile_regs<BM, BN, WAVES_M, WAVES_N>(p, acc, m0, n0, M);
+  } else if (p.out_mode == OUT_PIXSHUF && ((p.Cout >> 2) & 31) == 0 && (p.Wo & 31) == 0 && !p.gate_src && !p.res &&
+             p.wide_epilogue) {
+    if (p.seg_partial) store_tile_regs_pixshuf_wide<BM, BN, WAVES_M, WAVES_N, true>(p, lds, acc, m0, n0, M);
+    else store_tile_regs_pixshuf_wide<BM, BN, WAVES_M, WAVES_N, false>(p, lds, acc, m0, n0, M);
   } else if (p.out_mode == OUT_PIXSHUF && ((p.Cout >> 2) & 31) == 0 && (p.Wo & 31) == 0 && !p.gate_src && !p.res) {
     if (p.seg_partial)
       store_tile_regs_pixshuf<BM, BN, WAVES_M, WAVES_N, true>(p, acc, m0, n0, M);
@@ -726,6 +838,52 @@ int conv_seg_chunks(const ConvParams& p) {
   return 0;
 }
 
+// Tile shape of the buffer-DMA kernel for a fast-path shape (fast_shape_ok)
+static int launch_conv_fast(const ConvParams& p, int64_t M, hipStream_t s) {
+  const int64_t tiles256 = ((M + 255) / 256) * ((p.Cout + 127) / 128);
+  // 256x128 (one 8-wave workgroup per CU) needs a K loop long enough to amortise its serial
+  // prologue/epilogue; short-K 1x1 convs run as two 128x128 workgroups per CU, which overlap one
+  // tile's epilogue with the other's loop (measured in the step: 3x3 Cin=128 layers still prefer 256x128)
+  const int k_chunks = p.KH * p.KW * (p.Cin / BK);
+  static const int shortk = getenv("KD_SHORTK_TILE") ? atoi(getenv("KD_SHORTK_TILE")) : 0;   // experiment switch
+  if (p.KH * p.KW == 1 && k_chunks <= 8 && p.wz_rows == 0 && shortk == 1 &&
+      ((M + 127) / 128) * ((p.Cout + 127) / 128) >= 256) {
+    dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 127) / 128);
+    hipLaunchKernelGGL((conv_buf_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, s, p);
+  } else if (p.KH * p.KW == 1 && k_chunks <= 8 && p.wz_rows == 0 && shortk == 2 && tiles256 >= 256) {
+    dim3 grid((unsigned)((M + 255) / 256), (p.Cout + 127) / 128);
+    hipLaunchKernelGGL((conv_buf_kernel<256, 128, 4, 2, 2>), grid, dim3(512), 0, s, p);
+  } else if (p.KH * p.KW == 1 && k_chunks <= 8 && p.wz_rows == 0) {
+    // 1x1 convs with K <= 256 (ResnetBlock skip convs with the gate epilogue, pixel-shuffle upsamples)
+    // move as many bytes as they compute: three 128x64 workgroups per CU keep more loads in flight
+    // (measured -12..16 % on them; the Winograd GEMMs of the same K lose 4 % with this shape)
+    dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 63) / 64);
+    hipLaunchKernelGGL((conv_buf_kernel<128, 64, 2, 2, 3>), grid, dim3(256), 0, s, p);
+  } else if (tiles256 >= 512 && (p.KH * p.KW > 1 || k_chunks >= 64)) {
+    dim3 grid((unsigned)((M + 255) / 256), (p.Cout + 127) / 128);
+    hipLaunchKernelGGL((conv_buf_kernel<256, 128, 4, 2, 2>), grid, dim3(512), 0, s, p);
+  } else if (((M + 127) / 128) * ((p.Cout + 127) / 128) >= 512) {
+    dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 127) / 128);
+    hipLaunchKernelGGL((conv_buf_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, s, p);
+  } else {  // few tiles (deep 16x16 levels, attention projections): 128x64 tiles, 3 workgroups per CU
+    dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 63) / 64);
+    hipLaunchKernelGGL((conv_buf_kernel<128, 64, 2, 2, 3>), grid, dim3(256), 0, s, p);
+  }
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// 16-byte epilogue (store_tile_regs_wide): NHWC output whose rows, and those of every map the epilogue adds, start on
+// 16-byte boundaries; whole 32-row MFMA tiles (and one image per tile where a per-image gate is applied)
+static bool conv_wide_ok(const ConvParams& p) {
+  const int64_t M = (int64_t)p.B * p.Ho * p.Wo;
+  auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  return p.ksplit <= 1 && M % 32 == 0 && p.Cout % 4 == 0 && p.ldy % 4 == 0 && p.yoff % 4 == 0 && al(p.y) && al(p.bias) &&
+         (!p.res || (al(p.res) && p.ldres % 4 == 0)) &&
+         (!p.gate_src || (al(p.gate_src) && al(p.gate) && p.ldgs % 4 == 0 && (p.Ho * p.Wo) % 32 == 0)) &&
+         (!p.seg_partial || ((p.Ho * p.Wo) % 32 == 0 && p.Cout % 16 == 0));
+}
+
 int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
   KD_REQUIRE(p.Cin % 4 == 0 && p.ldx % 4 == 0, "igemm needs Cin and ldx multiples of 4");
   KD_REQUIRE(!p.seg_partial || (conv_seg_chunks(p) > 0 && p.seg_nseg > 0),
@@ -757,37 +915,14 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     return 0;
   }
   const bool fast = fast_shape_ok(p) && M > 64;
-  if (fast) {
-    const int64_t tiles256 = ((M + 255) / 256) * ((p.Cout + 127) / 128);
-    // 256x128 (one 8-wave workgroup per CU) needs a K loop long enough to amortise its serial
-    // prologue/epilogue; short-K 1x1 convs run as two 128x128 workgroups per CU, which overlap one
-    // tile's epilogue with the other's loop (measured in the step: 3x3 Cin=128 layers still prefer 256x128)
-    const int k_chunks = p.KH * p.KW * (p.Cin / BK);
-    static const int shortk = getenv("KD_SHORTK_TILE") ? atoi(getenv("KD_SHORTK_TILE")) : 0;   // experiment switch
-    if (p.KH * p.KW == 1 && k_chunks <= 8 && p.wz_rows == 0 && shortk == 1 &&
-        ((M + 127) / 128) * ((p.Cout + 127) / 128) >= 256) {
-      dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 127) / 128);
-      hipLaunchKernelGGL((conv_buf_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, s, p);
-    } else if (p.KH * p.KW == 1 && k_chunks <= 8 && p.wz_rows == 0 && shortk == 2 && tiles256 >= 256) {
-      dim3 grid((unsigned)((M + 255) / 256), (p.Cout + 127) / 128);
-      hipLaunchKernelGGL((conv_buf_kernel<256, 128, 4, 2, 2>), grid, dim3(512), 0, s, p);
-    } else if (p.KH * p.KW == 1 && k_chunks <= 8 && p.wz_rows == 0) {
-      // 1x1 convs with K <= 256 (ResnetBlock skip convs with the gate epilogue, pixel-shuffle upsamples)
-      // move as many bytes as they compute: three 128x64 workgroups per CU keep more loads in flight
-      // (measured -12..16 % on them; the Winograd GEMMs of the same K lose 4 % with this shape)
-      dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 63) / 64);
-      hipLaunchKernelGGL((conv_buf_kernel<128, 64, 2, 2, 3>), grid, dim3(256), 0, s, p);
-    } else if (tiles256 >= 512 && (p.KH * p.KW > 1 || k_chunks >= 64)) {
-      dim3 grid((unsigned)((M + 255) / 256), (p.Cout + 127) / 128);
-      hipLaunchKernelGGL((conv_buf_kernel<256, 128, 4, 2, 2>), grid, dim3(512), 0, s, p);
-    } else if (((M + 127) / 128) * ((p.Cout + 127) / 128) >= 512) {
-      dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 127) / 128);
-      hipLaunchKernelGGL((conv_buf_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, s, p);
-    } else {  // few tiles (deep 16x16 levels, attention projections): 128x64 tiles, 3 workgroups per CU
-      dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 63) / 64);
-      hipLaunchKernelGGL((conv_buf_kernel<128, 64, 2, 2, 3>), grid, dim3(256), 0, s, p);
-    }
-  } else if (p.wz_rows > 0) {
+  if (fast && (p.out_mode == OUT_NHWC || p.out_mode == OUT_PIXSHUF) && conv_wide_ok(p) &&
+      !(getenv("KD_CONV_WIDE") && atoi(getenv("KD_CONV_WIDE")) == 0)) {   // (A/B switch)
+    ConvParams q = p;
+    q.wide_epilogue = 1;
+    return launch_conv_fast(q, M, s);
+  }
+  if (fast) return launch_conv_fast(p, M, s);
+  if (p.wz_rows > 0) {
     KD_REQUIRE(false, "batched GEMM needs the buffer-load fast path (Cin % 32 == 0, Cout > 32)");
   } else if (p.Cout <= 32) {
     dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 31) / 32);
