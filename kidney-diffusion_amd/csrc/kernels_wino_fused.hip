@@ -1228,7 +1228,7 @@ int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* 
       int dev = 0;
       KD_HIP_CHECK(hipGetDevice(&dev));
       KD_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-      cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount / 8 * 8 : 256;
+      cus = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 8;   // a multiple of the 8 XCDs
     }
     const unsigned pgrid = var == 17 || grid < (unsigned)cus ? grid : (unsigned)cus;
 #ifdef KD_FWINO_STAMP_BUILD   // diagnostic library only (make EXTRA=-DKD_FWINO_STAMP_BUILD): not in the product build

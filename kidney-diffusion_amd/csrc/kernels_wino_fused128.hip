@@ -576,7 +576,7 @@ int launch_wino_fused_gn128(const float* x, int ldx, const float* ab, const floa
     int dev = 0;
     KD_HIP_CHECK(hipGetDevice(&dev));
     KD_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount / 8 * 8 : 256;
+    cus = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 8;   // a multiple of the 8 XCDs
   }
   const unsigned pgrid = grid < (unsigned)cus ? grid : (unsigned)cus;   // persistent: one workgroup per CU
   hipLaunchKernelGGL(wino_fused_gn128_kernel, dim3(pgrid), dim3(1024), 0, s, x, ldx, ab, U, bias, res, ldres, y, B, H, W, C, N,
