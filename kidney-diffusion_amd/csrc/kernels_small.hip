@@ -124,10 +124,14 @@ int launch_linear_skinny(const float* x, int ldx, const float* w, const float* b
 // logits[p] = x[p][:]·wk + bk ; pooled[c] = sum_p softmax_p(logits) x[p][c]   (per batch element)
 // One read of x: every wave keeps a running (max, sum, weighted channel sums) over its rows (online
 // softmax), waves are merged through LDS, blocks through a small partial buffer.
-constexpr int GCA_ROWS = 256;   // pixels per block (grows so that an image never has more than 1024 blocks)
-static inline int gca_rows(int HW) {
+// pixels per block: 256, more where an image would otherwise have more than 1024 blocks, fewer (down to 32) where the
+// launch would otherwise have fewer than 1024 blocks - the 16x16 / 32x32 levels and every level of a batch-1 patch
+// ran on 16 .. 256 blocks (a batch-1 64x64 x 1024-channel map: 43 us for 17 MB)
+constexpr int GCA_ROWS = 256;
+static inline int gca_rows(int HW, int B) {
   int r = GCA_ROWS;
   while ((HW + r - 1) / r > 1024) r *= 2;
+  while (r > 32 && (int64_t)((HW + r - 1) / r) * B < 1024) r /= 2;
   return r;
 }
 constexpr int GCA_MAXT = 8;     // float4 slices per lane: C <= 2048
@@ -268,14 +272,14 @@ __global__ __launch_bounds__(256) void gca_combine_kernel(const float* __restric
 }
 
 size_t gca_scratch_floats(int B, int HW, int C) {
-  int rows = gca_rows(HW), chunks = (HW + rows - 1) / rows;
+  int rows = gca_rows(HW, B), chunks = (HW + rows - 1) / rows;
   return (size_t)B * chunks * (C + 2);
 }
 
 int launch_gca_pool(const float* x, const float* wk, const float* bk, float* /*logits (unused)*/, float* pooled,
                     float* scratch, int B, int HW, int C, hipStream_t s) {
   KD_REQUIRE(C % 4 == 0 && C <= 64 * 4 * GCA_MAXT, "gca needs C % 4 == 0 and C <= 2048");
-  const int rows = gca_rows(HW), chunks = (HW + rows - 1) / rows;
+  const int rows = gca_rows(HW, B), chunks = (HW + rows - 1) / rows;
   size_t smem = (size_t)(4 * C + 8) * sizeof(float);
   const int C4 = C / 4;
   dim3 grid(chunks, B), blk(256);
