@@ -314,7 +314,8 @@ def grid_workload(args, world, rank, device, distributed, barrier):
     def run(positions, cond_images, canvases):
         out = D.sample_grids(sample_fn, (1, 2, 3), [positions] * canvases, [cond_images] * canvases, 0.25,
                              [n] * canvases, patch_width=geom.patch_width, device=slab_dev,
-                             pipeline=not args.no_pipeline, stage_cost=stage_cost)
+                             pipeline=not args.no_pipeline, stage_cost=stage_cost,
+                             overlap_stages=None if (args.no_overlap or args.no_pipeline) else device)
         sub = G.GridGeometry(geom.patch_width, geom.patch_dist, n, geom.out_patch_dist,
                              1024 + (n - 1) * geom.out_patch_dist)
         return [G.stitch_canvas(o, positions, sub, background=zoomed.to(o[0].device)) for o in out]
@@ -392,6 +393,9 @@ def main():
     ap.add_argument("--grid-resample", type=int, default=1, help="inpaint_resample_times for --workload grid")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="--workload grid: keep the reference's barrier between the stages")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="grid: run the stage groups of a wave one after the other (default: the light stage-1/2 groups "
+                         "on a side stream beside stage 3)")
     ap.add_argument("--grid-batch", type=int, default=1,
                     help="--workload grid: patches of a wave per sample() call in stages 1-2 (1 = the reference's way)")
     args = ap.parse_args()

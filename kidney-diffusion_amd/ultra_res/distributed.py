@@ -126,20 +126,66 @@ def _all_gather_patches(mine: torch.Tensor, counts: List[int], group) -> List[to
     return _all_gather_start(mine, counts, group)()
 
 
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _run_stage_groups(sample_fn: Callable, groups, results: Dict[int, List[torch.Tensor]], device) -> None:
+    """Runs the (stage, tasks, ...) groups of one generalised wave on this rank.  With a CUDA `device` and more than
+    one group: the first (heaviest) on the calling thread and stream, the others from a second thread on a side
+    stream (torch's current stream is per thread), both drained before the results are used."""
+    if device is None or len(groups) < 2 or torch.device(device).type != "cuda":
+        for g in groups:
+            results[g[0]] = list(sample_fn(*g))
+        return
+    import threading
+
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    side = _side_streams.get(key)
+    if side is None:
+        side = _side_streams[key] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))   # inputs assembled on the caller's stream
+    errors = []
+
+    def light():
+        try:
+            with torch.cuda.device(dev), torch.cuda.stream(side):
+                for g in groups[1:]:
+                    results[g[0]] = list(sample_fn(*g))
+            side.synchronize()
+        except BaseException as e:   # re-raised on the calling thread
+            errors.append(e)
+
+    th = threading.Thread(target=light, name="kd-grid-light-stages")
+    th.start()
+    try:
+        results[groups[0][0]] = list(sample_fn(*groups[0]))
+    finally:
+        th.join()
+    if errors:
+        raise errors[0]
+    torch.cuda.current_stream(dev).wait_stream(side)
+
+
 def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence[Sequence[G.Pos]],
                  cond_images: Sequence[Optional[torch.Tensor]], overlap: float,
                  num_patches_width: Sequence[int], orientations: Optional[Sequence[int]] = None,
                  lowres: Optional[Sequence[Optional[torch.Tensor]]] = None,
                  patch_width: Optional[int] = None, group=None,
                  device: Optional[torch.device] = None, pipeline: bool = True,
-                 stage_cost: Optional[Dict[int, float]] = None) -> List[List[torch.Tensor]]:
+                 stage_cost: Optional[Dict[int, float]] = None,
+                 overlap_stages: Optional[torch.device] = None) -> List[List[torch.Tensor]]:
     """Runs `stages` (e.g. (1,2,3)) over one or more canvases and returns, on every rank,
     `out[c][idx]` = (3,S,S) final-stage patch `idx` of canvas c (index order of patch_pos[c]).
 
     cond_images[c]: (N_c, Cc, 1024, 1024) or None; lowres[c]: optional (N_c,3,s,s) start images for
     the first stage in `stages` (the reference's --ignore_unet_1 path, sample_ultra_res.py:417-420).
     pipeline=False keeps the reference's barrier between the stages (same results: every task sees the same
-    inputs in either order)."""
+    inputs in either order).  overlap_stages=<the sampler's CUDA device> (pipelined waves): the stage groups of one generalised wave
+    on this rank are independent, so the heaviest (stage 3: kernels that fill the chip) runs on the caller's stream
+    while the lighter ones (batch-1 stage-1/2 passes: weight-bandwidth and launch-latency bound, most of the chip
+    idle) run from a second host thread on a side stream; same results, the wave ends when both are done.  The
+    sample_fn must have been warmed (plans built, graphs captured) and keep per-stage state apart."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     ncanvas = len(patch_pos)
@@ -156,6 +202,7 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
         mine = parts[rank]
         wave_stages = sorted({t[0] for t in wave})
         results: Dict[int, List[torch.Tensor]] = {}
+        groups = []
         for st in sorted({t[0] for t in mine}, reverse=True):   # heaviest stage first
             S = G.PATCH_SIZES[st]
             tasks = [t for t in mine if t[0] == st]
@@ -171,7 +218,8 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
                 conds.append(cond)
                 ips.append(ip)
                 ims.append(im)
-            results[st] = list(sample_fn(st, [(c, i, j) for (_, c, i, j) in tasks], lows, conds, ips, ims))
+            groups.append((st, [(c, i, j) for (_, c, i, j) in tasks], lows, conds, ips, ims))
+        _run_stage_groups(sample_fn, groups, results, overlap_stages)
         # one all-gather per stage present in the wave, all in flight together
         pending = []
         for st in wave_stages:

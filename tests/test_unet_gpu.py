@@ -497,3 +497,32 @@ def test_qk_norm_attention_variants_match_oracle(device, mode):
         ref = ou(x, t, text_embeds=text, text_mask=mask, cond_images=labels)
     got = pu(dv(x), dv(t), text_embeds=dv(text), text_mask=dv(mask), cond_images=dv(labels))
     assert H.rel_l2(got, ref) < FWD_REL_L2, H.rel_l2(got, ref)
+
+
+def test_patch_grid_overlapped_stage_groups_equal_the_sequential_run(device):
+    """sample_grids(overlap_stages=device): inside a generalised wave the stage-2 group runs on the caller's stream
+    while the stage-1 group runs from a second host thread on a side stream.  Same tasks, same inputs, same seeds:
+    the canvas must equal the sequential run bit for bit (two stages, 3x3 grid, pipelined waves)."""
+    from ultra_res import distributed as D
+    from ultra_res import grid as G
+
+    _, pim = _imagen_pair(device, ["small2", "small2"], (16, 32), (3, 4), ("noise", "v"))   # both stages take cond images
+    n = 3
+    pos = [(i, j) for i in range(n) for j in range(n)]
+    g = torch.Generator().manual_seed(11)
+    cond = torch.rand(n * n, 3, 32, 32, generator=g).to(device)
+    old = dict(G.PATCH_SIZES)
+    G.PATCH_SIZES.update({1: 16, 2: 32})
+    try:
+        fn = D.imagen_sample_fn(lambda stage: pim, 2, device, seed=7)
+        fn.warm({1: [1], 2: [1]}, cond[0])
+        kw = dict(stages=(1, 2), patch_pos=[pos], cond_images=[cond], overlap=0.25, num_patches_width=[n],
+                  orientations=[-1], device=device)
+        seq = D.sample_grids(fn, **kw)[0]
+        par = D.sample_grids(fn, overlap_stages=device, **kw)[0]
+    finally:
+        G.PATCH_SIZES.clear()
+        G.PATCH_SIZES.update(old)
+    assert len(seq) == len(par) == n * n
+    for a, b in zip(seq, par):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
