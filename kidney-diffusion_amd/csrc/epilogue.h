@@ -39,9 +39,10 @@ __device__ __forceinline__ float ep_act(float v, int act) {
 // scratch: 1024 floats of LDS owned by this wave for the duration of the call.  Every lane of the wave must call.
 // STATS: returns in (s1, s2) this lane's (sum, sum of squares) over its 16 output values in fp64 - the caller
 // reduces them (lanes with equal lane & 7 hold the same 4 columns; columns 0-15 live in lanes with (lane & 4) == 0).
-template <bool STATS>
-__device__ __forceinline__ void store_tile32_wide(const ep_f32x16& acc, float* scratch, const WideEpilogue& e, double& s1,
-                                                  double& s2) {
+// res_of(i, row, c4, live): the residual vector of this lane's i-th row (row = (lane >> 3) + 8 i, columns c4 .. c4 + 3).
+template <bool STATS, class ResFn>
+__device__ __forceinline__ void store_tile32_wide_impl(const ep_f32x16& acc, float* scratch, const WideEpilogue& e, double& s1,
+                                                       double& s2, ResFn res_of) {
   const int lane = threadIdx.x & 63;
   const int col = lane & 31, rbase = 4 * (lane >> 5);
 #pragma unroll
@@ -65,7 +66,7 @@ __device__ __forceinline__ void store_tile32_wide(const ep_f32x16& acc, float* s
         for (int k = 0; k < 4; ++k) v[k] = ep_act(v[k], e.act);
       }
       if (e.gate_src) v += *(const ep_f32x4*)(e.gate_src + row * e.ldgs + c4) * gv;
-      if (e.res) v += *(const ep_f32x4*)(e.res + row * e.ldres + c4);
+      v += res_of(i, row, c4);
       *(ep_f32x4*)(e.y + row * e.ldy + c4) = v;
       if (STATS) {
 #pragma unroll
@@ -78,6 +79,33 @@ __device__ __forceinline__ void store_tile32_wide(const ep_f32x16& acc, float* s
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch reads done before the next tile's writes
+}
+
+template <bool STATS>
+__device__ __forceinline__ void store_tile32_wide(const ep_f32x16& acc, float* scratch, const WideEpilogue& e, double& s1,
+                                                  double& s2) {
+  store_tile32_wide_impl<STATS>(acc, scratch, e, s1, s2, [&](int, int row, int c4) {
+    const ep_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return e.res ? *(const ep_f32x4*)(e.res + row * e.ldres + c4) : z;
+  });
+}
+
+// The residual vectors of a tile requested ahead of its accumulation (the k = 15 init conv runs 345 MFMAs between the
+// request and the use): rp[i] = res[row (lane >> 3) + 8 i][c4 .. c4 + 3], zeros where e.res is null or outside the tile
+__device__ __forceinline__ void wide_prefetch_res(const WideEpilogue& e, ep_f32x4 (&rp)[4]) {
+  const int lane = threadIdx.x & 63;
+  const int rq = lane >> 3, c4 = (lane & 7) * 4;
+  const ep_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = rq + 8 * i;
+    rp[i] = (e.res && c4 < e.cols && row < e.rows) ? *(const ep_f32x4*)(e.res + row * e.ldres + c4) : z;
+  }
+}
+template <bool STATS>
+__device__ __forceinline__ void store_tile32_wide_pre(const ep_f32x16& acc, float* scratch, const WideEpilogue& e,
+                                                      const ep_f32x4 (&rp)[4], double& s1, double& s2) {
+  store_tile32_wide_impl<STATS>(acc, scratch, e, s1, s2, [&](int i, int, int) { return rp[i]; });
 }
 
 // folds the (s1, s2) of store_tile32_wide over the wave: afterwards lanes 0 and 4 hold the sums of columns 0-15 and

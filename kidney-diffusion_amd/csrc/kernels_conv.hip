@@ -516,7 +516,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(ConvP
     __syncthreads();
   }
 
-  if (p.out_mode == OUT_NHWC && (!p.gate_src || (((p.Ho * p.Wo) & 31) == 0 && !p.res && p.act == ACT_NONE)))
+  if (p.out_mode == OUT_NHWC && p.wide_epilogue && (!p.gate_src || ((p.Ho * p.Wo) & 31) == 0)) {
+    static_assert(LDS_FLOATS >= WAVES_M * WAVES_N * 1024, "the 16-byte epilogue needs 4 KB of LDS per wave");
+    if (p.seg_partial) store_tile_regs_wide<BM, BN, WAVES_M, WAVES_N, true>(p, lds, acc, m0, n0, M);
+    else store_tile_regs_wide<BM, BN, WAVES_M, WAVES_N, false>(p, lds, acc, m0, n0, M);
+  } else if (p.out_mode == OUT_NHWC && (!p.gate_src || (((p.Ho * p.Wo) & 31) == 0 && !p.res && p.act == ACT_NONE)))
     store_tile_regs<BM, BN, WAVES_M, WAVES_N>(p, acc, m0, n0, M);
   else
     store_tile<BM, BN, WAVES_M, WAVES_N>(p, lds, acc, m0, n0, M);
@@ -741,7 +745,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv_buf_kernel(C
     q.bias = nullptr; q.act = ACT_NONE; q.res = nullptr; q.gate_src = nullptr; q.gate = nullptr;
     q.out_mode = OUT_NHWC; q.ldy = p.Cout; q.yoff = 0;
     q.y = p.partial + (int64_t)blockIdx.z * M * p.Cout;
-    store_tile_regs<BM, BN, WAVES_M, WAVES_N>(q, acc, m0, n0, M);
+    q.seg_partial = nullptr;
+    if (p.wide_epilogue) store_tile_regs_wide<BM, BN, WAVES_M, WAVES_N, false>(q, lds, acc, m0, n0, M);
+    else store_tile_regs<BM, BN, WAVES_M, WAVES_N>(q, acc, m0, n0, M);
   } else if (p.out_mode == OUT_NHWC && p.wide_epilogue && (!p.gate_src || (hw & 31) == 0)) {
     if (p.seg_partial) store_tile_regs_wide<BM, BN, WAVES_M, WAVES_N, true>(p, lds, acc, m0, n0, M);
     else store_tile_regs_wide<BM, BN, WAVES_M, WAVES_N, false>(p, lds, acc, m0, n0, M);
@@ -900,6 +906,8 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     KD_REQUIRE(((uintptr_t)p.partial & 15) == 0, "split-K partial buffer must be 16-B aligned");
     ConvParams q = p;
     q.ksplit = ks;
+    q.wide_epilogue = p.Cout % 4 == 0 &&   // the raw partial tiles [z][M][Cout] with 16-byte stores
+                      !(getenv("KD_CONV_WIDE") && atoi(getenv("KD_CONV_WIDE")) == 0);
     if (M <= 64) {
       // an 8x8 map of a batch-1 patch: 64-row tiles (a 128-row tile would spend half its MFMAs on padding and
       // these launches, K up to 9 x 3072, were bound by exactly that: 124 us for 226 MB of weights), 128 columns
@@ -922,20 +930,21 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     return launch_conv_fast(q, M, s);
   }
   if (fast) return launch_conv_fast(p, M, s);
-  if (p.wz_rows > 0) {
-    KD_REQUIRE(false, "batched GEMM needs the buffer-load fast path (Cin % 32 == 0, Cout > 32)");
-  } else if (p.Cout <= 32) {
+  KD_REQUIRE(p.wz_rows == 0, "batched GEMM needs the buffer-load fast path (Cin % 32 == 0, Cout > 32)");
+  ConvParams g = p;
+  g.wide_epilogue = p.out_mode == OUT_NHWC && conv_wide_ok(p) && !(getenv("KD_CONV_WIDE") && atoi(getenv("KD_CONV_WIDE")) == 0);
+  if (p.Cout <= 32) {
     dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 31) / 32);
-    hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, g);
   } else if (p.Cout <= 64) {
     dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 63) / 64);
-    hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2>), grid, dim3(256), 0, s, g);
   } else if (M <= 64) {
     dim3 grid((unsigned)((M + 63) / 64), (p.Cout + 127) / 128);
-    hipLaunchKernelGGL((conv_igemm_kernel<64, 128, 1, 4>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<64, 128, 1, 4>), grid, dim3(256), 0, s, g);
   } else {
     dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 127) / 128);
-    hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, g);
   }
   KD_HIP_CHECK(hipGetLastError());
   return 0;

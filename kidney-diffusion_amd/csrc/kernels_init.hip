@@ -148,8 +148,7 @@ __global__ __launch_bounds__(512, 1) void init_conv_kernel(InitConvParams p) {
       // lane (epilogue.h): 4 stores + 4 residual loads per tile instead of 16 + 16
       const int64_t pix0 = ((int64_t)b * S + y0 + row) * S + x0;
       const int64_t chunk = ((int64_t)(y0 + row) * S + x0) >> 5;   // 32-pixel run index inside the image
-      auto finish = [&](const f32x16& acc, int ch0, int nreal) {   // channels ch0 + [0, 32) of the output
-        if ((p.abl & 2) && acc[0] != 12345.678f) return;
+      auto tile_of = [&](int ch0, int nreal) {   // channels ch0 + [0, 32) of the output
         WideEpilogue e;
         e.y = p.y + pix0 * p.ldy + ch0;
         e.ldy = p.ldy;
@@ -162,9 +161,21 @@ __global__ __launch_bounds__(512, 1) void init_conv_kernel(InitConvParams p) {
         e.rows = 32;
         e.cols = nreal < 32 ? nreal : 32;
         e.act = ACT_NONE;
+        return e;
+      };
+      // the step-invariant share (residual) of all four tiles of this row, requested before the first MFMA: 64
+      // registers that arrive under the convolutions instead of 4 dependent loads in front of every tile's stores
+      ep_f32x4 rp15[4], rp7[4], rp3[N3T][4];
+      wide_prefetch_res(tile_of(p.n3 + p.n7, p.n15), rp15);
+      wide_prefetch_res(tile_of(p.n3, p.n7), rp7);
+#pragma unroll
+      for (int j = 0; j < N3T; ++j) wide_prefetch_res(tile_of(j * 32, p.n3 - j * 32), rp3[j]);
+      auto finish = [&](const f32x16& acc, int ch0, int nreal, const ep_f32x4 (&rp)[4]) {
+        if ((p.abl & 2) && acc[0] != 12345.678f) return;
+        const WideEpilogue e = tile_of(ch0, nreal);
         double s1, s2;
         if (p.seg) {   // wave-uniform
-          store_tile32_wide<true>(acc, scratch, e, s1, s2);
+          store_tile32_wide_pre<true>(acc, scratch, e, rp, s1, s2);
           reduce_tile32_stats(s1, s2);
           const int n = ch0 + 4 * (lane & 7);   // lane 0: columns 0-15, lane 4: columns 16-31
           if ((lane & ~4) == 0 && 4 * (lane & 7) < nreal) {
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(512, 1) void init_conv_kernel(InitConvParams p) {
             o[1] = s2;
           }
         } else {
-          store_tile32_wide<false>(acc, scratch, e, s1, s2);
+          store_tile32_wide_pre<false>(acc, scratch, e, rp, s1, s2);
         }
       };
       // k = 15: window rows row .. row + 14, columns frow .. frow + 14.  Two accumulator chains (even / odd k pairs,
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(512, 1) void init_conv_kernel(InitConvParams p) {
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) a15[r] += b15[r];
-          finish(a15, p.n3 + p.n7, p.n15);
+          finish(a15, p.n3 + p.n7, p.n15, rp15);
         }
       };
       // k = 7: the centred 7 x 7 window starts 4 rows / 4 columns into the 15 x 15 one
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(512, 1) void init_conv_kernel(InitConvParams p) {
             pa += IC_PW * 3;
             pb += IC_RUN7;
           }
-          finish(a7, p.n3, p.n7);
+          finish(a7, p.n3, p.n7, rp7);
         }
       };
       // k = 3: starts 6 rows / 6 columns in
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(512, 1) void init_conv_kernel(InitConvParams p) {
 #pragma unroll
             for (int kk = 0; kk < IC_RUN3 / 2; ++kk)
               a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[ky * IC_PW * 3 + 2 * kk], pb[ky * IC_RUN3 + 2 * kk], a3, 0, 0, 0);
-          finish(a3, j * 32, p.n3 - j * 32);
+          finish(a3, j * 32, p.n3 - j * 32, rp3[j]);
         }
       };
       // the two waves of a SIMD (w, w + 4) take the convs in opposite order: one's epilogues (LDS turn, residual
