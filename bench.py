@@ -98,8 +98,13 @@ def kernel_classes(lib, handle, iters=3):
         elif m:  # transforms move 5x the map: read 1x / write 4x (in), read 4x / write 1x (out)
             ch = int(m.group(3)) if m.group(1) == "wino_in" else int(m.group(4))
             add("wino_in_kernel + wino_out_kernel (Winograd transforms)", us, nbytes=20.0 * int(m.group(2)) * ch)
-        elif label.startswith("conv") or label.startswith("skinny"):
-            add("other conv / GEMM launches (1x1, 2x2-s2, init, final, skinny)", us, 2.0 * macs, 2.0 * (mfma or macs))
+        elif label.startswith("skinny"):   # M <= 32 rows: the weights are read once, nothing is reused
+            mk = re.match(r"skinny M(\d+) K(\d+) N(\d+)", label)
+            add("linear_skinny_mfma_kernel (time MLPs, GlobalContext FCs: weight-bandwidth / latency bound)", us,
+                nbytes=4.0 * int(mk.group(2)) * int(mk.group(3)) if mk else 0.0)
+        elif label.startswith("conv") or label.startswith("init conv"):
+            add("conv_buf_kernel / conv_igemm_kernel / init_conv_kernel: 1x1, 2x2-s2, init and final convs, token GEMMs", us,
+                2.0 * macs, 2.0 * (mfma or macs))
         else:
             add("GroupNorm, LayerNorm, attention core, GlobalContext, concat, gate (HBM-bound)", us)
     out = []
