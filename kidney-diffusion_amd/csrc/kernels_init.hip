@@ -81,7 +81,6 @@ struct InitConvParams {
   float* y;            // NHWC, row stride ldy, first channel at y
   double* seg;         // GroupNorm partials [B][(n3+n7+n15)/16][S*S/32][2] or nullptr
   int B, S, ldy, n3, n7, n15;
-  int abl;   // timing ablations (KD_INIT_ABL, experiments only): 1 no k=15 MFMAs, 2 no epilogue, 4 no halo fetch
 };
 
 template <int N3T>   // 32-row tiles of the k = 3 conv (1 or 2)
@@ -139,7 +138,7 @@ __global__ __launch_bounds__(512, 1) void init_conv_kernel(InitConvParams p) {
       }
     }
     __syncthreads();
-    if (tile + (int)gridDim.x < ntiles && !(p.abl & 4)) fetch(tile + gridDim.x);
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
 
     {   // wave w: row w of the tile (8 waves, two per SIMD); one conv after the other, each finished (stored) before
         // the next starts, so that only one set of accumulators is live
@@ -171,7 +170,6 @@ __global__ __launch_bounds__(512, 1) void init_conv_kernel(InitConvParams p) {
 #pragma unroll
       for (int j = 0; j < N3T; ++j) wide_prefetch_res(tile_of(j * 32, p.n3 - j * 32), rp3[j]);
       auto finish = [&](const f32x16& acc, int ch0, int nreal, const ep_f32x4 (&rp)[4]) {
-        if ((p.abl & 2) && acc[0] != 12345.678f) return;
         const WideEpilogue e = tile_of(ch0, nreal);
         double s1, s2;
         if (p.seg) {   // wave-uniform
@@ -200,7 +198,7 @@ __global__ __launch_bounds__(512, 1) void init_conv_kernel(InitConvParams p) {
             a15[r] = 0.f;
             b15[r] = 0.f;
           }
-          for (int ky = 0; ky < ((p.abl & 1) ? 0 : 15); ++ky) {
+          for (int ky = 0; ky < 15; ++ky) {
 #pragma unroll
             for (int kk = 0; kk + 1 < IC_RUN15 / 2; kk += 2) {
               a15 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * kk], pb[2 * kk], a15, 0, 0, 0);
@@ -271,8 +269,7 @@ int launch_init_conv(const float* x, const float* wp, const float* bias, const f
   KD_REQUIRE(ldy % 4 == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)res & 15) == 0 && ((uintptr_t)bias & 15) == 0,
              "init conv kernel: 16-byte aligned output / residual / bias rows");
   KD_REQUIRE(!seg || ((n3 % 16) == 0 && (n7 % 16) == 0 && (n15 % 16) == 0), "init conv partials: 16-channel segments");
-  static const int abl = getenv("KD_INIT_ABL") ? atoi(getenv("KD_INIT_ABL")) : 0;
-  InitConvParams p{x, wp, bias, res, y, seg, B, S, ldy, n3, n7, n15, abl};
+  InitConvParams p{x, wp, bias, res, y, seg, B, S, ldy, n3, n7, n15};
   const size_t smem = (init_conv_weight_floats(n3, n7, n15) + IC_PATCH + IC_SCRATCH) * sizeof(float);
   const int ntiles = B * (S / IC_TW) * (S / IC_TH);
   static int cus = 0;
