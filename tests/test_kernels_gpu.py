@@ -218,6 +218,8 @@ def test_conv3x3_winograd_fused_matches_direct(lib, device, B, H, W, Cin, Cout, 
     (1, 16, 32, 68, 128, 1, False, True),     # 17 chunks: one steady trip of 12 + a guarded remainder of 5; every patch a border
     (1, 32, 32, 1056, 128, 8, True, False),   # affine table beyond 1024 channels (second half), 264 chunks
     (20, 64, 64, 32, 64, 8, False, True),     # 64-channel items: 320 items on 256 persistent workgroups
+    (1, 16, 16, 8, 128, 2, False, False),     # 128-channel items: two items, two chunks (shorter than the pipeline's prefetch)
+    (2, 16, 48, 12, 256, 1, True, True),      # three chunks, four slabs of 64 ... as two of 128; W = 3 patches
 ])
 def test_gn_conv3x3_winograd_fused_matches_torch(lib, device, B, H, W, Cin, Cout, G, film, res):
     """ResnetBlock `Block` = conv3x3(SiLU(FiLM(GroupNorm(x)))) with the activation applied to the raw patch in
