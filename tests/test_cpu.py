@@ -288,7 +288,7 @@ def test_kernels_with_counted_vmcnt_waits_use_no_scratch(tmp_path):
     """conv_buf_kernel and wino_fused_kernel pace their LDS-DMA pipelines with counted `s_waitcnt vmcnt(N)`.
     A register spill would add scratch loads / stores to the same counter and let a barrier pass before the
     DMA data has landed (seen once in an experiment: wrong results AND 3x slower).  hipcc reports spills
-    only on request, so ask: every kernel of the two files must have ScratchSize 0 and no spilled VGPRs."""
+    only on request, so ask: every kernel of these files must have ScratchSize 0 and no spilled VGPRs."""
     import shutil
     import subprocess
 
@@ -296,10 +296,18 @@ def test_kernels_with_counted_vmcnt_waits_use_no_scratch(tmp_path):
     if not Path(hipcc).exists():
         pytest.skip("hipcc not available")
     csrc = ROOT / "kidney-diffusion_amd" / "csrc"
-    for src in ("kernels_conv.hip", "kernels_wino_fused.hip", "kernels_wino_fused128.hip"):
-        out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", str(csrc / src),
-                              f"-I{csrc}", f"-I{ROOT / 'include'}", "-Rpass-analysis=kernel-resource-usage",
-                              "-o", str(tmp_path / "x.o")], capture_output=True, text=True, timeout=900)
+    srcs = ("kernels_conv.hip", "kernels_wino_fused.hip", "kernels_wino_fused128.hip", "kernels_init.hip")
+
+    def compile_one(src):
+        return subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", str(csrc / src),
+                               f"-I{csrc}", f"-I{ROOT / 'include'}", "-Rpass-analysis=kernel-resource-usage",
+                               "-o", str(tmp_path / (src + ".o"))], capture_output=True, text=True, timeout=900)
+
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=4) as pool:   # the files compile side by side (about a minute each)
+        outs = list(pool.map(compile_one, srcs))
+    for src, out in zip(srcs, outs):
         assert out.returncode == 0, out.stderr[-2000:]
         scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
         spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", out.stderr)]
