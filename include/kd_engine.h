@@ -34,6 +34,10 @@ extern "C" {
 
 const char* kd_last_error(void);
 int kd_version(void);
+/* sha256 prefix (16 hex digits) of the sources this binary was compiled from (csrc/build_id.py); a build with
+ * EXTRA flags carries the suffix "+experiment".  The Python binding refuses a library whose id differs from
+ * the sources lying next to it. */
+const char* kd_build_id(void);
 
 /* ------------------------------------------------------------------------------------------
  * UNet.  Replaces `Unet(...)` construction + `Unet.forward` of imagen-pytorch as configured at

@@ -92,6 +92,7 @@ class kd_sample_args_t(C.Structure):
 SIGNATURES = {
     "kd_last_error": (C.c_char_p, []),
     "kd_version": (C.c_int, []),
+    "kd_build_id": (C.c_char_p, []),
     "kd_unet_create": (C.c_int, [C.POINTER(kd_unet_config_t), C.POINTER(kd_param_t), C.c_int,
                                  C.POINTER(C.c_void_p)]),
     "kd_unet_destroy": (None, [C.c_void_p]),
@@ -148,8 +149,38 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here means the .so is stale
         fn.restype = restype
         fn.argtypes = argtypes
+    _check_build_id(lib, path)
     _lib = lib
     return lib
+
+
+def source_build_id():
+    """Hash of the sources next to the package (csrc/build_id.py), or None when they are not there."""
+    script = Path(__file__).resolve().parent.parent / "csrc" / "build_id.py"
+    if not script.exists():
+        return None
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_kd_build_id", script)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build_id()
+
+
+def _check_build_id(lib, path):
+    """A library built from other sources than the ones lying next to it is refused (a stale binary once
+    passed the GPU tests for a commit it did not contain).  KD_ENGINE_LIB (an explicit foreign library) and
+    a source-less install skip the comparison."""
+    if "KD_ENGINE_LIB" in os.environ:
+        return
+    want = source_build_id()
+    if want is None:
+        return
+    have = lib.kd_build_id().decode()
+    if have.split("+")[0] != want:
+        raise EngineUnavailable(
+            f"{path} was built from other sources (library build id {have}, sources {want}): "
+            "rebuild with `make -C kidney-diffusion_amd/csrc`.")
 
 
 def check(rc: int):

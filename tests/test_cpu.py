@@ -271,6 +271,58 @@ def test_library_loads_and_exports_every_symbol_the_header_declares():
     assert lib.kd_quantile_workspace_bytes(4) == 4 * 16 + 4 * 4 * 256 * 4
 
 
+def test_library_build_id_matches_the_sources_and_the_build_is_up_to_date():
+    """The binary the tests load must be the one HEAD's sources build: kd_build_id() (sha256 of csrc/ + include/
+    baked in at compile time) equals the hash of the sources on disk, `make -q` has nothing to do, and a
+    library of another id is refused by the binding."""
+    import shutil
+    import subprocess
+
+    from imagen_pytorch import _engine as E
+
+    lib = E.load()
+    have = lib.kd_build_id().decode()
+    assert have.split("+")[0] == E.source_build_id(), "libkd_engine.so is stale: rebuild (make -C kidney-diffusion_amd/csrc)"
+
+    class Fake:
+        def kd_build_id(self):
+            return b"0123456789abcdef"
+
+    with pytest.raises(E.EngineUnavailable, match="built from other sources"):
+        E._check_build_id(Fake(), "fake.so")
+    if shutil.which("make") and Path("/opt/rocm/bin/hipcc").exists():
+        csrc = ROOT / "kidney-diffusion_amd" / "csrc"
+        assert subprocess.run(["make", "-C", str(csrc), "-q"]).returncode == 0, "objects older than their sources"
+
+
+def test_makefile_tracks_header_dependencies(tmp_path):
+    """Round 2 shipped a library that predated its last header edit: the Makefile listed headers by hand and
+    missed epilogue.h.  Dependencies now come from the compiler (-MMD): touching epilogue.h must schedule
+    exactly its users (kernels_conv, kernels_init) + the link, and nothing when nothing changed."""
+    import os
+    import shutil
+    import subprocess
+
+    csrc = ROOT / "kidney-diffusion_amd" / "csrc"
+    build = ROOT / "kidney-diffusion_amd" / "build"
+    if not shutil.which("make") or not (build / "kernels_conv.d").exists():
+        pytest.skip("no in-tree build with dependency files")
+    hdr = csrc / "epilogue.h"
+    st = hdr.stat()
+
+    def planned():
+        out = subprocess.run(["make", "-C", str(csrc), "-n"], capture_output=True, text=True, check=True).stdout
+        return sorted(set(re.findall(r"-c (\S+\.hip)", out)))
+
+    assert planned() == []
+    try:
+        os.utime(hdr, None)
+        assert planned() == ["kernels_conv.hip", "kernels_init.hip"]
+    finally:
+        os.utime(hdr, ns=(st.st_atime_ns, st.st_mtime_ns))
+    assert planned() == []
+
+
 def test_philox_host_reference_is_standard_normal_and_keyed():
     from oracle.philox_ref import philox4x32_10, philox_normal
 
