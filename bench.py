@@ -12,6 +12,13 @@ the data path); rank 0 prints ONE JSON line.
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          # without WORLD_SIZE: spawns exactly that launcher itself (one child
+                                          # process per GPU, as the reference spawns its workers,
+                                          # sample_ultra_res.py:235-240) before any GPU call and relays the line
+
+The line of the headline workload also carries `rccl_ranks` (an all-reduce of ones over the process group: the
+number of ranks the collective library saw) and a nested `grid` object: patches/s of the 8x8 ultra-res grid
+(BASELINE configs[4], the >= 6x scaling target) for 1 and 3 canvases in flight, measured by the same command.
 """
 import argparse
 import ctypes as C
@@ -163,6 +170,7 @@ def host_cpu_info():
 
 
 CPU_BATCH = 8
+PARITY_TOL = 2e-5   # rel-L2 of one UNet forward, engine vs CPU fp32 oracle (the tolerance the full-size tests state)
 CPU_K0 = 125   # schedule index of the CPU baseline's first step: mid-schedule, where the UNet output drives x_(t-1)
 
 
@@ -191,15 +199,24 @@ def cpu_baseline(unet_product, timed_steps=3):
     kw = dict(noise_scheduler=sched, text_embeds=None, text_mask=None, cond_images=cond, lowres_cond_img=lowres,
               lowres_noise_times=t_lr, cond_scale=1.0, pred_objective="noise", dynamic_threshold=True)
     dts, first = [], None
+    preds = []
+    fwd = ou.forward_with_cond_scale
+
+    def fwd_keep(*a, **k):   # the UNet's output of every timed step (the parity check reads the first)
+        out = fwd(*a, **k)
+        preds.append(out)
+        return out
+
+    ou.forward_with_cond_scale = fwd_keep
     with torch.no_grad():
         for k in range(CPU_K0, CPU_K0 + 1 + timed_steps):
             t, tn = times[k]
             noise = torch.randn(x.shape, generator=g)
             t0 = time.perf_counter()
-            x_next, _ = oim.p_sample(ou, x, t, noise, t_next=tn, **kw)
+            x_next, x0 = oim.p_sample(ou, x, t, noise, t_next=tn, **kw)
             dts.append(time.perf_counter() - t0)
             if first is None:
-                first = dict(x=x, noise=noise, lowres=lowres, cond=cond, x_next=x_next)
+                first = dict(x=x, noise=noise, lowres=lowres, cond=cond, x_next=x_next, pred=preds[0], x0=x0)
             x = x_next
     timed = dts[1:]
     sec_per_step_b16 = (sum(timed) / len(timed)) * (BATCH / b)
@@ -239,12 +256,30 @@ def engine_parity(unet, first, device, lib):
     sa.d_noise_step = E.ptr(noise)   # index 0 of the [T*R, B, 3, S, S] layout
     sa.use_graph = 1
     E.check(lib.kd_sample_steps(h, C.byref(sc), C.byref(sa), E.ptr(x), 0, 1, E.current_stream()))
+    # what the step computed on the way (kd_sample_last): the UNet's eps-hat and the x0 estimate.  x_(t-1) itself is
+    # ~97 % the identical input x_t and the identical injected noise at this step (c ~ 0.025), so an error of the UNet
+    # would be attenuated ~50x in it: it is reported, but the asserted figures are those of eps-hat and x0-hat
+    pred, x0raw, thr = torch.empty_like(x), torch.empty_like(x), torch.empty(b, device=device)
+    for which, dst in ((0, pred), (1, x0raw), (2, thr)):
+        E.check(lib.kd_sample_last(h, which, E.ptr(dst), E.current_stream()))
     torch.cuda.synchronize()
-    got, ref = x.double().cpu(), first["x_next"].double()
-    return {"parity_rel_l2": float((got - ref).norm() / ref.norm()), "parity_max_abs": float((got - ref).abs().max()),
-            "parity_case": f"x_(t-1) of denoising step {CPU_K0} of {T_SCHED} at batch {b}: engine (default plan, Winograd convs) vs the CPU "
-                           "oracle on identical weights / x_T / conditioning / injected noise; stated tolerance of "
-                           "one UNet forward 2e-5 rel-L2 (tests/test_fullsize_gpu.py)"}
+    sth = thr[:, None, None, None]
+    x0 = torch.maximum(torch.minimum(x0raw, sth), -sth) / sth   # the clamp of ddpm_update_kernel, restated for the check
+
+    def rel(got, ref):
+        got, ref = got.double().cpu(), ref.double()
+        return float((got - ref).norm() / ref.norm())
+
+    out = {"parity_pred_rel_l2": rel(pred, first["pred"]), "parity_x0_rel_l2": rel(x0, first["x0"]),
+           "parity_xprev_rel_l2": rel(x, first["x_next"]),
+           "parity_pred_max_abs": float((pred.double().cpu() - first["pred"].double()).abs().max()),
+           "parity_tolerance_rel_l2": PARITY_TOL,
+           "parity_case": f"denoising step {CPU_K0} of {T_SCHED} at batch {b}: engine (default plan, Winograd convs) vs the CPU "
+                          "oracle on identical weights / x_t / conditioning / injected noise: rel-L2 of the UNet output "
+                          "eps-hat (pred), of the thresholded x0 estimate, and of x_(t-1) (the last is dominated by the shared "
+                          f"input and noise); asserted: pred and x0 < {PARITY_TOL:g} (tests/test_fullsize_gpu.py)"}
+    assert out["parity_pred_rel_l2"] < PARITY_TOL and out["parity_x0_rel_l2"] < PARITY_TOL, out
+    return out
 
 
 F_, T_ = False, True
@@ -257,11 +292,14 @@ ULTRA_UNETS = {  # train_ultra_res.py:29-60 (magnification level > 0: 3 conditio
 }
 
 
-def grid_workload(args, world, rank, device, distributed, barrier):
+def grid_workload(args, world, rank, device, distributed, barrier, canvases_list, T, steps, warmup):
     """BASELINE configs[4]: the 8x8 ultra-res outpainting grid of 1024-px patches through the 3-stage
     cascade (sample_ultra_res.py:264-448), sharded over the ranks by anti-diagonal waves with one
-    all-gather per wave (ultra_res/distributed.py).  One "step" = one full set of --canvases grids.
-    Strong scaling: the same 64 x canvases patches whatever N is."""
+    all-gather per wave (ultra_res/distributed.py).  One "step" = one full set of `canvases` grids.
+    Strong scaling: the same 64 x canvases patches whatever N is.  Returns, on rank 0, one result
+    dict per entry of canvases_list (the models are loaded and warmed once)."""
+    import torch.distributed as dist
+
     import imagen_pytorch as ip
     from ultra_res import distributed as D
     from ultra_res import grid as G
@@ -278,7 +316,6 @@ def grid_workload(args, world, rank, device, distributed, barrier):
         def forward(self, x, *a, **k):
             return x
 
-    T = args.grid_steps
     imagens = {}
 
     def load_imagen(stage):  # train_ultra_res.py:79-90 with one real UNet resident per Imagen
@@ -306,11 +343,8 @@ def grid_workload(args, world, rank, device, distributed, barrier):
     gb = {1: args.grid_batch, 2: args.grid_batch, 3: 1}
     sample_fn = D.imagen_sample_fn(load_imagen, args.grid_resample, device, use_graph=not args.no_graph, seed=1234,
                                    max_batch=gb)
-    ncan = args.canvases
     # finished patches live where the all-gather runs: HBM under RCCL, host memory in a gloo rehearsal
     # (gloo has no CUDA all_gather)
-    import torch.distributed as dist
-
     slab_dev = device if (not distributed or dist.get_backend() == "nccl") else torch.device("cpu")
 
     # deal order inside a generalised wave: batch-1 step times per stage (profiles/README.md) x this run's timesteps
@@ -328,23 +362,9 @@ def grid_workload(args, world, rank, device, distributed, barrier):
     # Warm-up on EVERY rank: load the three stages, build every plan shape the timed run can use (batch 1..grid_batch
     # in stages 1-2, batch 1 in stage 3) and capture their step graphs, so none of that lands in the timed region
     # (one patch through run() would only exercise rank 0 at batch 1).
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         sample_fn.warm({st: range(1, gb[st] + 1) for st in (1, 2, 3)}, cond[0])
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        canv = run(pos, cond, ncan)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    assert all(torch.isfinite(c).all() for c in canv)
-    if distributed:
-        import torch.distributed as dist
 
-        tmax = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    if rank != 0:
-        return
     from imagen_pytorch import _engine as E
 
     lib = E.load()
@@ -354,31 +374,77 @@ def grid_workload(args, world, rank, device, distributed, barrier):
         h = imagens[stage].unets[stage - 1].engine(1, size, device, with_text=False)
         flop_patch += 2.0 * lib.kd_unet_macs(h) * T * R         # direct convolutions, as the reference computes them
         issued_patch += 2.0 * lib.kd_unet_mfma_macs(h) * T * R  # what the plans put on the matrix cores (Winograd: 16/36)
-    patches = len(pos) * ncan * args.steps
-    waves = D.merged_waves([pos] * ncan, [G.choose_orientation(pos)] * ncan)
-    achieved = patches * issued_patch / elapsed / 1e12 / world
-    direct_equiv = patches * flop_patch / elapsed / 1e12 / world
-    print(json.dumps({
-        "metric": "patches/sec (ultra-res outpainting grid, 1024-px patches, 3-stage cascade)",
-        "value": patches / elapsed, "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[4]: {n}x{n} grid x {ncan} canvas(es), overlap 0.25, stages 64->256->1024 "
-                               f"(train_ultra_res.py:27-92), batch 1 per patch as the reference samples them, "
-                               f"timesteps ({T},{T},{T}) [reference default (1024,256,256)], inpaint_resample {R}, "
-                               f"stage-1/2 patches per sample() call <= {args.grid_batch}, random-init weights",
-                   "patches": len(pos) * ncan, "schedule_slots": D.schedule_length(waves, world),
-                   "pipeline_steps": len(D.stage_waves([pos] * ncan, [G.choose_orientation(pos)] * ncan, (1, 2, 3),
-                                                       not args.no_pipeline)),
-                   "parallelism": f"{world} rank(s): anti-diagonal waves of the three stages pipelined (a patch's "
-                                  "stage s starts once its stage s-1 and its neighbours' stage s are done), dealt "
-                                  "heaviest first with column affinity, one all-gather per stage and wave"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_PEAK_TFLOPS, "achieved_direct_equiv": direct_equiv, "traffic": None,
-                     "kernel": f"whole patch pipeline per GPU: {issued_patch / 1e12:.2f} TFLOP issued on the matrix cores per "
-                               f"patch ({flop_patch / 1e12:.2f} of direct-convolution work), over the wall clock (includes "
-                               "host-side inpaint-tensor assembly, all-gathers and idle wave slots)"},
-    }), flush=True)
+
+    results = []
+    for ncan in canvases_list:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            canv = run(pos, cond, ncan)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        assert all(torch.isfinite(c).all() for c in canv)
+        assert all(tuple(c.shape[-2:]) == (1024 + (n - 1) * geom.out_patch_dist,) * 2 for c in canv)
+        if distributed:
+            tmax = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        patches = len(pos) * ncan * steps
+        orient = [G.choose_orientation(pos)] * ncan
+        waves = D.merged_waves([pos] * ncan, orient)
+        achieved = patches * issued_patch / elapsed / 1e12 / world
+        direct_equiv = patches * flop_patch / elapsed / 1e12 / world
+        results.append({
+            "metric": "patches/sec (ultra-res outpainting grid, 1024-px patches, 3-stage cascade)",
+            "value": patches / elapsed, "unit": "patches/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed * 1e3 / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4]: {n}x{n} grid x {ncan} canvas(es), overlap 0.25, stages 64->256->1024 "
+                                   f"(train_ultra_res.py:27-92), batch 1 per patch as the reference samples them, "
+                                   f"timesteps ({T},{T},{T}) [reference default (1024,256,256)], inpaint_resample {R}, "
+                                   f"stage-1/2 patches per sample() call <= {args.grid_batch}, random-init weights",
+                       "canvases": ncan, "patches": len(pos) * ncan, "schedule_slots": D.schedule_length(waves, world),
+                       "pipeline_steps": len(D.stage_waves([pos] * ncan, orient, (1, 2, 3), not args.no_pipeline)),
+                       "parallelism": f"{world} rank(s): anti-diagonal waves of the three stages pipelined (a patch's "
+                                      "stage s starts once its stage s-1 and its neighbours' stage s are done), dealt "
+                                      "heaviest first with column affinity, one all-gather per stage and wave"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_PEAK_TFLOPS, "achieved_direct_equiv": direct_equiv, "traffic": None,
+                         "kernel": f"whole patch pipeline per GPU: {issued_patch / 1e12:.2f} TFLOP issued on the matrix cores per "
+                                   f"patch ({flop_patch / 1e12:.2f} of direct-convolution work), over the wall clock (includes "
+                                   "host-side inpaint-tensor assembly, all-gathers and idle wave slots)"},
+        })
+    return results if rank == 0 else None
+
+
+def rccl_ranks(distributed, backend, device):
+    """Number of ranks the collective library really connected: an all-reduce (sum) of ones."""
+    if not distributed:
+        return 1
+    import torch.distributed as dist
+
+    one = torch.ones(1, device=device if backend == "nccl" else "cpu", dtype=torch.int32)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(one.item())
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) through
+    torch.distributed.run as a CHILD process - before this process has made any GPU call - relay its output
+    (rank 0 prints the one JSON line) and exit with its code.  The reference does the same with
+    torch.multiprocessing (sample_ultra_res.py:235-240, 493)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -403,6 +469,9 @@ def main():
                          "on a side stream beside stage 3)")
     ap.add_argument("--grid-batch", type=int, default=1,
                     help="--workload grid: patches of a wave per sample() call in stages 1-2 (1 = the reference's way)")
+    ap.add_argument("--no-line-grid", action="store_true",
+                    help="sr: leave the nested `grid` object (8x8 grid patches/s for 1 and 3 canvases) out of the line")
+    ap.add_argument("--line-grid-steps", type=int, default=4, help="timesteps per stage of the nested grid runs")
     args = ap.parse_args()
     grid = args.workload == "grid"
     if args.steps is None:
@@ -410,6 +479,8 @@ def main():
     if args.warmup is None:
         args.warmup = 1 if grid else 3
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -433,8 +504,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    nranks = rccl_ranks(distributed, backend, device)
+    assert nranks == world, f"the collective backend connected {nranks} ranks, WORLD_SIZE is {world}"
+    coll = "none (single process)" if not distributed else ("nccl = RCCL" if backend == "nccl" else backend)
     if grid:
-        grid_workload(args, world, rank, device, distributed, barrier)
+        res = grid_workload(args, world, rank, device, distributed, barrier, [args.canvases], args.grid_steps, args.steps,
+                            args.warmup)
+        if rank == 0:
+            res[0].update(rccl_ranks=nranks, collective_backend=coll)
+            print(json.dumps(res[0]), flush=True)
         if distributed:
             dist.barrier()
             dist.destroy_process_group()
@@ -494,6 +572,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # the >= 6x target of BASELINE.json is patch throughput of the 8x8 grid: measured by the same command, after the
+    # timed region of the headline metric, on every rank (collective inside); 1 canvas (dependency bound 4.27x at 8
+    # ranks) and 3 canvases in flight (bound 6.2x)
+    grid_res = None
+    if not args.no_line_grid:
+        grid_res = grid_workload(args, world, rank, device, distributed, barrier, [1, 3], args.line_grid_steps, 1, 1)
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         dev_ms_per_step = dev_ms / args.steps
@@ -550,7 +635,18 @@ def main():
                        "batch_per_gpu": BATCH, "image_size": SIZE, "launches_per_step": launches,
                        "parallelism": f"{world} independent batch replicas (no data-path collective)"},
             "roofline": roof,
+            "rccl_ranks": nranks, "collective_backend": coll,
         }
+        if grid_res:
+            out["grid"] = {
+                "what": "BASELINE configs[4] measured by this same command after the headline region: patches/s of the 8x8 "
+                        "grid of 1024-px patches (3-stage cascade, strong scaling: the same patches whatever N is), for 1 canvas "
+                        "and for 3 canvases in flight; compare `patches_per_s` across the N = 1/2/4/8 lines",
+                "timesteps_per_stage": args.line_grid_steps,
+                **{f"canvases_{r['config']['canvases']}": {
+                    "patches_per_s": r["value"], "patches": r["config"]["patches"], "seconds": r["ms_per_step"] / 1e3,
+                    "schedule_slots": r["config"]["schedule_slots"], "pipeline_steps": r["config"]["pipeline_steps"],
+                    "mfma_frac_per_gpu": r["roofline"]["frac"]} for r in grid_res}}
         if world == 1 and not args.no_cpu_baseline:
             cpu, first = cpu_baseline(unet)
             out["cpu_baseline"] = cpu

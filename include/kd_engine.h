@@ -213,6 +213,11 @@ int kd_sample_steps(kd_unet_t* u, const kd_schedule_t* sched, const kd_sample_ar
 /* The tail of p_sample_loop on its own: clamp(-1,1), paste of the known inpaint pixels,
  * (x+1)/2.  kd_sample_loop == kd_sample_steps(0,T) + kd_sample_finalize. */
 int kd_sample_finalize(kd_unet_t* u, const kd_sample_args_t* args, float* d_img, void* stream);
+/* What the last executed iteration left behind (parity checks against p_mean_variance of the library):
+ * which = 0: the UNet's output eps-hat / v-hat after guidance [B,3,S,S]; 1: the x0 estimate before the
+ * threshold clamp [B,3,S,S]; 2: the per-sample dynamic thresholds max(1, quantile_p |x0|) [B].
+ * Stream-ordered device-to-device copy into d_out. */
+int kd_sample_last(kd_unet_t* u, int which, float* d_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Individual kernels, exported so that tests/ can check each one against the oracle through

@@ -112,6 +112,7 @@ SIGNATURES = {
     "kd_sample_steps": (C.c_int, [C.c_void_p, C.POINTER(kd_schedule_t), C.POINTER(kd_sample_args_t), C.c_void_p,
                                   C.c_int, C.c_int, C.c_void_p]),
     "kd_sample_finalize": (C.c_int, [C.c_void_p, C.POINTER(kd_sample_args_t), C.c_void_p, C.c_void_p]),
+    "kd_sample_last": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "kd_conv2d_nhwc": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]),
     "kd_conv3x3_winograd_nhwc": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     "kd_conv3x3_winograd_fused_nhwc": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),

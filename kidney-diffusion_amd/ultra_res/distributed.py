@@ -133,11 +133,24 @@ def _run_stage_groups(sample_fn: Callable, groups, results: Dict[int, List[torch
     """Runs the (stage, tasks, ...) groups of one generalised wave on this rank.  With a CUDA `device` and more than
     one group: the first (heaviest) on the calling thread and stream, the others from a second thread on a side
     stream (torch's current stream is per thread), both drained before the results are used."""
-    if device is None or len(groups) < 2 or torch.device(device).type != "cuda":
+    # A (stage, batch) the sampler has not run yet would build its plan and capture its graph on the side thread
+    # while this thread launches: such a wave runs its groups one after the other
+    is_warm = getattr(sample_fn, "is_warm", None)
+    cold = is_warm is not None and not all(is_warm(g[0], len(g[1])) for g in groups)
+    if device is None or len(groups) < 2 or torch.device(device).type != "cuda" or cold:
         for g in groups:
             results[g[0]] = list(sample_fn(*g))
         return
     import threading
+
+    # An unseeded sampler draws its Philox keys from torch's global CPU generator; two threads drawing from it would
+    # make the patch -> seed mapping depend on their interleaving.  The draws happen HERE, on the calling thread, in
+    # group order, and are handed in (torch.manual_seed then reproduces an overlapped run)
+    seeded = getattr(sample_fn, "takes_base_seed", False)
+    base = [int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if seeded else None for _ in groups]
+
+    def call(n):
+        return list(sample_fn(*groups[n], base_seed=base[n]) if seeded else sample_fn(*groups[n]))
 
     dev = torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -150,8 +163,8 @@ def _run_stage_groups(sample_fn: Callable, groups, results: Dict[int, List[torch
     def light():
         try:
             with torch.cuda.device(dev), torch.cuda.stream(side):
-                for g in groups[1:]:
-                    results[g[0]] = list(sample_fn(*g))
+                for n in range(1, len(groups)):
+                    results[groups[n][0]] = call(n)
             side.synchronize()
         except BaseException as e:   # re-raised on the calling thread
             errors.append(e)
@@ -159,7 +172,7 @@ def _run_stage_groups(sample_fn: Callable, groups, results: Dict[int, List[torch
     th = threading.Thread(target=light, name="kd-grid-light-stages")
     th.start()
     try:
-        results[groups[0][0]] = list(sample_fn(*groups[0]))
+        results[groups[0][0]] = call(0)
     finally:
         th.join()
     if errors:
@@ -275,7 +288,9 @@ def imagen_sample_fn(load_imagen: Callable, inpaint_resample: int, device: torch
     def stack(ts):
         return None if ts[0] is None else torch.stack([t.to(device) for t in ts])
 
-    def fn(stage, tasks, lows, conds, ips, ims):
+    warmed = set()   # (stage, batch) whose plan exists and whose step graph has been captured
+
+    def fn(stage, tasks, lows, conds, ips, ims, base_seed=None):
         if stage not in cache:
             cache[stage] = load_imagen(stage).to(device)
         imagen = cache[stage]
@@ -289,12 +304,20 @@ def imagen_sample_fn(load_imagen: Callable, inpaint_resample: int, device: torch
                       use_tqdm=False, device=device, use_graph=use_graph)
             if seed is not None:
                 kw["seed"] = seed + 7919 * stage + 104729 * hash(tasks[n0]) % (2 ** 31)
+            elif base_seed is not None:   # drawn by the scheduler on its own thread (overlapped stage groups)
+                kw["seed"] = (base_seed + n0) % (2 ** 31 - 1)
             # the reference passes the (possibly all-zero) inpaint tensors for every grid patch (:149-174)
             kw.update(inpaint_images=stack(ips[sl]), inpaint_masks=stack(ims[sl]),
                       inpaint_resample_times=inpaint_resample)
             out = imagen.sample(**kw)
+            warmed.add((stage, b))
             outs.extend(out[i] for i in range(b))
         return outs
+
+    def is_warm(stage, ntasks):
+        step = cap(stage)
+        sizes = {min(step, ntasks - n0) for n0 in range(0, ntasks, step)}
+        return all((stage, b) in warmed for b in sizes)
 
     def warm(batches_per_stage, cond_image=None):
         """Builds what a timed run must not pay for: for every stage its Imagen on the device and, for every batch
@@ -315,5 +338,7 @@ def imagen_sample_fn(load_imagen: Callable, inpaint_resample: int, device: torch
                     fn._force_batch = None
 
     fn.warm = warm
+    fn.is_warm = is_warm
+    fn.takes_base_seed = seed is None
     fn._force_batch = None
     return fn

@@ -194,6 +194,75 @@ def test_text_lowres_sr_unet_cond_dim_512_forward_matches_oracle(device):
         assert err < FWD_REL_L2, f"text+lowres SR UNet, drop={drop}: rel-L2 {err:.3e}"
 
 
+# ------------------------------------------------------------------------------- the remaining reference kwargs sets
+def _text_inputs(B):
+    text = torch.tensor([0.0, 0.5, 0.2]).reshape(1, 1, 3).repeat_interleave(B, dim=0)   # sample_cond.py:37
+    return text, torch.any(text != 0.0, dim=-1)
+
+
+def test_kumar_two_stage_unets_forward_match_oracle(device):
+    """train_kumar.py:27-81: base UNet with text + ONE conditioning channel, and an SR UNet that is built WITHOUT
+    text_embed_dim and gets its text conditioning from `Imagen(text_embed_dim=3)` re-casting it
+    (condition_on_text defaults to True); `timesteps=1000` as a scalar for both stages."""
+    import imagen_pytorch as ip
+
+    k1 = dict(dim=256, dim_mults=(1, 2, 3, 4), cond_dim=512, text_embed_dim=3, num_resnet_blocks=3,
+              layer_attns=(F_, T_, T_, T_), layer_cross_attns=(F_, T_, T_, T_), cond_images_channels=1)   # :29-38
+    k2 = dict(dim=128, cond_dim=512, dim_mults=(1, 2, 4, 8), num_resnet_blocks=2, memory_efficient=True,
+              layer_attns=(F_, F_, F_, T_), layer_cross_attns=(F_, F_, T_, T_), init_conv_to_final_conv_residual=True,
+              cond_images_channels=1)                                                                       # :41-51
+    oim = RS.Imagen([R.Unet(**k1), R.Unet(**k2)], image_sizes=(64, 256), timesteps=1000, text_embed_dim=3)
+    for n, u in enumerate(oim.unets):
+        H.randomize_(u, 91 + n).eval()
+    pim = ip.Imagen([ip.Unet(**k1), ip.Unet(**k2)], image_sizes=(64, 256), timesteps=1000, text_embed_dim=3,
+                    random_crop_sizes=(None, None))
+    pim.load_state_dict(oim.state_dict(), strict=True)   # same key set after the re-cast (text modules of the SR UNet)
+    pim = pim.to(device)
+    assert [s.num_timesteps for s in pim.noise_schedulers] == [1000, 1000]
+    assert pim.unets[1].cond_on_text and pim.unets[1].lowres_cond and not pim.unets[0].lowres_cond
+    dv = _dv(device)
+    g = torch.Generator().manual_seed(17)
+    for stage, (B, S) in enumerate(((2, 64), (1, 256))):
+        ou, pu = oim.unets[stage], pim.unets[stage]
+        x = torch.randn(B, 3, S, S, generator=g)
+        t = torch.randn(B, generator=g) * 2
+        cond = torch.rand(B, 1, 1024 if stage == 0 else S, 1024 if stage == 0 else S, generator=g)
+        lr = torch.randn(B, 3, S, S, generator=g) if stage else None
+        tl = torch.full((B,), -1.2) if stage else None
+        text, mask = _text_inputs(B)
+        with torch.no_grad():
+            ref = ou(x, t, text_embeds=text, text_mask=mask, cond_images=cond, lowres_cond_img=lr, lowres_noise_times=tl)
+        got = pu(dv(x), dv(t), text_embeds=dv(text), text_mask=dv(mask), cond_images=dv(cond), lowres_cond_img=dv(lr),
+                 lowres_noise_times=dv(tl))
+        err = H.rel_l2(got, ref)
+        assert err < FWD_REL_L2, f"kumar unet{stage + 1}: rel-L2 {err:.3e}"
+
+
+def test_segcond_unet3_blocks_2444_text_forward_matches_oracle(device):
+    """train.py:55-65: the third UNet of the seg-cond cascade - text, low-res, cond_dim 512, resnet blocks
+    (2, 4, 4, 4), FOUR conditioning channels - on the 256 crop it is trained on (train.py:92)."""
+    kw = dict(dim=128, cond_dim=512, dim_mults=(1, 2, 4, 8), num_resnet_blocks=(2, 4, 4, 4), memory_efficient=True,
+              layer_attns=False, layer_cross_attns=(F_, F_, F_, T_), init_conv_to_final_conv_residual=True,
+              cond_images_channels=4)
+    ou = H.randomize_(R.Unet(**kw, lowres_cond=True, cond_on_text=True, text_embed_dim=3), 95).eval()
+    pu = H.product_unet_like(ou).to(device)
+    B, S = 1, 256
+    g = torch.Generator().manual_seed(18)
+    x = torch.randn(B, 3, S, S, generator=g)
+    lr = torch.randn(B, 3, S, S, generator=g)
+    t = torch.randn(B, generator=g)
+    tl = torch.full((B,), -0.9)
+    text, mask = _text_inputs(B)
+    labels = torch.nn.functional.one_hot(torch.randint(0, 4, (B, S, S), generator=g), 4).permute(0, 3, 1, 2).float()
+    with torch.no_grad():
+        ref = ou(x, t, lowres_cond_img=lr, lowres_noise_times=tl, text_embeds=text, text_mask=mask, cond_images=labels)
+    dv = _dv(device)
+    got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), text_embeds=dv(text), text_mask=dv(mask),
+             cond_images=dv(labels))
+    err = H.rel_l2(got, ref)
+    assert err < FWD_REL_L2, f"train.py unet3: rel-L2 {err:.3e}"
+
+
 # ------------------------------------------------------------------------------- C4 stage 3 on a crop
 def test_unet3_on_a_256_crop_forward_matches_oracle(device):
     """train_ultra_res.py:51-60 at full dim on the 256x256 crop it is trained on (:88): 753.5 GFLOP."""
