@@ -82,6 +82,13 @@ typedef struct kd_unet_config {
    * 2 = learned per-channel `q_scale` / `k_scale` on the normalised q / k, * 8 (later versions; the host
    * switches to it when a checkpoint carries those keys).  Applies to self-, cross- and text-pooling attention. */
   int attn_qk_norm;
+  /* Structural forks between library versions, named by a checkpoint's keys / shapes:
+   * downsample_conv4 = 1: Downsample is `Conv2d(dim, dim_out, 4, stride 2, pad 1)` (parameters `<pre>.weight`
+   * [d_out, d, 4, 4], `<pre>.bias`) instead of pixel-unshuffle + 1x1 conv (`<pre>.1.weight` [d_out, 4 d, 1, 1]);
+   * mid_attn_plain = 1: mid_attn is a residual multi-query attention without a feed-forward (parameters
+   * `mid_attn.fn.fn.*`) instead of a TransformerBlock (`mid_attn.layers.0.{0,1}.*`). */
+  int downsample_conv4;
+  int mid_attn_plain;
 } kd_unet_config_t;
 
 /* One named parameter tensor of the UNet's state_dict (key WITHOUT the `unets.N.` prefix,
@@ -236,24 +243,20 @@ int kd_conv2d_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias,
  * only.  Needs even H, W; B*H*W/4 % 256 == 0; Cin % 32 == 0; Cout > 32. */
 int kd_conv3x3_winograd_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias, float* d_y,
                              int B, int H, int W, int Cin, int Cout, void* stream);
-/* The same convolution (+ optional residual d_res, NHWC with Cout channels, may be NULL) through the
- * fused Winograd kernel the plan uses for wide maps with few channels (kernels_wino_fused.hip).
- * Needs H % 16 == 0, W % 16 == 0, Cin % 4 == 0, Cout % 64 == 0; returns non-zero otherwise. */
-int kd_conv3x3_winograd_fused_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias,
-                                   const float* d_res, float* d_y, int B, int H, int W, int Cin,
-                                   int Cout, void* stream);
 /* ResnetBlock `Block` in one pass over x: conv3x3(SiLU(FiLM(GroupNorm_G(x)))) + bias (+ d_res), the form the
  * plan uses for those layers: statistics, a per-(image, channel) affine fold, and the fused Winograd kernel
  * with the activation applied to the raw patch in LDS (the activated map is never written).  d_scale_shift
- * ([B, 2 Cin] = [scale | shift]) and d_res may be NULL.  Shape rules of kd_conv3x3_winograd_fused_nhwc plus
- * Cin <= 2048, Cin % G == 0, (Cin / G) % 4 == 0, 16-byte aligned d_y / d_bias / d_res.  Runs the kernel the plan would
+ * ([B, 2 Cin] = [scale | shift]) and d_res (NHWC, Cout channels) may be NULL.  Needs H % 16 == 0, W % 16 == 0, Cin % 4 == 0,
+ * Cout % 64 == 0 (non-zero return otherwise), Cin <= 2048, Cin % G == 0, (Cin / G) % 4 == 0, 16-byte aligned d_y / d_bias / d_res.  Runs the kernel the plan would
  * pick for the shape: items of 16 x 8 pixels x 128 output channels where Cout % 128 == 0
  * (kernels_wino_fused128.hip), 16 x 16 pixels x 64 channels otherwise (kernels_wino_fused.hip). */
 int kd_gn_conv3x3_winograd_fused_nhwc(const float* d_x, const float* d_gamma, const float* d_beta,
                                       const float* d_scale_shift, const float* d_w_oihw,
                                       const float* d_bias, const float* d_res, float* d_y, int B, int H,
                                       int W, int Cin, int Cout, int G, float eps, float* d_out_stats,
-                                      void* stream);
+                                      int ldx, void* stream);
+/* (ldx: row stride of d_x in floats, >= Cin and a multiple of 4, 0 = dense: the plan hands this kernel channel-slice
+ * views of wider buffers - a skip tensor living in the concat it will join.) */
 /* (d_out_stats, may be NULL: [B, G, 2] = (mean, rstd) of y per image and group of Cout / G channels, reduced
  * from the partial sums the kernel's epilogue leaves for the GroupNorm of the next layer; needs
  * (Cout / G) % 16 == 0.) */

@@ -5,6 +5,15 @@
 #include <stdio.h>
 #include <string>
 
+// Experiment switches of the A/B measurements logged in profiles/README.md.  The product build compiles every switch
+// to its default (no behaviour depends on the ambient environment); `make EXTRA=-DKD_EXPERIMENT` builds a library
+// whose switches read the environment (scratch/experiment_switch.h; kd_build_id() then ends in "+experiment").
+#ifdef KD_EXPERIMENT
+#include "../../scratch/experiment_switch.h"
+#else
+constexpr int kd_switch(const char*, int dflt) { return dflt; }
+#endif
+
 namespace kd {
 
 void set_error(const std::string& msg);
@@ -100,8 +109,7 @@ int launch_wino_in(const float* x, int ldx, const float* stats, const float* gam
 int launch_wino_out(const float* D, const float* bias, const float* res, int ldres, float* y, int B, int H, int W,
                     int C, int64_t t0, int64_t nt, hipStream_t s);
 
-// ---- fused Winograd F(2x2,3x3) conv for wide maps with few channels (kernels_wino_fused.hip)
-// y = conv3x3(x) + bias (+ res): x dense NHWC [B][H][W][C] (already activated), y dense [B][H][W][N],
+// ---- fused Winograd F(2x2,3x3) conv + GroupNorm / FiLM / SiLU, items of 64 output channels (kernels_wino_fused.hip)
 // U from launch_wino_fused_pack (16*N*C floats).  wino_fused_ok states the shapes it takes.
 bool wino_fused_ok(int B, int H, int W, int C, int N);
 int launch_wino_fused_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s, float scale = 1.0f);
@@ -110,11 +118,7 @@ int launch_wino_fused_pack(const float* w_oihw, float* U, int O, int I, hipStrea
 // linear, so the factor left on the activated values moves into U)
 constexpr float WF_AB_SCALE = -1.4426950408889634f;
 constexpr float WF_U_SCALE = -0.6931471805599453f;
-int launch_wino_fused(const float* x, const float* U, const float* bias, const float* res, int ldres, float* y, int B,
-                      int H, int W, int C, int N, hipStream_t s);
-
-// The same with GroupNorm (+FiLM) + SiLU applied to x on the way in: ab = launch_gn_fold's per-(image, channel)
-// affine [B][C][2]; Cin <= 512.
+// y = conv3x3(SiLU(A x + B)) + bias (+ res): ab = launch_gn_fold's per-(image, channel) affine [B][C][2]; Cin <= 2048.
 int launch_gn_fold(const float* stats, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
                    float* ab, int B, int C, int G, hipStream_t s);
 // out_partial != nullptr: the kernel also leaves (sum, sum of squares) partials of y per (image, group of

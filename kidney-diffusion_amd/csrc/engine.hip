@@ -308,7 +308,7 @@ struct Builder {
     std::vector<SegPart> parts;
   };
   std::unordered_map<size_t, SegList> seg_of;   // key: T::at() - a slice and its buffer have different keys
-  const bool seg_on = !(getenv("KD_SEG_STATS") && atoi(getenv("KD_SEG_STATS")) == 0);
+  const bool seg_on = kd_switch("KD_SEG_STATS", 1) != 0;
   void drop_seg_block(size_t block) {
     for (auto it = seg_of.begin(); it != seg_of.end();) {
       if (it->second.block == block) {
@@ -660,9 +660,11 @@ struct Builder {
   }
 
   // TransformerBlock (depth 1): x = attn(x, ctx) + x ; x = ff(x) + x.
-  T transformer(const T& x, const std::string& pre, const T* ctx, const T* dst = nullptr) {
+  // plain: the residual attention of earlier library versions (cfg.mid_attn_plain): parameters `<pre>.fn.fn.*`,
+  // x = attn(x) + x and no feed-forward
+  T transformer(const T& x, const std::string& pre, const T* ctx, const T* dst = nullptr, bool plain = false) {
     int H = cfg.attn_heads, D = cfg.attn_dim_head, inner = H * D, dim = x.C;
-    std::string a = pre + ".layers.0.0", f = pre + ".layers.0.1";
+    std::string a = plain ? pre + ".fn.fn" : pre + ".layers.0.0", f = pre + ".layers.0.1";
     T xn = layernorm(x, P(a + ".norm.g", dim), nullptr);
     T q = linear(xn, P(a + ".to_q.weight", (int64_t)inner * dim), nullptr, inner);
     T kv = linear(xn, P(a + ".to_kv.weight", (int64_t)2 * D * dim), nullptr, 2 * D);
@@ -702,6 +704,7 @@ struct Builder {
     free(o);
     T x1 = layernorm(proj, P(a + ".to_out.1.g", dim), nullptr, &x);
     free(proj);
+    if (plain) return x1;
     // feed forward
     int hidden = dim * cfg.ff_mult_x2 / 2;
     T h0 = layernorm(x1, P(f + ".0.g", dim), nullptr);
@@ -757,7 +760,7 @@ struct Builder {
     // 1024 / all: 48.1 / 44.8 / 44.5 / 45.1 / 45.3 with the eight-wave kernel of round 1 (its Cin = 1024 launches lost
     // to the batched GEMMs), 37.59 / 37.36 / 37.40 at <= 512 / 1024 / 2048 with the persistent sixteen-wave kernel
     // (300 us against 265 + 40 + 21 for GEMM + transforms).  KD_FWINO_MAX_CIN moves it for experiments, read per plan
-    const int fw_max = getenv("KD_FWINO_MAX_CIN") ? atoi(getenv("KD_FWINO_MAX_CIN")) : 2048;
+    const int fw_max = kd_switch("KD_FWINO_MAX_CIN", 2048);
     if (cfg.conv_algo < 32 && x.C <= fw_max && fwino_ok(x, cout)) return false;
     if ((x.H & 1) || (x.W & 1) || x.C < min_cin || x.C % 32 || cout <= 32 || cout % 4) return false;
     const int64_t Mt = (int64_t)x.B * (x.H / 2) * (x.W / 2);
@@ -777,7 +780,7 @@ struct Builder {
     // KD_WINO_SLICE_MB caps V+D per slice.  Default: one slice - slices small enough to stay in the
     // 256 MB Infinity Cache were measured and are slower (56.5 ms/step unsliced, 59.3 at 96 MB,
     // 57.5 at 192 MB): the cache does not turn the V/D round trip into hits.
-    const int64_t slice_mb = getenv("KD_WINO_SLICE_MB") ? atoll(getenv("KD_WINO_SLICE_MB")) : 0;  // read per plan
+    const int64_t slice_mb = kd_switch("KD_WINO_SLICE_MB", 0);  // read per plan
     int64_t nt_slice = Mt;
     if (slice_mb > 0) {
       nt_slice = (slice_mb << 20) / (64 * (int64_t)(Cin + Cout)) / 256 * 256;
@@ -826,48 +829,22 @@ struct Builder {
     return y;
   }
 
-  // ---- fused Winograd F(2x2,3x3) (kernels_wino_fused.hip) for the 3x3 convs the path above leaves to the
-  // direct kernel: wide maps with few channels, input already activated by gn_apply.  cfg.conv_algo 0:
-  // wherever the shape fits and the launch fills the chip; 1 and 2: never (2 = the non-fused path only);
-  // 3: wherever the shape fits (tests).
+  // ---- fused Winograd F(2x2,3x3) + GroupNorm / FiLM / SiLU (kernels_wino_fused128.hip; kernels_wino_fused.hip where
+  // Cout % 128 != 0): every ResnetBlock 3x3 conv whose map the kernels can tile.  cfg.conv_algo 0: wherever the shape
+  // fits and the launch fills the chip; 1 and 2: never (2 = the batched-GEMM Winograd path only); 3: wherever the
+  // shape fits (tests).
   bool fwino_ok(const T& x, int cout) const {
     if (cfg.conv_algo == 1 || cfg.conv_algo == 2) return false;
     if (x.C < 32 || !wino_fused_ok(x.B, x.H, x.W, x.C, cout)) return false;
     if (cfg.conv_algo == 3) return true;
     return (int64_t)x.B * (x.H / 16) * (x.W / 16) * (cout / 64) >= 256;  // one workgroup per CU and round
   }
-  T fwino_conv(const T& x, const std::string& conv_prefix, int Cout, const T* res) {
-    const int Cin = x.C, Bx = x.B, H = x.H, W = x.W;
-    const float* bias = P(conv_prefix + ".bias", Cout);
-    const float* wsrc = raw(conv_prefix + ".weight", (int64_t)Cout * Cin * 9);
-    float* U = cached("winof:" + conv_prefix, (size_t)16 * Cout * Cin,
-                      [&](float* dst) { KD_THROW_IF(launch_wino_fused_pack(wsrc, dst, Cout, Cin, 0)); });
-    if (!x.dense()) throw std::runtime_error("plan: fwino_conv needs a dense input");
-    T y = alloc(Bx, H, W, Cout);
-    size_t xo = x.off, yo = y.off, ro = res ? res->at() : 0;
-    const bool hr = res != nullptr;
-    const int ldres = res ? res->LD() : 0;
-    kd_unet* uu = u;
-    const int64_t m = (int64_t)Bx * H * W * Cout * Cin * 9;
-    emit([=](hipStream_t s) {
-      return launch_wino_fused(uu->P(xo), U, bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W, Cin, Cout, s);
-    }, "wino fused M" + std::to_string((int64_t)Bx * H * W) + " Cin" + std::to_string(Cin) + " Cout" +
-           std::to_string(Cout), m);
-    if (!to_text) u->macs += m;
-    if (!to_text && !to_static) {
-      const int64_t issued = (int64_t)Bx * H * W * 4 * Cout * ((Cin / 4 + 2) / 3 * 12);
-      u->mfma_macs += issued;
-      u->op_mfma.back() = issued;
-    }
-    return y;
-  }
-
   // The same layer straight from the un-normalised block input: GroupNorm statistics, the per-(image, channel)
   // affine fold, and the fused kernel that applies GroupNorm / FiLM / SiLU to the raw patch in LDS
   // (wino_fused_gn_kernel): the activated map is never written.  KD_FWINO_GN=0 keeps the separate
   // gn_apply_silu pass (A/B, read per plan).
   bool fwino_gn_ok(const T& x, int cout) const {
-    const bool on = !getenv("KD_FWINO_GN") || atoi(getenv("KD_FWINO_GN")) != 0;
+    const bool on = kd_switch("KD_FWINO_GN", 1) != 0;
     return on && x.C <= wino_fused_gn_max_cin() && x.C % cfg.resnet_groups == 0 && fwino_ok(x, cout) &&
            (int64_t)x.H * x.W * x.LD() * 4 < 0x7fffffff;
   }
@@ -896,7 +873,7 @@ struct Builder {
       }, "gn fold C" + std::to_string(Cin));
     }
     // the epilogue leaves the partials of y for whichever GroupNorm reads it next (block2, or the next block)
-    const bool so_ = seg_on && Cout % 16 == 0 && !(getenv("KD_FWINO_STATS") && atoi(getenv("KD_FWINO_STATS")) == 0);
+    const bool so_ = seg_on && Cout % 16 == 0 && kd_switch("KD_FWINO_STATS", 1) != 0;
     const size_t pout = so_ ? add_seg(y, 0, Cout / 16, (int)wino_fused_out_stats_chunks(H, W, Cout, Cout / 16)) : 0;
     size_t xo = x.at(), yo = y.off, ro = res ? res->at() : 0, abo = ab.off;
     const bool hr = res != nullptr;
@@ -948,11 +925,8 @@ struct Builder {
       h = fwino_gn_conv(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
     } else {
       T y1 = gn_silu(x, pre + ".block1.groupnorm", -1);
-      if (fwino_ok(y1, dim_out))
-        h = fwino_conv(y1, pre + ".block1.project", dim_out, nullptr);
-      else
-        h = conv(y1, pack_conv(pre + ".block1.project.weight", dim_out, dim_in, dim_in, 3),
-                 P(pre + ".block1.project.bias", dim_out), dim_out, 3, 1, 1, ConvOpt());
+      h = conv(y1, pack_conv(pre + ".block1.project.weight", dim_out, dim_in, dim_in, 3),
+               P(pre + ".block1.project.bias", dim_out), dim_out, 3, 1, 1, ConvOpt());
       free(y1);
     }
     if (has_cross) {
@@ -978,11 +952,8 @@ struct Builder {
       if (!use_gca && !has_res_conv) o2.res = &x;  // h2 + x folded into the conv epilogue
       o2.want_seg = true;
       free(h);
-      if (fwino_ok(y2, dim_out))
-        h2 = fwino_conv(y2, pre + ".block2.project", dim_out, o2.res);
-      else
-        h2 = conv(y2, pack_conv(pre + ".block2.project.weight", dim_out, dim_out, dim_out, 3),
-                  P(pre + ".block2.project.bias", dim_out), dim_out, 3, 1, 1, o2);
+      h2 = conv(y2, pack_conv(pre + ".block2.project.weight", dim_out, dim_out, dim_out, 3),
+                P(pre + ".block2.project.bias", dim_out), dim_out, 3, 1, 1, o2);
       free(y2);
     }
     if (!use_gca && !has_res_conv) return h2;
@@ -1035,6 +1006,11 @@ struct Builder {
   }
 
   T downsample(const T& x, const std::string& pre, int dim_out) {  // pixel-unshuffle + conv1x1 == 2x2/s2 conv
+    if (cfg.downsample_conv4) {   // earlier library versions: Conv2d(dim, dim_out, 4, stride 2, pad 1)
+      ConvOpt o4;
+      o4.want_seg = true;
+      return conv(x, pack_conv(pre + ".weight", dim_out, x.C, x.C, 4), P(pre + ".bias", dim_out), dim_out, 4, 2, 1, o4);
+    }
     const float* src = raw(pre + ".1.weight", (int64_t)dim_out * 4 * x.C);
     const int C = x.C;
     float* w = cached("unshuffle:" + pre, (size_t)dim_out * 4 * C,

@@ -851,7 +851,7 @@ static int launch_conv_fast(const ConvParams& p, int64_t M, hipStream_t s) {
   // prologue/epilogue; short-K 1x1 convs run as two 128x128 workgroups per CU, which overlap one
   // tile's epilogue with the other's loop (measured in the step: 3x3 Cin=128 layers still prefer 256x128)
   const int k_chunks = p.KH * p.KW * (p.Cin / BK);
-  static const int shortk = getenv("KD_SHORTK_TILE") ? atoi(getenv("KD_SHORTK_TILE")) : 0;   // experiment switch
+  static const int shortk = kd_switch("KD_SHORTK_TILE", 0);   // experiment switch
   if (p.KH * p.KW == 1 && k_chunks <= 8 && p.wz_rows == 0 && shortk == 1 &&
       ((M + 127) / 128) * ((p.Cout + 127) / 128) >= 256) {
     dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 127) / 128);
@@ -907,7 +907,7 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     ConvParams q = p;
     q.ksplit = ks;
     q.wide_epilogue = p.Cout % 4 == 0 &&   // the raw partial tiles [z][M][Cout] with 16-byte stores
-                      !(getenv("KD_CONV_WIDE") && atoi(getenv("KD_CONV_WIDE")) == 0);
+                      kd_switch("KD_CONV_WIDE", 1) != 0;
     if (M <= 64) {
       // an 8x8 map of a batch-1 patch: 64-row tiles (a 128-row tile would spend half its MFMAs on padding and
       // these launches, K up to 9 x 3072, were bound by exactly that: 124 us for 226 MB of weights), 128 columns
@@ -924,7 +924,7 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
   }
   const bool fast = fast_shape_ok(p) && M > 64;
   if (fast && (p.out_mode == OUT_NHWC || p.out_mode == OUT_PIXSHUF) && conv_wide_ok(p) &&
-      !(getenv("KD_CONV_WIDE") && atoi(getenv("KD_CONV_WIDE")) == 0)) {   // (A/B switch)
+      kd_switch("KD_CONV_WIDE", 1) != 0) {   // (A/B switch)
     ConvParams q = p;
     q.wide_epilogue = 1;
     return launch_conv_fast(q, M, s);
@@ -932,7 +932,7 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
   if (fast) return launch_conv_fast(p, M, s);
   KD_REQUIRE(p.wz_rows == 0, "batched GEMM needs the buffer-load fast path (Cin % 32 == 0, Cout > 32)");
   ConvParams g = p;
-  g.wide_epilogue = p.out_mode == OUT_NHWC && conv_wide_ok(p) && !(getenv("KD_CONV_WIDE") && atoi(getenv("KD_CONV_WIDE")) == 0);
+  g.wide_epilogue = p.out_mode == OUT_NHWC && conv_wide_ok(p) && kd_switch("KD_CONV_WIDE", 1) != 0;
   if (p.Cout <= 32) {
     dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 31) / 32);
     hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, g);

@@ -538,9 +538,8 @@ bool wino_fused128_ok(int B, int H, int W, int C, int N) {
 
 // the plan / the C ABI take this form wherever it applies; KD_FWINO_N128=0 (read once) keeps the 64-channel items (A/B)
 bool wino_fused128_use(int B, int H, int W, int C, int N) {
-  static const bool on = !getenv("KD_FWINO_N128") || atoi(getenv("KD_FWINO_N128")) != 0;
-  static const bool k16 = !getenv("KD_FWINO_VAR") || atoi(getenv("KD_FWINO_VAR")) != 8;   // (the eight-wave kernel: 64 only)
-  return on && k16 && wino_fused128_ok(B, H, W, C, N);
+  static const bool on = kd_switch("KD_FWINO_N128", 1) != 0;
+  return on && wino_fused128_ok(B, H, W, C, N);
 }
 
 int launch_wino_fused128_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s, float scale) {
@@ -585,7 +584,7 @@ int launch_wino_fused_gn128(const float* x, int ldx, const float* ab, const floa
     cus = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 8;   // a multiple of the 8 XCDs
   }
   const unsigned pgrid = grid < (unsigned)cus ? grid : (unsigned)cus;   // persistent: one workgroup per CU
-  static const int prio = getenv("KD_FWINO_PRIO") ? atoi(getenv("KD_FWINO_PRIO")) : 1;
+  static const int prio = kd_switch("KD_FWINO_PRIO", 1);
   hipLaunchKernelGGL(wino_fused_gn128_kernel, dim3(pgrid), dim3(1024), 0, s, x, ldx, ab, U, bias, res, ldres, y, B, H, W, C, N,
                      out_partial, out_groups, (const int4*)items, prio);
   KD_HIP_CHECK(hipGetLastError());

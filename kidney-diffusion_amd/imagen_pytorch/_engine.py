@@ -50,6 +50,8 @@ class kd_unet_config_t(C.Structure):
         ("image_size", C.c_int),
         ("conv_algo", C.c_int),
         ("attn_qk_norm", C.c_int),
+        ("downsample_conv4", C.c_int),
+        ("mid_attn_plain", C.c_int),
     ]
 
 
@@ -115,8 +117,7 @@ SIGNATURES = {
     "kd_sample_last": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "kd_conv2d_nhwc": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]),
     "kd_conv3x3_winograd_nhwc": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
-    "kd_conv3x3_winograd_fused_nhwc": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
-    "kd_gn_conv3x3_winograd_fused_nhwc": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_void_p]),
+    "kd_gn_conv3x3_winograd_fused_nhwc": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "kd_init_conv_nchw": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
     "kd_groupnorm_silu_nhwc": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "kd_layernorm": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),

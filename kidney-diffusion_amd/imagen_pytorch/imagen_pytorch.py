@@ -19,6 +19,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import re
 from typing import Callable, Optional
 
 import torch
@@ -82,7 +83,12 @@ class CrossEmbedLayer(_Decl):
             [nn.Conv2d(dim_in, s, k, stride=stride, padding=(k - stride) // 2) for k, s in zip(kernel_sizes, scales)])
 
 
-def _downsample(dim, dim_out):
+def _downsample(dim, dim_out, form="unshuffle"):
+    """Library 1.18.x: Rearrange (pixel-unshuffle) + Conv2d(4 dim, dim_out, 1), keys `<pre>.1.*`; earlier versions:
+    Conv2d(dim, dim_out, 4, 2, 1), keys `<pre>.*` with a [dim_out, dim, 4, 4] weight (SURVEY A.1 version fork)."""
+    if form == "conv4x4":
+        return nn.Conv2d(dim, dim_out, 4, 2, 1)
+    assert form == "unshuffle"
     return nn.Sequential(_Stateless(), nn.Conv2d(dim * 4, dim_out, 1))
 
 
@@ -150,6 +156,21 @@ def _feed_forward(dim, mult):
     hidden = int(dim * mult)
     return nn.Sequential(LayerNorm(dim), nn.Linear(dim, hidden, bias=False), _Stateless(), LayerNorm(hidden),
                          nn.Linear(hidden, dim, bias=False))
+
+
+class _Fn(_Decl):   # one `.fn` level of the key path (Residual / EinopsToAndFrom wrappers of the library)
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+
+class ResidualAttentionBlock(_Decl):
+    """mid_attn of earlier library versions: EinopsToAndFrom(Residual(Attention(mid_dim))) - keys `mid_attn.fn.fn.*`,
+    attention + residual without a feed-forward (SURVEY A.1 version fork)."""
+
+    def __init__(self, dim, *, heads, dim_head):
+        super().__init__()
+        self.fn = _Fn(Attention(dim, dim_head=dim_head, heads=heads))
 
 
 class TransformerBlock(_Decl):
@@ -237,9 +258,12 @@ class Unet(nn.Module):
         attn_pool_text=True, attn_pool_num_latents=32, dropout=0.0, memory_efficient=False,
         init_conv_to_final_conv_residual=False, use_global_context_attn=True, scale_skip_connection=True,
         final_resnet_block=True, final_conv_kernel_size=3, self_cond=False, pixel_shuffle_upsample=True,
-        cosine_sim_attn=False, attn_qk_norm=None,
+        cosine_sim_attn=False, attn_qk_norm=None, downsample_form="unshuffle", mid_attn_form="transformer",
     ):
-        """`cosine_sim_attn` is the library's kwarg (1.18.x: l2-normalised q, k with a fixed scale of 16).
+        """`downsample_form` / `mid_attn_form` (engine extensions) name the two structural forks between library
+        versions - "unshuffle" | "conv4x4" and "transformer" | "residual_attention"; load_state_dict() selects them
+        from the incoming keys and shapes, as it does for the attention similarity.
+        `cosine_sim_attn` is the library's kwarg (1.18.x: l2-normalised q, k with a fixed scale of 16).
         `attn_qk_norm` (engine extension, 0 / 1 / 2, see include/kd_engine.h) overrides it; 2 = the learned
         q_scale / k_scale attention of later library versions, which load_state_dict() also selects by itself
         when the incoming keys contain `q_scale` - so the first real checkpoint decides the variant."""
@@ -320,12 +344,12 @@ class Unet(nn.Module):
             cur = d_in
             pre = None
             if memory_efficient:
-                pre = _downsample(d_in, d_out)
+                pre = _downsample(d_in, d_out, downsample_form)
                 cur = d_out
             skip_dims.append(cur)
             post = None
             if not memory_efficient:
-                post = _downsample(cur, d_out) if not is_last else Parallel(
+                post = _downsample(cur, d_out, downsample_form) if not is_last else Parallel(
                     nn.Conv2d(d_in, d_out, 3, padding=1), nn.Conv2d(d_in, d_out, 1))
             self.downs.append(nn.ModuleList([
                 pre,
@@ -337,7 +361,13 @@ class Unet(nn.Module):
             ]))
         mid = dims[-1]
         self.mid_block1 = ResnetBlock(mid, mid, cond_dim=cond_dim, time_cond_dim=tcd, groups=groups[-1], **ak)
-        self.mid_attn = TransformerBlock(mid, depth=1, ff_mult=2, **ak) if attend_at_middle else None
+        assert downsample_form in ("unshuffle", "conv4x4") and mid_attn_form in ("transformer", "residual_attention")
+        self.downsample_form, self.mid_attn_form = downsample_form, mid_attn_form
+        self._dims = dims
+        self.mid_attn = None
+        if attend_at_middle:
+            self.mid_attn = TransformerBlock(mid, depth=1, ff_mult=2, **ak) if mid_attn_form == "transformer" \
+                else ResidualAttentionBlock(mid, **ak)
         self.mid_block2 = ResnetBlock(mid, mid, cond_dim=cond_dim, time_cond_dim=tcd, groups=groups[-1], **ak)
         for ind, ((d_in, d_out), n, g, la, lc) in enumerate(
                 zip(reversed(in_out), reversed(nrb), reversed(groups), reversed(attns), reversed(cross))):
@@ -360,7 +390,10 @@ class Unet(nn.Module):
         self._engines_fingerprint = None
         self._io_buffers = {}  # per (batch, size, device): sampler inputs at stable addresses (step graph reuse)
         self.attn_qk_norm = 0
-        self.set_attn_qk_norm(int(attn_qk_norm) if exists(attn_qk_norm) else (1 if cosine_sim_attn else 0))
+        # what the CONSTRUCTOR asked for: the variant a checkpoint without q_scale / k_scale falls back to
+        self._ctor_qk_norm = int(attn_qk_norm) if exists(attn_qk_norm) else (1 if cosine_sim_attn else 0)
+        self._ctor_qk_explicit = exists(attn_qk_norm)
+        self.set_attn_qk_norm(self._ctor_qk_norm)
         self.register_load_state_dict_post_hook(_invalidate_engine_hook)
 
     def set_attn_qk_norm(self, mode: int):
@@ -373,20 +406,58 @@ class Unet(nn.Module):
             if isinstance(m, _QKNorm):
                 m.set_qk_norm(mode)
 
-    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
-        # Runs before the children load: a checkpoint whose attention blocks carry q_scale / k_scale was written
-        # by a library version with qk-norm attention -> grow those parameters so that the strict load succeeds
-        # and the engine plans the matching similarity (and the other way round for a checkpoint without them).
+    def set_version_forks(self, downsample_form=None, mid_attn_form=None):
+        """Rebuilds the parameter containers of the two structural version forks in place (fresh parameters, same
+        device / dtype) and drops the execution plans."""
+        ref = self.final_conv.weight
+        changed = False
+        if downsample_form is not None and downsample_form != self.downsample_form:
+            for l, lvl in enumerate(self.downs):
+                for slot in (0, 4):
+                    if isinstance(lvl[slot], (nn.Sequential, nn.Conv2d)):   # (not the last level's Parallel, not None)
+                        lvl[slot] = _downsample(self._dims[l], self._dims[l + 1], downsample_form).to(ref)
+            self.downsample_form = self._locals["downsample_form"] = downsample_form
+            changed = True
+        if mid_attn_form is not None and mid_attn_form != self.mid_attn_form and exists(self.mid_attn):
+            ak = dict(heads=self._plan["attn_heads"], dim_head=self._plan["attn_dim_head"])
+            self.mid_attn = (TransformerBlock(self._dims[-1], depth=1, ff_mult=2, **ak) if mid_attn_form == "transformer"
+                             else ResidualAttentionBlock(self._dims[-1], **ak)).to(ref)
+            self.mid_attn_form = self._locals["mid_attn_form"] = mid_attn_form
+            self.set_attn_qk_norm(self.attn_qk_norm)
+            changed = True
+        if changed and getattr(self, "_engines", None):
+            self.invalidate_engine()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, *args, **kwargs):
+        # Runs before the children load.  The library's module tree forked between versions (SURVEY A.1 "version
+        # forks"); the incoming key set / shapes name the fork, and the tree (and so the engine's plan) follows it, so
+        # that a checkpoint of a neighbouring version loads STRICTLY instead of falling into restore_parts half-loaded:
+        #   * Downsample: `downs.L.{0,4}.weight` [d_out, d, 4, 4] (strided conv) vs `downs.L.{0,4}.1.weight` (unshuffle + 1x1)
+        #   * mid_attn:   `mid_attn.fn.fn.*` (residual attention) vs `mid_attn.layers.*` (TransformerBlock)
+        #   * attention similarity: `*.q_scale` / `*.k_scale` present (learned qk-norm) or not
+        if any(k.startswith(prefix + "downs.") for k in state_dict):
+            conv4 = any(re.fullmatch(re.escape(prefix) + r"downs\.\d+\.[04]\.weight", k) and v.dim() == 4 and v.shape[-1] == 4
+                        for k, v in state_dict.items())
+            plain = any(k.startswith(prefix + "mid_attn.fn.") for k in state_dict)
+            want = ("conv4x4" if conv4 else "unshuffle", "residual_attention" if plain else "transformer")
+            if want != (self.downsample_form, self.mid_attn_form):
+                print(f"imagen_pytorch: checkpoint keys name the library fork downsample={want[0]}, mid_attn={want[1]} "
+                      "-> module tree and engine plan follow it")
+                self.set_version_forks(*want)
         has = any(k.startswith(prefix) and k.endswith(".q_scale") for k in state_dict)
         if has and self.attn_qk_norm != 2:
             print("imagen_pytorch: checkpoint carries q_scale / k_scale -> attention variant switched to qk-norm "
                   "(learned scales, x8)")
             self.set_attn_qk_norm(2)
-        elif not has and self.attn_qk_norm == 2 and any(k.startswith(prefix) for k in state_dict):
-            print("imagen_pytorch: checkpoint has no q_scale / k_scale -> attention variant switched back to the "
-                  "scaled dot product")
-            self.set_attn_qk_norm(0)
-        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        elif not has and self.attn_qk_norm == 2 and any(k.startswith(prefix) for k in state_dict) \
+                and not (self._ctor_qk_explicit and self._ctor_qk_norm == 2):
+            # (a Unet BUILT with attn_qk_norm=2 keeps it: torch then reports the missing q_scale / k_scale keys - an
+            # error under strict=True, defaults of one under strict=False)
+            back = self._ctor_qk_norm if self._ctor_qk_norm != 2 else 0   # cosine_sim_attn=True stays cosine-sim
+            print("imagen_pytorch: checkpoint has no q_scale / k_scale -> attention variant back to "
+                  + ("cosine-sim (x16)" if back == 1 else "the scaled dot product"))
+            self.set_attn_qk_norm(back)
+        return super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, *args, **kwargs)
 
     # ---- library API used by Imagen
     def cast_model_parameters(self, *, lowres_cond, text_embed_dim, channels, channels_out, cond_on_text):
@@ -416,7 +487,11 @@ class Unet(nn.Module):
         or an optimizer step must rebuild them.  torch bumps `_version` on every in-place write through the
         parameter or a `detach()`ed alias (what state_dict() hands out).  Writes through `p.data` carry their
         own version counter and are invisible here: after those, call `invalidate_engine()` yourself."""
-        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+        import itertools
+
+        # (parameters() / buffers() walk the live module tree - a replaced Parameter object is seen - without building the
+        # state_dict's OrderedDict and running its hooks: this runs on every sample() call, once per patch and stage)
+        return tuple((t.data_ptr(), t._version) for t in itertools.chain(self.parameters(), self.buffers()))
 
     def __deepcopy__(self, memo):
         """copy.deepcopy(unet) - ImagenTrainer's EMA copies (trainer.py), the reference builds the trainer around
@@ -468,7 +543,7 @@ class Unet(nn.Module):
         # engine extension (not a library kwarg): 0 = auto (Winograd for the deep 3x3 convs), 1 = direct only
         conv_algo = int(getattr(self, "conv_algo", os.environ.get("KD_CONV_ALGO", "0")))
         key = (batch, image_size, device.index, bool(with_text), conv_algo, self.attn_qk_norm) + \
-            ((replica,) if replica else ())
+            ((replica,) if replica else ())   # (the structural forks drop every plan when they change)
         if self._engines:
             fp = self._weights_fingerprint()
             if fp != self._engines_fingerprint:   # a parameter was written in place: packed copies are stale
@@ -502,6 +577,8 @@ class Unet(nn.Module):
         cfg.batch, cfg.image_size = batch, image_size
         cfg.conv_algo = conv_algo
         cfg.attn_qk_norm = self.attn_qk_norm
+        cfg.downsample_conv4 = int(self.downsample_form == "conv4x4")
+        cfg.mid_attn_plain = int(self.mid_attn_form == "residual_attention")
 
         with torch.cuda.device(device):
             sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous()

@@ -26,6 +26,7 @@ reference's path reduces to when it runs on CPU.
 from __future__ import annotations
 
 import math
+import re
 from functools import partial
 
 import torch
@@ -97,8 +98,14 @@ class PixelUnshuffle2(nn.Module):
         return x.permute(0, 1, 3, 5, 2, 4).reshape(b, c * 4, h // 2, w // 2)
 
 
-def Downsample(dim, dim_out=None):
+def Downsample(dim, dim_out=None, form="unshuffle"):
+    """1.18.x: pixel-unshuffle + 1x1 conv (keys `<pre>.1.weight` [d_out, 4 d, 1, 1]).  Earlier library versions:
+    a strided convolution `Conv2d(dim, dim_out, 4, 2, 1)` (key `<pre>.weight` [d_out, d, 4, 4]) - SURVEY A.1's
+    version fork, selected by a checkpoint's key shapes (Unet._load_from_state_dict)."""
     dim_out = default(dim_out, dim)
+    if form == "conv4x4":
+        return nn.Conv2d(dim, dim_out, 4, 2, 1)
+    assert form == "unshuffle"
     return nn.Sequential(PixelUnshuffle2(), nn.Conv2d(dim * 4, dim_out, 1))
 
 
@@ -291,6 +298,30 @@ class TransformerBlock(nn.Module):
         return x.reshape(b, h, w, c).permute(0, 3, 1, 2)
 
 
+class _Residual(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, x, **kw):
+        return self.fn(x, **kw) + x
+
+
+class ResidualAttentionBlock(nn.Module):
+    """The mid-block attention of earlier library versions: `EinopsToAndFrom('b c h w', 'b (h w) c',
+    Residual(Attention(mid_dim)))` - attention + residual WITHOUT the feed-forward of a TransformerBlock; state-dict
+    keys `mid_attn.fn.fn.*` (SURVEY A.1's version fork)."""
+
+    def __init__(self, dim, *, heads=8, dim_head=64):
+        super().__init__()
+        self.fn = _Residual(Attention(dim=dim, heads=heads, dim_head=dim_head))
+
+    def forward(self, x, context=None):
+        b, c, h, w = x.shape
+        x = self.fn(x.permute(0, 2, 3, 1).reshape(b, h * w, c))
+        return x.reshape(b, h, w, c).permute(0, 3, 1, 2)
+
+
 class PerceiverAttention(nn.Module, _QKNorm):
     def __init__(self, *, dim, dim_head=64, heads=8):
         super().__init__()
@@ -440,6 +471,7 @@ class Unet(nn.Module):
         attn_pool_num_latents=32, memory_efficient=False,
         init_conv_to_final_conv_residual=False, use_global_context_attn=True,
         scale_skip_connection=True, final_conv_kernel_size=3, cosine_sim_attn=False, attn_qk_norm=None,
+        downsample_form="unshuffle", mid_attn_form="transformer",
     ):
         super().__init__()
         self._locals = {k: v for k, v in locals().items() if k not in ("self", "__class__")}
@@ -526,12 +558,12 @@ class Unet(nn.Module):
             current_dim = dim_in
             pre_downsample = None
             if memory_efficient:
-                pre_downsample = Downsample(dim_in, dim_out)
+                pre_downsample = Downsample(dim_in, dim_out, downsample_form)
                 current_dim = dim_out
             skip_connect_dims.append(current_dim)
             post_downsample = None
             if not memory_efficient:
-                post_downsample = Downsample(current_dim, dim_out) if not is_last else Parallel(
+                post_downsample = Downsample(current_dim, dim_out, downsample_form) if not is_last else Parallel(
                     nn.Conv2d(dim_in, dim_out, 3, padding=1), nn.Conv2d(dim_in, dim_out, 1))
             attn = TransformerBlock(dim=current_dim, depth=attn_depth, ff_mult=ff_mult,
                                     context_dim=cond_dim, **attn_kwargs) if layer_attn else Identity()
@@ -550,7 +582,12 @@ class Unet(nn.Module):
         mid_dim = dims[-1]
         self.mid_block1 = ResnetBlock(mid_dim, mid_dim, cond_dim=cond_dim,
                                       time_cond_dim=time_cond_dim, groups=resnet_groups[-1])
-        self.mid_attn = TransformerBlock(mid_dim, depth=1, **attn_kwargs) if attend_at_middle else None
+        self.mid_attn = None
+        if attend_at_middle:
+            self.mid_attn = TransformerBlock(mid_dim, depth=1, **attn_kwargs) if mid_attn_form == "transformer" \
+                else ResidualAttentionBlock(mid_dim, **attn_kwargs)
+        assert mid_attn_form in ("transformer", "residual_attention")
+        self.downsample_form, self.mid_attn_form = downsample_form, mid_attn_form
         self.mid_block2 = ResnetBlock(mid_dim, mid_dim, cond_dim=cond_dim,
                                       time_cond_dim=time_cond_dim, groups=resnet_groups[-1])
 
@@ -593,7 +630,32 @@ class Unet(nn.Module):
             if isinstance(m, _QKNorm):
                 m.set_qk_norm(mode)
 
+    def set_version_forks(self, downsample_form=None, mid_attn_form=None):
+        """Rebuilds the modules of the two structural version forks in place (fresh parameters)."""
+        L = self._locals
+        dims = [L["dim"], *[L["dim"] * m for m in L["dim_mults"]]]
+        if downsample_form is not None and downsample_form != self.downsample_form:
+            for l, lvl in enumerate(self.downs):
+                for slot in (0, 4):
+                    if isinstance(lvl[slot], (nn.Sequential, nn.Conv2d)):
+                        lvl[slot] = Downsample(dims[l], dims[l + 1], downsample_form)   # pre (mem-eff) and post alike
+            self.downsample_form = L["downsample_form"] = downsample_form
+        if mid_attn_form is not None and mid_attn_form != self.mid_attn_form and exists(self.mid_attn):
+            kw = dict(heads=L["attn_heads"], dim_head=L["attn_dim_head"])
+            self.mid_attn = TransformerBlock(dims[-1], depth=1, **kw) if mid_attn_form == "transformer" \
+                else ResidualAttentionBlock(dims[-1], **kw)
+            self.mid_attn_form = L["mid_attn_form"] = mid_attn_form
+            self.set_attn_qk_norm(self.attn_qk_norm)
+
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        conv4 = any(re.fullmatch(re.escape(prefix) + r"downs\.\d+\.[04]\.weight", k) and v.dim() == 4 and v.shape[-1] == 4
+                    for k, v in state_dict.items())
+        mine = any(k.startswith(prefix + "downs.") for k in state_dict)
+        if mine:
+            self.set_version_forks(
+                downsample_form="conv4x4" if conv4 else "unshuffle",
+                mid_attn_form="residual_attention" if any(k.startswith(prefix + "mid_attn.fn.") for k in state_dict)
+                else "transformer")
         has = any(k.startswith(prefix) and k.endswith(".q_scale") for k in state_dict)
         if has and self.attn_qk_norm != 2:
             self.set_attn_qk_norm(2)

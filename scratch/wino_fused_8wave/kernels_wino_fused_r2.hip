@@ -1,15 +1,26 @@
-// Fused Winograd F(2x2,3x3) convolution + GroupNorm / FiLM / SiLU for the ResnetBlock 3x3 convs whose Cout is a
-// multiple of 64 but not of 128 (the layers with Cout % 128 == 0 - every layer of the reference's UNets - run the
-// 128-channel items of kernels_wino_fused128.hip; this file serves reduced-width models):
+// Fused Winograd F(2x2,3x3) convolution for the shallow, wide-map 3x3 layers (Cin = 128-type levels).
 //
-//   y = conv3x3(SiLU(A x + B)) + bias (+ res),  x NHWC (row stride ldx), ab = per-(image, channel) affine of
-//   GroupNorm (+ FiLM) (launch_gn_fold / launch_gn_fold_seg), 3x3 / stride 1 / pad 1, H % 16 == 0, W % 16 == 0,
-//   Cin % 4 == 0, Cin <= 2048, Cout % 64 == 0.
+//   y = conv3x3(x) + bias (+ res),  x NHWC already activated (GroupNorm/FiLM/SiLU applied by gn_apply),
+//   3x3 / stride 1 / pad 1, H % 16 == 0, W % 16 == 0, Cin % 4 == 0, Cout % 64 == 0.
 //
-// Nothing but x, U and y touches HBM: one work item is a 16x16-pixel patch (8x8 output tiles) x 64 output channels
-// with ALL 16 Winograd positions' accumulators in registers, so the MFMA work is 4 MACs per output and input channel
-// instead of 9.  The eight-wave forms this kernel grew out of (round 1 / first half of round 2: one item per
-// workgroup, pre-activated or GroupNorm-fused input) are kept for the record in scratch/wino_fused_8wave/.
+// kernels_wino.hip runs the 16 Winograd GEMMs on the implicit-GEMM kernel and moves V and D (4x the map
+// each) through HBM; that loses below Cin = 256.  Here nothing but x, U and y touches HBM: one workgroup
+// owns a 16x16-pixel patch (8x8 output tiles) x 64 output channels and keeps ALL 16 positions'
+// accumulators in registers, so the MFMA work is 4 MACs per output and input channel instead of 9.
+//
+// What shaped it (profiles/README.md, scratch/mfma_fill.hip): on gfx950 a VALU instruction issued in the
+// shadow of v_mfma_f32_32x32x2_f32 costs its full 4-8 cycles (the fp32 MFMA holds the SIMD's vector
+// issue; only LDS / DMA instructions hide), and one wave per SIMD leaves every LDS latency exposed.  So
+//   * 8 waves = 2 per SIMD, 128 accumulator registers each: wave (ph, wm, wn) owns 32 tiles x 32 channels
+//     x the 8 positions of transformed rows {2ph, 2ph+1};
+//   * the input transform is the only VALU work in the loop: 20 instructions per thread and 4-channel
+//     chunk (thread = tile x channel x row pair); the activation stays in the HBM-bound gn_apply pass and
+//     zero padding is the out-of-range result of the buffer DMA;
+//   * raw 18x18x4 patches and 16x64x4 weight chunks arrive by buffer_load ... lds, three stages, ONE
+//     barrier per chunk; every stage is its own __shared__ object with a compile-time index, otherwise
+//     hipcc cannot tell the DMA's LDS writes from the ds_reads and waits vmcnt(0) before each of them;
+//   * the output transform A^T m A is linear in the rows of m: each wave forms partial 2x2 outputs from
+//     its two rows and the pair swaps halves through LDS.
 // Result differs from the direct conv by re-association only.
 #include "common.h"
 
@@ -17,7 +28,6 @@
 
 #include <type_traits>
 #include <vector>
-
 
 namespace kd {
 
@@ -65,7 +75,589 @@ __global__ __launch_bounds__(256) void wino_fused_pack_kernel(const float* __res
   }
 }
 
-constexpr int WG16_MAXC = 2048;   // channels of the affine table kept in LDS
+__global__ __launch_bounds__(512, 1) void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ U,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ res, int ldres,
+                                                            float* __restrict__ y, int B, int H, int W, int C, int N) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(1024))) float raw_0[WF_RAW], raw_1[WF_RAW], raw_2[WF_RAW];
+  __shared__ __attribute__((aligned(1024))) float us_0[WF_UV], us_1[WF_UV], us_2[WF_UV];
+  __shared__ __attribute__((aligned(1024))) float vs_0[WF_UV], vs_1[WF_UV], vs_2[WF_UV];
+  auto rawp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return raw_0; else if constexpr (decltype(S)::value == 1) return raw_1; else return raw_2; };
+  auto usp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return us_0; else if constexpr (decltype(S)::value == 1) return us_1; else return us_2; };
+  auto vsp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return vs_0; else if constexpr (decltype(S)::value == 1) return vs_1; else return vs_2; };
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int pw = W / 16, ph_ = H / 16;
+  const int nh = N / 64;
+  const int npatch = B * pw * ph_;
+  // the N/64 workgroups of one patch run back to back on ONE XCD (block ids go round-robin over the 8 XCDs)
+  int bpatch, nhalf;
+  if ((npatch & 7) == 0) {
+    const int id = blockIdx.x;
+    bpatch = (id / (8 * nh)) * 8 + (id & 7);
+    nhalf = (id >> 3) % nh;
+  } else {
+    bpatch = blockIdx.x / nh;
+    nhalf = blockIdx.x % nh;
+  }
+  const int b = bpatch / (pw * ph_);
+  const int prem = bpatch - b * pw * ph_;
+  const int y0 = (prem / pw) * 16, x0 = (prem % pw) * 16;
+  const int n0 = nhalf * 64;
+  const int nchunks = C / WF_K;
+
+  // one image per descriptor: 32-bit buffer offsets cover H*W*C*4 < 2^31 (1024^2 x 128 fp32 = 512 MB)
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)b * H * W * C), 0,
+                                                                       (int)((int64_t)H * W * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU =
+      __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, (int)((int64_t)16 * N * C * 4), 0x00020000);
+
+  // raw patch loader: thread = pixel slot of the 18x18 patch (origin at the output origin - 1), 16 B = 4 channels
+  uint32_t voffX;
+  {
+    // slot = row * 18 + (even columns 0, 2, .. 16 first, then the odd ones): the transform's reads of column
+    // 2 * ttx + s then run along ttx with stride 1 and are free of LDS bank conflicts (stride 2 pixels = 8
+    // floats puts lanes ttx and ttx + 4 on one bank)
+    int py = tid / 18, pq = tid - py * 18;
+    int px = pq < 9 ? 2 * pq : 2 * (pq - 9) + 1;
+    int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    bool ok = tid < 324 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    voffX = ok ? (uint32_t)(((iy * W + ix) * C) * 4) : OOB_OFF;
+  }
+  auto issue_raw = [&](int chunk, auto S) {
+    __attribute__((address_space(3))) float* rb = (__attribute__((address_space(3))) float*)(rawp(S) + wave * 256);
+    const uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t)(chunk * WF_K * 4));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, rb, 16, chunk < nchunks ? voffX : OOB_OFF, sx, 0, 0);
+  };
+  auto issue_u = [&](int chunk, auto S) {
+    __attribute__((address_space(3))) float* ub = (__attribute__((address_space(3))) float*)(usp(S) + wave * 256);
+    const uint32_t su = __builtin_amdgcn_readfirstlane((uint32_t)(((nhalf * nchunks + chunk) * WF_UV) * 4));
+    const bool live = chunk < nchunks;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, ub + q * 2048, 16, live ? (uint32_t)((q * 512 + tid) * 16) : OOB_OFF, su,
+                                               0, 0);
+  };
+  // input transform: thread = (tile tt, channel tc, row pair hb); waves 0-3 (hb = 0) make rows 0,1 of B^T d B,
+  // waves 4-7 (hb = 1) rows 2,3.  hb is a compile-time constant of the loop each half runs (run(HB) below)
+  const int t8 = tid & 255;
+  const int tc = t8 & 3, ttx = (t8 >> 2) & 7, tty = t8 >> 5;
+  const int tt = tty * 8 + ttx;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  const int frow = lane & 31, khalf = lane >> 5;
+  const int aoff = (int)wf_uv_index(0, ph * 8, wm * 32 + frow, khalf * 2);
+  const int boff = (int)wf_uv_index(0, ph * 8, wn * 32 + frow, khalf * 2);
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  auto run = [&](auto HB) {
+    constexpr int hb = decltype(HB)::value;
+    const int roff = ((2 * tty + hb) * 18 + ttx) * 4 + tc;               // first of the three patch rows read
+    const int voffA = (int)wf_uv_index(0, (hb ? 3 : 0) * 4, tt, tc);     // V row made of e0 - e2
+    const int voffB = (int)wf_uv_index(0, (hb ? 2 : 1) * 4, tt, tc);     // V row made of e1 +- (e2 | e0)
+    constexpr int VJ[4] = {0, 2, 2 * 64 * 4, 2 * 64 * 4 + 2};            // positions r*4 + j relative to r*4
+    constexpr int RS[4] = {0, 9, 1, 10};                                  // slot of column 2*ttx + s relative to ttx
+    auto load_raw = [&](auto S, float (&e)[3][4]) {
+      const float* rp = rawp(S) + roff;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) e[i][s] = rp[(i * 18 + RS[s]) * 4];
+    };
+    auto write_v = [&](auto S, const float (&e)[3][4]) {
+      float ua[4], ub[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        ua[s] = e[0][s] - e[2][s];                              // rows 0 (hb = 0: d0 - d2) and 3 (hb = 1: d1 - d3)
+        ub[s] = hb ? e[1][s] - e[0][s] : e[1][s] + e[2][s];     // rows 1 (d1 + d2) and 2 (d2 - d1)
+      }
+      float* va = vsp(S) + voffA;
+      float* vb = vsp(S) + voffB;
+      va[VJ[0]] = ua[0] - ua[2];
+      va[VJ[1]] = ua[1] + ua[2];
+      va[VJ[2]] = ua[2] - ua[1];
+      va[VJ[3]] = ua[1] - ua[3];
+      vb[VJ[0]] = ub[0] - ub[2];
+      vb[VJ[1]] = ub[1] + ub[2];
+      vb[VJ[2]] = ub[2] - ub[1];
+      vb[VJ[3]] = ub[1] - ub[3];
+    };
+    auto mfmas = [&](auto S) {
+      const float* va = vsp(S) + aoff;
+      const float* ub = usp(S) + boff;
+      float4 a4[4], b4[4];   // positions 2i, 2i+1 of this wave's eight: (k-step 0, k-step 1) each
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a4[i] = *(const float4*)(va + i * 2 * 64 * 4);
+        b4[i] = *(const float4*)(ub + i * 2 * 64 * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[i].x, acc[2 * i], 0, 0, 0);
+        acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[i].z, acc[2 * i + 1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[i].y, acc[2 * i], 0, 0, 0);
+        acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[i].w, acc[2 * i + 1], 0, 0, 0);
+      }
+    };
+    // iteration c: raw(c+1) and U(c) have landed (issued two iterations ago), barrier, issue raw(c+3) and U(c+2)
+    // into the stages everybody has just finished with, MFMAs of chunk c, transform of chunk c+1.  The wait
+    // covers this wave's own V stores (lgkmcnt) as __syncthreads would.  The order INSIDE the body is hipcc's:
+    // it spreads the LDS reads between the MFMAs and carries half of them across the barrier.  Four
+    // hand-placed orders (sched_barrier fences) were all slower, 45.9-46.4 against 43.5-44.6 ms/step:
+    // every LDS read right after the barrier with the transform between or after the MFMA groups, the
+    // second k-step held back across the barrier, and the two waves of a SIMD in opposite phase order
+    // (profiles/README.md).  A 4-wave form on 16 x 8 pixel patches (76 KB of LDS, two unsynchronised
+    // workgroups per CU covering each other's barrier waits, prologue and epilogue) measured the same:
+    // 43.4 against 43.0 ms/step; so did 16 x 8 patches x 128 output channels per workgroup (half the
+    // transform and patch DMA per MFMA): 44.7 against 44.1.
+    auto body = [&](int c, auto S, auto Sn, auto Snn) {
+      asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_raw(c + 3, S);
+      issue_u(c + 2, Snn);
+      float e[3][4];
+      load_raw(Sn, e);
+      mfmas(S);
+      write_v(Sn, e);
+    };
+    {
+      float e[3][4];
+      load_raw(S0{}, e);
+      write_v(S0{}, e);
+    }
+    for (int c = 0; c < nchunks; c += 3) {
+      body(c, S0{}, S1{}, S2{});
+      body(c + 1, S1{}, S2{}, S0{});
+      body(c + 2, S2{}, S0{}, S1{});
+    }
+  };
+  issue_raw(0, S0{});
+  issue_u(0, S0{});
+  issue_raw(1, S1{});
+  issue_u(1, S1{});
+  issue_raw(2, S2{});
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // raw(0) (and U(0)) landed
+  __builtin_amdgcn_s_barrier();
+  if (ph == 0) {
+    run(std::integral_constant<int, 0>{});
+  } else {
+    // the second-dispatched half of the workgroup loses every issue arbitration against its (older) SIMD
+    // partner; one static priority raise for the whole loop evens that out (MI355X_MICROARCH.md, two waves
+    // per SIMD, item 4)
+    __builtin_amdgcn_s_setprio(1);   // 42.8 against 42.95 ms/step
+    run(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_s_setprio(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (out-of-range, zero) DMAs still write LDS
+  __builtin_amdgcn_s_barrier();
+
+  // output transform: Y = A^T m A is linear in the rows of m, so each wave forms the partial 2x2 outputs of
+  // its two rows; the pair (ph = 0, 1) of a (wm, wn) tile swaps halves (r < 8 / r >= 8) through LDS
+  float* exb = (wm * 2 + wn) == 0 ? vs_0 : (wm * 2 + wn) == 1 ? vs_1 : (wm * 2 + wn) == 2 ? vs_2 : us_0;
+  float4* ex = (float4*)exb;
+  float4 part[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float q0[4], q1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (ph == 0) {   // rows 0, 1
+        q0[s] = acc[s][r] + acc[4 + s][r];
+        q1[s] = acc[4 + s][r];
+      } else {         // rows 2, 3
+        q0[s] = acc[s][r];
+        q1[s] = -acc[s][r] - acc[4 + s][r];
+      }
+    }
+    part[r] = make_float4(q0[0] + q0[1] + q0[2], q0[1] - q0[2] - q0[3], q1[0] + q1[1] + q1[2], q1[1] - q1[2] - q1[3]);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if ((r >> 3) != ph) ex[(ph * 8 + (r & 7)) * 64 + lane] = part[r];
+  __syncthreads();
+  const int n = n0 + wn * 32 + (lane & 31);
+  const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if ((r >> 3) != ph) continue;
+    const float4 o = ex[((1 - ph) * 8 + (r & 7)) * 64 + lane];
+    const int t = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int ty = t >> 3, tx = t & 7;
+    const int64_t pix = ((int64_t)b * H + y0 + 2 * ty) * W + x0 + 2 * tx;
+    float o00 = part[r].x + o.x + bv, o01 = part[r].y + o.y + bv, o10 = part[r].z + o.z + bv,
+          o11 = part[r].w + o.w + bv;
+    if (res) {
+      o00 += res[pix * ldres + n];
+      o01 += res[(pix + 1) * ldres + n];
+      o10 += res[(pix + W) * ldres + n];
+      o11 += res[(pix + W + 1) * ldres + n];
+    }
+    y[pix * N + n] = o00;
+    y[(pix + 1) * N + n] = o01;
+    y[(pix + W) * N + n] = o10;
+    y[(pix + W + 1) * N + n] = o11;
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same convolution with GroupNorm (+ FiLM) + SiLU applied ON THE WAY IN: x is the raw block input, ab
+// holds the per-(image, channel) affine the normalisation folds to (launch_gn_fold: y = SiLU(A x + B)).
+// The activated map is never written to HBM (gn_apply_silu moved 2 x the map per layer).
+//
+// The activation is applied once per patch pixel, not once per tile that uses it (a pixel is in up to 4
+// tiles): every thread activates 2-3 values of the raw patch in place in LDS, one pipeline stage before the
+// transform reads them, so the raw patch has 4 stages here (DMA lands -> activate -> transform), U has 4
+// (stage = chunk % 4, static indices as above) and V 3 with a run-time index (V is never a DMA target, so
+// hipcc needs no static index to keep its vmcnt waits away).  Cost probe (kd_conv_bench variant 59): the
+// 21 VALU + 6 LDS instructions per thread and chunk add 4 % to the kernel, the apply pass they replace was
+// 14 % of conv + apply.  Zero padding: the pixel's slot is known to be outside the image -> 0 after the
+// activation as well.
+constexpr int WG_MAXC = 512;   // channels of the affine table kept in LDS (eight-wave kernel)
+constexpr int WG16_MAXC = 2048;   // ... sixteen-wave kernel
+
+// Two V stages with compile-time indices (the single barrier per chunk already orders the last reads of V(c) before
+// the first writes of V(c + 2)); the steady-state loop iterations run without the DMA liveness selects, interior
+// patches without the padding mask.  (Measured and dropped, profiles/README.md: the chunk's DMA pieces issued later
+// in the body; three V stages with a run-time index; every other / no barrier in the loop - a timing ablation with
+// wrong results - changed the time by -2 % / 0 %: the loop does not wait for its barriers.)
+__global__ __launch_bounds__(512, 1) void wino_fused_gn_kernel(const float* __restrict__ x, int ldx,
+                                                               const float* __restrict__ ab,
+                                                               const float* __restrict__ U,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ res, int ldres,
+                                                               float* __restrict__ y, int B, int H, int W, int C,
+                                                               int N, double* __restrict__ opart, int oG) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(1024))) float raw_0[WF_RAW], raw_1[WF_RAW], raw_2[WF_RAW], raw_3[WF_RAW];
+  __shared__ __attribute__((aligned(1024))) float us_0[WF_UV], us_1[WF_UV], us_2[WF_UV], us_3[WF_UV];
+  __shared__ __attribute__((aligned(1024))) float vs[2 * WF_UV];
+  __shared__ __attribute__((aligned(16))) float abl[2 * WG_MAXC];
+  auto rawp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return raw_0; else if constexpr (decltype(S)::value == 1) return raw_1; else if constexpr (decltype(S)::value == 2) return raw_2; else return raw_3; };
+  auto usp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return us_0; else if constexpr (decltype(S)::value == 1) return us_1; else if constexpr (decltype(S)::value == 2) return us_2; else return us_3; };
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int pw = W / 16, ph_ = H / 16;
+  const int nh = N / 64;
+  const int npatch = B * pw * ph_;
+  int bpatch, nhalf;
+  if ((npatch & 7) == 0) {   // the N/64 workgroups of one patch back to back on ONE XCD
+    const int id = blockIdx.x;
+    bpatch = (id / (8 * nh)) * 8 + (id & 7);
+    nhalf = (id >> 3) % nh;
+  } else {
+    bpatch = blockIdx.x / nh;
+    nhalf = blockIdx.x % nh;
+  }
+  const int b = bpatch / (pw * ph_);
+  const int prem = bpatch - b * pw * ph_;
+  const int y0 = (prem / pw) * 16, x0 = (prem % pw) * 16;
+  const int n0 = nhalf * 64;
+  const int nchunks = C / WF_K;
+
+  // the affine table of this image (C <= 512 pairs): loaded before the DMAs are issued, stored after
+  float2 abv = make_float2(0.f, 0.f);
+  if (tid < C) abv = ((const float2*)ab)[(int64_t)b * C + tid];
+
+  // x may be a channel slice of a wider map (row stride ldx >= C): a skip tensor inside its concat buffer
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)b * H * W * ldx), 0,
+                                                                       (int)((int64_t)H * W * ldx * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU =
+      __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, (int)((int64_t)16 * N * C * 4), 0x00020000);
+
+  // patch slot -> pixel (columns permuted as in wino_fused_kernel); in_image(slot) also tells the activation
+  // which of its values are padding
+  auto slot_pixel = [&](int slot, int& iy, int& ix) {
+    int py = slot / 18, pq = slot - py * 18;
+    int px = pq < 9 ? 2 * pq : 2 * (pq - 9) + 1;
+    iy = y0 - 1 + py;
+    ix = x0 - 1 + px;
+    return slot < 324 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+  };
+  uint32_t voffX;
+  {
+    int iy, ix;
+    const bool ok = slot_pixel(tid, iy, ix);
+    voffX = ok ? (uint32_t)(((iy * W + ix) * ldx) * 4) : OOB_OFF;
+  }
+  // activation: values tid, tid + 512, tid + 1024 of the 324 x 4 patch floats; channel tid & 3, slots (tid >> 2) + 128 i
+  bool aok[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int iy, ix;
+    aok[i] = slot_pixel((tid >> 2) + 128 * i, iy, ix);
+  }
+  // LIVE (compile time): the chunk is known to exist - no select against the out-of-range offset that turns the
+  // DMA of a chunk past the end into zeros (the steady-state iterations of the loop)
+  auto issue_raw = [&](int chunk, auto S, auto LIVE) {
+    __attribute__((address_space(3))) float* rb = (__attribute__((address_space(3))) float*)(rawp(S) + wave * 256);
+    const uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t)(chunk * WF_K * 4));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, rb, 16, (decltype(LIVE)::value || chunk < nchunks) ? voffX : OOB_OFF, sx,
+                                             0, 0);
+  };
+  auto issue_u = [&](int chunk, auto S, auto LIVE) {
+    __attribute__((address_space(3))) float* ub = (__attribute__((address_space(3))) float*)(usp(S) + wave * 256);
+    const uint32_t su = __builtin_amdgcn_readfirstlane((uint32_t)(((nhalf * nchunks + chunk) * WF_UV) * 4));
+    const bool live = decltype(LIVE)::value || chunk < nchunks;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, ub + q * 2048, 16, live ? (uint32_t)((q * 512 + tid) * 16) : OOB_OFF, su,
+                                               0, 0);
+  };
+  // MASK (compile time): the patch touches the image border, values of padding pixels are forced back to 0
+  auto activate = [&](int chunk, auto S, auto LIVE, auto MASK) {
+    const int cc = (decltype(LIVE)::value ? chunk : min(chunk, nchunks - 1)) * WF_K + (tid & 3);
+    const float2 a2 = *(const float2*)(abl + 2 * cc);
+    float* ap = rawp(S) + tid;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i < 2 || tid < 324 * 4 - 1024) {
+        // ab holds -log2(e) (A, B) (launch_gn_fold*), so u = -log2(e) v with v = A x + B, e^-v = 2^u, and
+        // u / (1 + 2^u) = -log2(e) SiLU(v): 5 VALU per value; the factor -ln 2 that is left sits in U (WF_U_SCALE)
+        const float u = ap[i * 512] * a2.x + a2.y;
+        const float v = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
+        ap[i * 512] = (!decltype(MASK)::value || aok[i]) ? v : 0.f;
+      }
+    }
+  };
+  const int t8 = tid & 255;
+  const int tc = t8 & 3, ttx = (t8 >> 2) & 7, tty = t8 >> 5;
+  const int tt = tty * 8 + ttx;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  const int frow = lane & 31, khalf = lane >> 5;
+  const int aoff = (int)wf_uv_index(0, ph * 8, wm * 32 + frow, khalf * 2);
+  const int boff = (int)wf_uv_index(0, ph * 8, wn * 32 + frow, khalf * 2);
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  using S3 = std::integral_constant<int, 3>;
+  using LiveT = std::integral_constant<bool, true>;
+  using LiveF = std::integral_constant<bool, false>;
+  auto run = [&](auto HB, auto MASK) {
+    constexpr int hb = decltype(HB)::value;
+    const int roff = ((2 * tty + hb) * 18 + ttx) * 4 + tc;
+    const int voffA = (int)wf_uv_index(0, (hb ? 3 : 0) * 4, tt, tc);
+    const int voffB = (int)wf_uv_index(0, (hb ? 2 : 1) * 4, tt, tc);
+    constexpr int VJ[4] = {0, 2, 2 * 64 * 4, 2 * 64 * 4 + 2};
+    constexpr int RS[4] = {0, 9, 1, 10};
+    auto load_raw = [&](auto S, float (&e)[3][4]) {
+      const float* rp = rawp(S) + roff;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) e[i][s] = rp[(i * 18 + RS[s]) * 4];
+    };
+    // the four store addresses of a V stage (two positions each, 2 KB apart: beyond ds_write2's offset field).
+    // With static stages they are loop invariants; the empty asm keeps hipcc from re-deriving them with a
+    // v_add_u32 per store pair and chunk (4 VALU per chunk = 0.4 ms per step: every VALU slot in this loop is
+    // taken from the fp32 MFMA pipe)
+    typedef __attribute__((address_space(3))) float lds_float;
+    lds_float* vaddr[2][4];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      vaddr[st][0] = (lds_float*)(vs + st * WF_UV + voffA);
+      vaddr[st][1] = (lds_float*)(vs + st * WF_UV + voffA + VJ[2]);
+      vaddr[st][2] = (lds_float*)(vs + st * WF_UV + voffB);
+      vaddr[st][3] = (lds_float*)(vs + st * WF_UV + voffB + VJ[2]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(vaddr[st][q]));
+    }
+    auto write_v = [&](const float (&e)[3][4], int vstage) {
+      float ua[4], ub[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        ua[s] = e[0][s] - e[2][s];
+        ub[s] = hb ? e[1][s] - e[0][s] : e[1][s] + e[2][s];
+      }
+      lds_float* va0 = vstage ? vaddr[1][0] : vaddr[0][0];
+      lds_float* va1 = vstage ? vaddr[1][1] : vaddr[0][1];
+      lds_float* vb0 = vstage ? vaddr[1][2] : vaddr[0][2];
+      lds_float* vb1 = vstage ? vaddr[1][3] : vaddr[0][3];
+      va0[0] = ua[0] - ua[2];
+      va0[2] = ua[1] + ua[2];
+      va1[0] = ua[2] - ua[1];
+      va1[2] = ua[1] - ua[3];
+      vb0[0] = ub[0] - ub[2];
+      vb0[2] = ub[1] + ub[2];
+      vb1[0] = ub[2] - ub[1];
+      vb1[2] = ub[1] - ub[3];
+    };
+    auto mfmas = [&](auto S, const float* vst) {
+      const float* va = vst + aoff;
+      const float* ub = usp(S) + boff;
+      float4 a4[4], b4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a4[i] = *(const float4*)(va + i * 2 * 64 * 4);
+        b4[i] = *(const float4*)(ub + i * 2 * 64 * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[i].x, acc[2 * i], 0, 0, 0);
+        acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[i].z, acc[2 * i + 1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[i].y, acc[2 * i], 0, 0, 0);
+        acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[i].w, acc[2 * i + 1], 0, 0, 0);
+      }
+    };
+    // iteration c (stages of chunk j: raw j % 4, U j % 4, V j % 2): raw(c+2) and U(c) have landed (issued two
+    // iterations ago), barrier, issue raw(c+4) and U(c+2), activate raw(c+2), MFMAs of chunk c, transform of
+    // raw(c+1) (activated one iteration ago) into V(c+1)
+    auto body = [&](int c, auto Sc, auto Sc1, auto Sc2, auto LIVE) {
+      asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_raw(c + 4, Sc, LIVE);
+      issue_u(c + 2, Sc2, LIVE);
+      constexpr int vcur = decltype(Sc)::value & 1;   // chunk c sits in raw / U stage c % 4: its parity is c's
+      float e[3][4];
+      load_raw(Sc1, e);
+      mfmas(Sc, vs + vcur * WF_UV);
+      activate(c + 2, Sc2, LIVE, MASK);
+      write_v(e, vcur ^ 1);
+    };
+    {
+      float e[3][4];
+      load_raw(S0{}, e);
+      write_v(e, 0);
+    }
+    int c = 0;
+    for (; c + 8 <= nchunks; c += 4) {   // steady state: every chunk these four bodies prefetch exists
+      body(c, S0{}, S1{}, S2{}, LiveT{});
+      body(c + 1, S1{}, S2{}, S3{}, LiveT{});
+      body(c + 2, S2{}, S3{}, S0{}, LiveT{});
+      body(c + 3, S3{}, S0{}, S1{}, LiveT{});
+    }
+    for (; c < nchunks; c += 4) {
+      body(c, S0{}, S1{}, S2{}, LiveF{});
+      body(c + 1, S1{}, S2{}, S3{}, LiveF{});
+      body(c + 2, S2{}, S3{}, S0{}, LiveF{});
+      body(c + 3, S3{}, S0{}, S1{}, LiveF{});
+    }
+  };
+  // prologue: the first five pieces stand in for "two iterations ago", the last three for "one iteration ago"
+  issue_raw(0, S0{}, LiveF{});
+  issue_u(0, S0{}, LiveF{});
+  issue_raw(1, S1{}, LiveF{});
+  issue_raw(2, S2{}, LiveF{});
+  issue_raw(3, S3{}, LiveF{});
+  issue_u(1, S1{}, LiveF{});
+  if (tid < C) *(float2*)(abl + 2 * tid) = abv;
+  asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // raw(0), U(0), raw(1) landed
+  __builtin_amdgcn_s_barrier();
+  activate(0, S0{}, LiveF{}, LiveT{});
+  activate(1, S1{}, LiveF{}, LiveT{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // interior patches (the whole 18 x 18 halo inside the image) run the loop without the padding mask
+  const bool border = y0 == 0 || x0 == 0 || y0 + 16 >= H || x0 + 16 >= W;
+  if (ph == 0) {
+    if (border) run(std::integral_constant<int, 0>{}, LiveT{});
+    else run(std::integral_constant<int, 0>{}, LiveF{});
+  } else {
+    __builtin_amdgcn_s_setprio(1);
+    if (border) run(std::integral_constant<int, 1>{}, LiveT{});
+    else run(std::integral_constant<int, 1>{}, LiveF{});
+    __builtin_amdgcn_s_setprio(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const int pair = wm * 2 + wn;
+  float4* ex = (float4*)(pair < 2 ? vs + pair * WF_UV : pair == 2 ? us_1 : us_0);
+  float4 part[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float q0[4], q1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (ph == 0) {
+        q0[s] = acc[s][r] + acc[4 + s][r];
+        q1[s] = acc[4 + s][r];
+      } else {
+        q0[s] = acc[s][r];
+        q1[s] = -acc[s][r] - acc[4 + s][r];
+      }
+    }
+    part[r] = make_float4(q0[0] + q0[1] + q0[2], q0[1] - q0[2] - q0[3], q1[0] + q1[1] + q1[2], q1[1] - q1[2] - q1[3]);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if ((r >> 3) != ph) ex[(ph * 8 + (r & 7)) * 64 + lane] = part[r];
+  __syncthreads();
+  const int n = n0 + wn * 32 + (lane & 31);
+  const float bv = bias ? bias[n] : 0.f;
+  double gs1 = 0.0, gs2 = 0.0;   // sum and sum of squares of this lane's outputs (GroupNorm of the NEXT layer)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if ((r >> 3) != ph) continue;
+    const float4 o = ex[((1 - ph) * 8 + (r & 7)) * 64 + lane];
+    const int t = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int ty = t >> 3, tx = t & 7;
+    const int64_t pix = ((int64_t)b * H + y0 + 2 * ty) * W + x0 + 2 * tx;
+    float o00 = part[r].x + o.x + bv, o01 = part[r].y + o.y + bv, o10 = part[r].z + o.z + bv,
+          o11 = part[r].w + o.w + bv;
+    if (res) {
+      o00 += res[pix * ldres + n];
+      o01 += res[(pix + 1) * ldres + n];
+      o10 += res[(pix + W) * ldres + n];
+      o11 += res[(pix + W + 1) * ldres + n];
+    }
+    y[pix * N + n] = o00;
+    y[(pix + 1) * N + n] = o01;
+    y[(pix + W) * N + n] = o10;
+    y[(pix + W + 1) * N + n] = o11;
+    if (opart) {
+      gs1 += ((double)o00 + (double)o01) + ((double)o10 + (double)o11);
+      gs2 += ((double)o00 * o00 + (double)o01 * o01) + ((double)o10 * o10 + (double)o11 * o11);
+    }
+  }
+  // GroupNorm statistics of y for the layer that reads it: one (sum, sum of squares) per wave and 16-channel
+  // segment, in the layout gn_finalize_kernel sums in a fixed order - that layer's statistics pass over y
+  // (a full read of the map) is not needed.  Groups are multiples of 16 channels (host check).
+  if (opart) {
+#pragma unroll
+    for (int off = 1; off <= 8; off <<= 1) {
+      gs1 += __shfl_xor(gs1, off, 64);
+      gs2 += __shfl_xor(gs2, off, 64);
+    }
+    gs1 += __shfl_xor(gs1, 32, 64);
+    gs2 += __shfl_xor(gs2, 32, 64);
+    if ((lane & 47) == 0) {   // lanes 0 and 16: channel segments 0 and 1 of this wave
+      const int Cg = N / oG;
+      const int cabs = n0 + wn * 32 + (lane & 16);
+      const int g = cabs / Cg, cseg = (cabs - g * Cg) >> 4;
+      const int npi = pw * ph_;
+      const int64_t chunks = (int64_t)(Cg >> 4) * npi * 4;
+      const int64_t entry = ((int64_t)cseg * npi + prem) * 4 + (wm * 2 + ph);
+      double* op = opart + (((int64_t)b * oG + g) * chunks + entry) * 2;
+      op[0] = gs1;
+      op[1] = gs2;
+    }
+  }
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------
 // The same kernel as SIXTEEN waves (four per SIMD, 64 accumulator registers each, <= 128 VGPRs).  With two waves
@@ -558,6 +1150,16 @@ int launch_wino_fused_pack(const float* w_oihw, float* U, int O, int I, hipStrea
   return 0;
 }
 
+int launch_wino_fused(const float* x, const float* U, const float* bias, const float* res, int ldres, float* y, int B,
+                      int H, int W, int C, int N, hipStream_t s) {
+  KD_REQUIRE(wino_fused_ok(B, H, W, C, N),
+             "fused Winograd conv needs H, W % 16 == 0, Cin % 4 == 0, Cout % 64 == 0 and maps below 2 GB per image");
+  const unsigned grid = (unsigned)((int64_t)B * (H / 16) * (W / 16) * (N / 64));
+  hipLaunchKernelGGL(wino_fused_kernel, dim3(grid), dim3(512), 0, s, x, U, bias, res, ldres, y, B, H, W, C, N);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 // ab[b][c] = (A, B) with GroupNorm(+FiLM)(x)[b][c] = A x + B (same arithmetic as gn_apply_silu_kernel)
 __global__ __launch_bounds__(256) void gn_fold_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta,
@@ -589,10 +1191,18 @@ int launch_gn_fold(const float* stats, const float* gamma, const float* beta, co
   return 0;
 }
 
-int wino_fused_gn_max_cin() { return WG16_MAXC; }
+// Which form launch_wino_fused_gn runs.  Default 16: sixteen waves, persistent workgroups.  KD_FWINO_VAR (read
+// once, for A/B measurements): 17 = sixteen waves, one item per workgroup; 8 = the eight-wave kernel.
+static int fwino_var() {
+  static const int var = getenv("KD_FWINO_VAR") ? atoi(getenv("KD_FWINO_VAR")) : 16;
+  return var;
+}
+static bool fwino_16() { return fwino_var() != 8; }
+
+int wino_fused_gn_max_cin() { return fwino_16() ? WG16_MAXC : WG_MAXC; }
 
 size_t wino_fused_out_stats_chunks(int H, int W, int N, int G) {
-  return (size_t)(N / G / 16) * (H / 16) * (W / 16) * 8;
+  return (size_t)(N / G / 16) * (H / 16) * (W / 16) * (fwino_16() ? 8 : 4);
 }
 
 int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* U, const float* bias, const float* res,
@@ -600,12 +1210,13 @@ int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* 
                          const void* items, hipStream_t s) {
   KD_REQUIRE(ldx >= C && ldx % 4 == 0 && (int64_t)H * W * ldx * 4 < 0x7fffffff && ((uintptr_t)x & 15) == 0,
              "GroupNorm-fused Winograd conv: bad input row stride");
-  KD_REQUIRE(wino_fused_ok(B, H, W, C, N) && C <= WG16_MAXC,
+  KD_REQUIRE(wino_fused_ok(B, H, W, C, N) && C <= (fwino_16() ? WG16_MAXC : WG_MAXC),
              "GroupNorm-fused Winograd conv needs H, W % 16 == 0, Cin % 4 == 0, Cin <= 2048, Cout % 64 == 0");
   KD_REQUIRE(!out_partial || (out_groups > 0 && N % out_groups == 0 && (N / out_groups) % 16 == 0),
              "output statistics need groups of a multiple of 16 channels");
   const unsigned grid = (unsigned)((int64_t)B * (H / 16) * (W / 16) * (N / 64));
-  {
+  const int var = fwino_var();
+  if (fwino_16()) {
     KD_REQUIRE(((uintptr_t)y & 15) == 0 && ((uintptr_t)bias & 15) == 0 && ((uintptr_t)res & 15) == 0 && ldres % 4 == 0,
                "GroupNorm-fused Winograd conv: output, bias and residual rows must be 16-byte aligned");
     KD_REQUIRE(items != nullptr, "GroupNorm-fused Winograd conv: item table missing (launch_wino_fused_items)");
@@ -619,9 +1230,9 @@ int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* 
       KD_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
       cus = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 8;   // a multiple of the 8 XCDs
     }
-    const unsigned pgrid = grid < (unsigned)cus ? grid : (unsigned)cus;   // persistent: one workgroup per CU
+    const unsigned pgrid = var == 17 || grid < (unsigned)cus ? grid : (unsigned)cus;
 #ifdef KD_FWINO_STAMP_BUILD   // diagnostic library only (make EXTRA=-DKD_FWINO_STAMP_BUILD): not in the product build
-    static const bool stamping = kd_switch("KD_FWINO_STAMP", 0) != 0;   // (build with EXTRA="-DKD_FWINO_STAMP_BUILD -DKD_EXPERIMENT")
+    static const bool stamping = getenv("KD_FWINO_STAMP") && atoi(getenv("KD_FWINO_STAMP")) != 0;
     if (stamping) {   // diagnostic: per-phase cycle counts of the first items of every workgroup, printed to stderr
       const size_t n = (size_t)pgrid * 2 * 8 * 8;
       long long* d = nullptr;
@@ -660,6 +1271,10 @@ int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* 
     KD_HIP_CHECK(hipGetLastError());
     return 0;
   }
+  hipLaunchKernelGGL(wino_fused_gn_kernel, dim3(grid), dim3(512), 0, s, x, ldx, ab, U, bias, res, ldres, y, B, H, W, C, N,
+                     out_partial, out_groups);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 }  // namespace kd

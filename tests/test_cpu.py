@@ -204,6 +204,71 @@ def test_reference_style_construction_and_checkpoint_roundtrip(tmp_path):
         tr.train_step(unet_number=1)
 
 
+@pytest.mark.parametrize("name", ["small1", "small2", "ultra1"])
+def test_checkpoints_of_the_neighbouring_library_forks_load_strictly(name):
+    """SURVEY A.1 lists two STRUCTURAL forks between library versions besides the attention similarity: Downsample as
+    pixel-unshuffle + 1x1 conv vs Conv2d(4, stride 2, pad 1), and mid_attn as a TransformerBlock vs a bare residual
+    attention.  A checkpoint names its fork through its keys and shapes; the drop-in Unet follows it, so the strict
+    load of sample_ultra_res.py:59 succeeds instead of falling into restore_parts half-loaded."""
+    from imagen_pytorch import Unet
+
+    kw = dict(H.UNET_KW[name], cond_on_text=False, text_embed_dim=None)
+    for forms in (dict(downsample_form="conv4x4"), dict(mid_attn_form="residual_attention"),
+                  dict(downsample_form="conv4x4", mid_attn_form="residual_attention")):
+        old = H.randomize_(R.Unet(**kw, **forms), 5)
+        sd = old.state_dict()
+        if "downsample_form" in forms:
+            ds = [k for k, v in sd.items() if re.fullmatch(r"downs\.\d+\.[04]\.weight", k)]
+            assert ds and all(sd[k].shape[-2:] == (4, 4) for k in ds) and not any(re.fullmatch(r"downs\.\d+\.[04]\.1\.weight", k) for k in sd)
+        if "mid_attn_form" in forms:
+            assert "mid_attn.fn.fn.to_q.weight" in sd and not any(k.startswith("mid_attn.layers") for k in sd)
+        # a default-built product Unet and a default-built oracle both follow the checkpoint
+        for cls in (Unet, R.Unet):
+            u = cls(**kw)
+            u.load_state_dict(sd, strict=True)
+            assert u.downsample_form == forms.get("downsample_form", "unshuffle")
+            assert u.mid_attn_form == forms.get("mid_attn_form", "transformer")
+            assert list(u.state_dict().keys()) == list(sd.keys())
+            assert all(torch.equal(a, b) for a, b in zip(u.state_dict().values(), sd.values()))
+            # ... and back again with a checkpoint of the default fork
+            new = R.Unet(**kw).state_dict()
+            u.load_state_dict(new, strict=True)
+            assert (u.downsample_form, u.mid_attn_form) == ("unshuffle", "transformer")
+            assert list(u.state_dict().keys()) == list(new.keys())
+        # the oracle's function really differs between the forks (no silent aliasing of the two module trees)
+        x, t = torch.randn(1, 3, 16, 16), torch.randn(1)
+        cond = torch.rand(1, 3, 16, 16) if kw.get("cond_images_channels") else None
+        with torch.no_grad():
+            a = old.eval()(x, t, cond_images=cond)
+        assert torch.isfinite(a).all()
+
+
+def test_qk_norm_fallback_follows_the_constructor():
+    """A checkpoint without q_scale / k_scale resets a Unet that had switched to learned qk-norm - back to what the
+    CONSTRUCTOR asked for (cosine_sim_attn=True stays cosine-sim), and a Unet built explicitly with attn_qk_norm=2
+    keeps it: torch reports the missing keys (an error under strict=True)."""
+    from imagen_pytorch import Unet
+
+    kw = dict(H.UNET_KW["small1"], cond_on_text=False, text_embed_dim=None)
+    with_scales = R.Unet(**kw, attn_qk_norm=2).state_dict()
+    without = R.Unet(**kw).state_dict()
+    u = Unet(**kw, cosine_sim_attn=True)
+    assert u.attn_qk_norm == 1
+    u.load_state_dict(with_scales, strict=True)
+    assert u.attn_qk_norm == 2
+    u.load_state_dict(without, strict=True)
+    assert u.attn_qk_norm == 1, "cosine_sim_attn=True must survive a checkpoint without q_scale"
+    u0 = Unet(**kw)
+    u0.load_state_dict(with_scales, strict=True)
+    u0.load_state_dict(without, strict=True)
+    assert u0.attn_qk_norm == 0
+    u2 = Unet(**kw, attn_qk_norm=2)
+    with pytest.raises(RuntimeError, match="q_scale"):   # torch's own "Missing key(s)" report
+        u2.load_state_dict(without, strict=True)
+    missing, unexpected = u2.load_state_dict(without, strict=False)
+    assert u2.attn_qk_norm == 2 and missing and all(k.endswith(("q_scale", "k_scale")) for k in missing) and not unexpected
+
+
 def test_restore_parts_reports_what_it_could_not_load_and_unets_deepcopy():
     """A checkpoint from another library version must not be half-loaded silently (sample_ultra_res.py:59-63
     falls back to restore_parts on any RuntimeError of the strict load)."""
@@ -267,7 +332,7 @@ def test_library_loads_and_exports_every_symbol_the_header_declares():
         assert hasattr(lib, sym), f"libkd_engine.so does not export {sym}"
     assert set(E.SIGNATURES) == declared, "ctypes table and header disagree"
     assert lib.kd_version() == 1
-    assert C.sizeof(E.kd_unet_config_t) == 4 * (2 + 4 * E.KD_MAX_LEVELS + 20)  # ints only, header order
+    assert C.sizeof(E.kd_unet_config_t) == 4 * (2 + 4 * E.KD_MAX_LEVELS + 22)  # ints only, header order
     assert lib.kd_quantile_workspace_bytes(4) == 4 * 16 + 4 * 4 * 256 * 4
 
 

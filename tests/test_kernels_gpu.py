@@ -37,6 +37,8 @@ CONV_REL = 2e-6
     (3, 9, 7, 36, 40, 3, 1, 1, 1),        # ragged sizes, Cin not /32, Cout not /32, SiLU
     (2, 16, 16, 64, 96, 1, 1, 0, 2),      # 1x1 + GELU
     (2, 16, 16, 32, 48, 2, 2, 0, 0),      # 2x2 stride 2 (pixel-unshuffle downsample)
+    (2, 32, 32, 64, 128, 4, 2, 1, 0),     # 4x4 stride 2 pad 1: the Downsample of earlier library versions (fast path)
+    (1, 10, 14, 12, 24, 4, 2, 1, 0),      # ... ragged, generic path
     (1, 20, 20, 12, 16, 7, 1, 3, 0),      # init-conv shapes: tiny Cin, wide window
     (1, 20, 20, 12, 16, 15, 1, 7, 0),
     (2, 8, 8, 132, 3, 3, 1, 1, 0),        # final conv: Cout = 3
@@ -173,55 +175,26 @@ def test_conv3x3_winograd_rejects_unsupported_shapes(lib, device):
     assert rc != 0 and b"even" in lib.kd_last_error()
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,res", [
-    (2, 64, 64, 128, 128, False),   # the SR UNet's top level, scaled down: 32 patches x 2 channel halves
-    (1, 16, 16, 128, 64, True),     # ONE patch: every side is zero padding; residual in the epilogue
-    (3, 32, 48, 20, 192, True),     # 5 chunks (not a multiple of the 3 pipeline stages), 3 channel slabs, H != W
-    (1, 48, 16, 4, 64, False),      # a single 4-channel chunk
-    (2, 32, 32, 256, 128, False),   # 64 chunks
+@pytest.mark.parametrize("B,H,W,Cin,Cout,G,film,res,ldx", [
+    (2, 64, 64, 128, 128, 8, True, False, 0),    # FiLM, 32 chunks (a multiple of the 4 pipeline stages)
+    (1, 16, 16, 128, 64, 8, False, True, 0),     # one patch: every side is padding (must stay 0 after the activation)
+    (3, 32, 48, 40, 192, 2, True, True, 0),      # 10 chunks (padded to 12), 3 channel slabs, H != W
+    (1, 48, 16, 8, 64, 2, False, False, 0),      # 2 chunks
+    (2, 32, 32, 512, 128, 8, True, False, 0),    # 128 chunks, one 128-channel slab
+    (6, 64, 64, 64, 256, 8, True, True, 0),      # 128-channel items: 384 items on 256 persistent workgroups (a second item per
+                                                 # workgroup: prefetch under the epilogue, table written behind the exchange)
+    (1, 16, 32, 68, 128, 1, False, True, 0),     # 17 chunks: one steady trip of 12 + a guarded remainder of 5; every patch a border
+    (1, 32, 32, 1056, 128, 8, True, False, 0),   # affine table beyond 1024 channels (second half), 264 chunks
+    (20, 64, 64, 32, 64, 8, False, True, 0),     # 64-channel items: 320 items on 256 persistent workgroups
+    (1, 16, 16, 8, 128, 2, False, False, 0),     # 128-channel items: two items, two chunks (shorter than the pipeline's prefetch)
+    (2, 16, 48, 12, 256, 1, True, True, 0),      # three chunks, four slabs of 64 ... as two of 128; W = 3 patches
+    (2, 32, 32, 128, 128, 8, True, True, 384),   # STRIDED input: a 128-channel slice at channel offset 128 of 384-float rows
+                                                 # (a skip tensor living in its concat buffer); 128-channel items
+    (1, 32, 32, 96, 64, 8, False, False, 224),   # strided input, 64-channel items, row stride not a multiple of the slice
+    (1, 16, 32, 2048, 128, 8, True, False, 0),   # Cin = 2048: the whole affine table in LDS (the 16x16 level's first conv), 512 chunks
+    (2, 16, 16, 2048, 256, 8, False, True, 3072),  # Cin = 2048 read through a 3072-float row stride
 ])
-def test_conv3x3_winograd_fused_matches_direct(lib, device, B, H, W, Cin, Cout, res):
-    E = _E()
-    x = torch.randn(B, Cin, H, W, generator=g(1))
-    w = torch.randn(Cout, Cin, 3, 3, generator=g(2)) * (Cin * 9) ** -0.5
-    b = torch.randn(Cout, generator=g(3))
-    r = torch.randn(B, Cout, H, W, generator=g(4)) if res else None
-    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
-    if res:
-        ref = ref + r.double()
-    xd = x.permute(0, 2, 3, 1).contiguous().to(device)
-    wd, bd = w.to(device), b.to(device)
-    rd = r.permute(0, 2, 3, 1).contiguous().to(device) if res else None
-    y = torch.full((B, H, W, Cout), float("nan"), device=device)
-    E.check(lib.kd_conv3x3_winograd_fused_nhwc(E.ptr(xd), E.ptr(wd), E.ptr(bd), E.ptr(rd) if res else None, E.ptr(y),
-                                               B, H, W, Cin, Cout, E.current_stream()))
-    got = y.permute(0, 3, 1, 2).cpu().double()
-    assert torch.isfinite(got).all()
-    err = float((got - ref).norm() / ref.norm())
-    assert err <= WINO_REL, err
-    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), "element-wise outlier"
-    # a second call is bit-identical (no atomics, fixed summation order)
-    y2 = torch.empty_like(y)
-    E.check(lib.kd_conv3x3_winograd_fused_nhwc(E.ptr(xd), E.ptr(wd), E.ptr(bd), E.ptr(rd) if res else None, E.ptr(y2),
-                                               B, H, W, Cin, Cout, E.current_stream()))
-    assert torch.equal(y, y2)
-
-
-@pytest.mark.parametrize("B,H,W,Cin,Cout,G,film,res", [
-    (2, 64, 64, 128, 128, 8, True, False),    # FiLM, 32 chunks (a multiple of the 4 pipeline stages)
-    (1, 16, 16, 128, 64, 8, False, True),     # one patch: every side is padding (must stay 0 after the activation)
-    (3, 32, 48, 40, 192, 2, True, True),      # 10 chunks (padded to 12), 3 channel slabs, H != W
-    (1, 48, 16, 8, 64, 2, False, False),      # 2 chunks
-    (2, 32, 32, 512, 128, 8, True, False),    # 128 chunks, one 128-channel slab
-    (6, 64, 64, 64, 256, 8, True, True),      # 128-channel items: 384 items on 256 persistent workgroups (a second item per
-                                              # workgroup: prefetch under the epilogue, table written behind the exchange)
-    (1, 16, 32, 68, 128, 1, False, True),     # 17 chunks: one steady trip of 12 + a guarded remainder of 5; every patch a border
-    (1, 32, 32, 1056, 128, 8, True, False),   # affine table beyond 1024 channels (second half), 264 chunks
-    (20, 64, 64, 32, 64, 8, False, True),     # 64-channel items: 320 items on 256 persistent workgroups
-    (1, 16, 16, 8, 128, 2, False, False),     # 128-channel items: two items, two chunks (shorter than the pipeline's prefetch)
-    (2, 16, 48, 12, 256, 1, True, True),      # three chunks, four slabs of 64 ... as two of 128; W = 3 patches
-])
-def test_gn_conv3x3_winograd_fused_matches_torch(lib, device, B, H, W, Cin, Cout, G, film, res):
+def test_gn_conv3x3_winograd_fused_matches_torch(lib, device, B, H, W, Cin, Cout, G, film, res, ldx):
     """ResnetBlock `Block` = conv3x3(SiLU(FiLM(GroupNorm(x)))) with the activation applied to the raw patch in
     LDS inside the fused Winograd kernel (hardware exp2 / reciprocal: ~1 ulp each)."""
     E = _E()
@@ -239,6 +212,13 @@ def test_gn_conv3x3_winograd_fused_matches_torch(lib, device, B, H, W, Cin, Cout
     if res:
         ref = ref + r.double()
     xd = x.permute(0, 2, 3, 1).contiguous().to(device)
+    if ldx:   # the kernel's input is channels [c0, c0 + Cin) of rows of ldx floats; the other channels hold junk
+        c0 = min(128, (ldx - Cin) // 4 * 4)
+        wide = torch.full((B, H, W, ldx), 1e30, device=device)
+        wide[..., c0:c0 + Cin] = xd
+        xd = wide[..., c0:]          # data_ptr at channel c0 of row 0; the tensor itself is only a pointer carrier
+        assert xd.data_ptr() % 16 == 0
+    xptr = C.c_void_p(xd.data_ptr())
     gd, bed, wd, bd = gamma.to(device), beta.to(device), w.to(device), b.to(device)
     ssd = ss.to(device) if film else None
     rd = r.permute(0, 2, 3, 1).contiguous().to(device) if res else None
@@ -247,9 +227,9 @@ def test_gn_conv3x3_winograd_fused_matches_torch(lib, device, B, H, W, Cin, Cout
     Go = 8 if (Cout // 8) % 16 == 0 else 0
     ostats = torch.full((B, max(Go, 1), 2), float("nan"), device=device)
     call = lambda out: E.check(lib.kd_gn_conv3x3_winograd_fused_nhwc(
-        E.ptr(xd), E.ptr(gd), E.ptr(bed), E.ptr(ssd) if film else None, E.ptr(wd), E.ptr(bd),
+        xptr, E.ptr(gd), E.ptr(bed), E.ptr(ssd) if film else None, E.ptr(wd), E.ptr(bd),
         E.ptr(rd) if res else None, E.ptr(out), B, H, W, Cin, Cout, G, 1e-5, E.ptr(ostats) if Go and G == 8 else None,
-        E.current_stream()))
+        ldx, E.current_stream()))
     call(y)
     if Go and G == 8:
         grp = ref.reshape(B, Go, -1)
@@ -268,36 +248,43 @@ def test_gn_conv3x3_winograd_fused_matches_torch(lib, device, B, H, W, Cin, Cout
     assert torch.equal(y, y2)
 
 
-def test_conv3x3_winograd_fused_at_benchmark_size_is_repeatable(lib, device):
-    """The SR UNet's top level at the benchmark's batch (16 x 256 x 256 x 128 -> 128: 2048 workgroups, 8 rounds
-    per CU): repeated launches are bit-identical (no race between the DMA stages, the V stores and the
-    barriers shows up under full occupancy) and image 0 matches an fp64 convolution."""
+def test_gn_conv3x3_winograd_fused_at_benchmark_size_is_repeatable(lib, device):
+    """The SR UNet's top level at the benchmark's batch (16 x 256 x 256 x 128 -> 128: 8192 items of 16 x 8 pixels on
+    256 persistent workgroups, 32 items each): repeated launches are bit-identical (no race between the DMA stages, the
+    V stores, the exchange and the barriers shows up under full occupancy) and image 0 matches an fp64 reference."""
     E = _E()
-    B, H, W, Cin, Cout = 16, 256, 256, 128, 128
+    B, H, W, Cin, Cout, G = 16, 256, 256, 128, 128, 8
     gd = torch.Generator(device=device).manual_seed(5)
     x = torch.randn(B, H, W, Cin, device=device, generator=gd)
     w = torch.randn(Cout, Cin, 3, 3, device=device, generator=gd) * (Cin * 9) ** -0.5
     b = torch.randn(Cout, device=device, generator=gd)
+    gamma = 1 + 0.2 * torch.randn(Cin, device=device, generator=gd)
+    beta = 0.2 * torch.randn(Cin, device=device, generator=gd)
+    call = lambda out: E.check(lib.kd_gn_conv3x3_winograd_fused_nhwc(
+        E.ptr(x), E.ptr(gamma), E.ptr(beta), None, E.ptr(w), E.ptr(b), None, E.ptr(out), B, H, W, Cin, Cout, G, 1e-5, None,
+        0, E.current_stream()))
     y0 = torch.empty(B, H, W, Cout, device=device)
-    E.check(lib.kd_conv3x3_winograd_fused_nhwc(E.ptr(x), E.ptr(w), E.ptr(b), None, E.ptr(y0), B, H, W, Cin, Cout,
-                                               E.current_stream()))
+    call(y0)
     y = torch.empty_like(y0)
     for _ in range(8):
         y.fill_(float("nan"))
-        E.check(lib.kd_conv3x3_winograd_fused_nhwc(E.ptr(x), E.ptr(w), E.ptr(b), None, E.ptr(y), B, H, W, Cin, Cout,
-                                                   E.current_stream()))
+        call(y)
         assert torch.equal(y, y0)
-    ref = F.conv2d(x[:1].permute(0, 3, 1, 2).cpu().double(), w.cpu().double(), b.cpu().double(), padding=1)
+    x0 = x[:1].permute(0, 3, 1, 2).cpu().double()
+    h = F.silu(F.group_norm(x0, G, gamma.cpu().double(), beta.cpu().double(), eps=1e-5))
+    ref = F.conv2d(h, w.cpu().double(), b.cpu().double(), padding=1)
     got = y0[:1].permute(0, 3, 1, 2).cpu().double()
     assert float((got - ref).norm() / ref.norm()) <= WINO_REL
 
 
-def test_conv3x3_winograd_fused_rejects_unsupported_shapes(lib, device):
+def test_gn_conv3x3_winograd_fused_rejects_unsupported_shapes(lib, device):
     E = _E()
-    t = torch.zeros(16, device=device)
-    for shape in [(1, 24, 16, 32, 64), (1, 16, 16, 30, 64), (1, 16, 16, 32, 96)]:
-        rc = lib.kd_conv3x3_winograd_fused_nhwc(E.ptr(t), E.ptr(t), None, None, E.ptr(t), *shape, E.current_stream())
-        assert rc != 0 and b"% 16" in lib.kd_last_error()
+    t = torch.zeros(4096, device=device)
+    p = E.ptr(t)
+    for shape, ldx, word in [((1, 24, 16, 32, 64), 0, b"% 16"), ((1, 16, 16, 30, 64), 0, b"% 16"), ((1, 16, 16, 32, 96), 0, b"% 16"),
+                             ((1, 16, 16, 32, 64), 16, b"row stride"), ((1, 16, 16, 32, 64), 34, b"row stride")]:
+        rc = lib.kd_gn_conv3x3_winograd_fused_nhwc(p, p, p, None, p, p, None, p, *shape, 8, 1e-5, None, ldx, E.current_stream())
+        assert rc != 0 and word in lib.kd_last_error(), (shape, ldx, lib.kd_last_error())
 
 
 @pytest.mark.parametrize("B,HW,C,G,film", [(2, 64, 32, 8, False), (3, 100, 96, 8, True), (1, 4096, 128, 8, True),

@@ -499,6 +499,36 @@ def test_qk_norm_attention_variants_match_oracle(device, mode):
     assert H.rel_l2(got, ref) < FWD_REL_L2, H.rel_l2(got, ref)
 
 
+@pytest.mark.parametrize("name,lowres", [("ultra1", False), ("ultra2", True), ("small1", False)])
+def test_library_version_forks_match_oracle(device, name, lowres):
+    """The two structural forks between library versions: Downsample = Conv2d(4, stride 2, pad 1) and
+    mid_attn = residual attention without feed-forward - built by the oracle, loaded into a DEFAULT-constructed
+    product Unet (the checkpoint's keys select the fork) and compared on the engine, both forks together and each
+    alone; memory-efficient (pre-downsample) and plain (post-downsample + the last level's Parallel) trees."""
+    import imagen_pytorch as ip
+    from oracle import imagen_ref as R
+
+    kw = dict(H.UNET_KW[name], lowres_cond=lowres, cond_on_text=False, text_embed_dim=None)
+    x, lr, cond, t, tl = _inputs(name, 2, 32, lowres)
+    dv = lambda v: None if v is None else v.to(device)
+    outs = {}
+    for forms in (dict(downsample_form="conv4x4", mid_attn_form="residual_attention"), dict(downsample_form="conv4x4"),
+                  dict(mid_attn_form="residual_attention"), dict()):
+        ou = H.randomize_(R.Unet(**kw, **forms), 77).eval()
+        pu = ip.Unet(**kw)
+        pu.load_state_dict(ou.state_dict(), strict=True)
+        assert (pu.downsample_form, pu.mid_attn_form) == (ou.downsample_form, ou.mid_attn_form)
+        pu = pu.to(device)
+        with torch.no_grad():
+            ref = ou(x, t, lowres_cond_img=lr, lowres_noise_times=tl, cond_images=cond)
+        got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
+        err = H.rel_l2(got, ref)
+        assert err < FWD_REL_L2, (forms, err)
+        outs[tuple(sorted(forms))] = ref
+    refs = list(outs.values())
+    assert all(H.rel_l2(refs[i], refs[-1]) > 1e-3 for i in range(3)), "a fork must change the function"
+
+
 def test_patch_grid_overlapped_stage_groups_equal_the_sequential_run(device):
     """sample_grids(overlap_stages=device): inside a generalised wave the stage-2 group runs on the caller's stream
     while the stage-1 group runs from a second host thread on a side stream.  Same tasks, same inputs, same seeds:
