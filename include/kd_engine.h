@@ -89,6 +89,9 @@ typedef struct kd_unet_config {
    * `mid_attn.fn.fn.*`) instead of a TransformerBlock (`mid_attn.layers.0.{0,1}.*`). */
   int downsample_conv4;
   int mid_attn_plain;
+  /* Batched-GEMM Winograd layers: cap of the V + D transform buffers per slice of tiles in MiB (the map is walked in
+   * slices, bit-identical results); 0 = one slice (default: fastest, largest workspace). */
+  int wino_slice_mb;
 } kd_unet_config_t;
 
 /* One named parameter tensor of the UNet's state_dict (key WITHOUT the `unets.N.` prefix,

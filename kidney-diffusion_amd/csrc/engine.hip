@@ -777,10 +777,10 @@ struct Builder {
     float* U = cached("wino:" + conv_prefix, (size_t)16 * Cout * Cin,
                       [&](float* dst) { KD_THROW_IF(launch_wino_pack(wsrc, dst, Cout, Cin, 0)); });
     // The map can be walked in slices of tiles (V and D are 4x the slice each) to bound the workspace:
-    // KD_WINO_SLICE_MB caps V+D per slice.  Default: one slice - slices small enough to stay in the
+    // cfg.wino_slice_mb caps V+D per slice.  Default: one slice - slices small enough to stay in the
     // 256 MB Infinity Cache were measured and are slower (56.5 ms/step unsliced, 59.3 at 96 MB,
     // 57.5 at 192 MB): the cache does not turn the V/D round trip into hits.
-    const int64_t slice_mb = kd_switch("KD_WINO_SLICE_MB", 0);  // read per plan
+    const int64_t slice_mb = cfg.wino_slice_mb;
     int64_t nt_slice = Mt;
     if (slice_mb > 0) {
       nt_slice = (slice_mb << 20) / (64 * (int64_t)(Cin + Cout)) / 256 * 256;

@@ -52,6 +52,7 @@ class kd_unet_config_t(C.Structure):
         ("attn_qk_norm", C.c_int),
         ("downsample_conv4", C.c_int),
         ("mid_attn_plain", C.c_int),
+        ("wino_slice_mb", C.c_int),
     ]
 
 

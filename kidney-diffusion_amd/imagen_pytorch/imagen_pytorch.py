@@ -542,7 +542,8 @@ class Unet(nn.Module):
         device = torch.device(device)
         # engine extension (not a library kwarg): 0 = auto (Winograd for the deep 3x3 convs), 1 = direct only
         conv_algo = int(getattr(self, "conv_algo", os.environ.get("KD_CONV_ALGO", "0")))
-        key = (batch, image_size, device.index, bool(with_text), conv_algo, self.attn_qk_norm) + \
+        slice_mb = int(getattr(self, "wino_slice_mb", 0))   # engine extension: workspace cap of the batched Winograd layers
+        key = (batch, image_size, device.index, bool(with_text), conv_algo, self.attn_qk_norm, slice_mb) + \
             ((replica,) if replica else ())   # (the structural forks drop every plan when they change)
         if self._engines:
             fp = self._weights_fingerprint()
@@ -577,6 +578,7 @@ class Unet(nn.Module):
         cfg.batch, cfg.image_size = batch, image_size
         cfg.conv_algo = conv_algo
         cfg.attn_qk_norm = self.attn_qk_norm
+        cfg.wino_slice_mb = slice_mb
         cfg.downsample_conv4 = int(self.downsample_form == "conv4x4")
         cfg.mid_attn_plain = int(self.mid_attn_form == "residual_attention")
 

@@ -66,18 +66,15 @@ def test_unet_forward_with_winograd_levels_matches_oracle(device):
     import os
 
     outs, n_gemm = {}, {}
-    # (conv_algo, KD_WINO_SLICE_MB): the last variant walks every Winograd layer in 256-tile slices
+    # (conv_algo, wino_slice_mb): the third variant walks every Winograd layer in 256-tile slices
     # conv_algo=3: the FUSED Winograd kernel (kernels_wino_fused.hip) wherever its shape rules allow, even
     # where the launch would not fill the chip (here the 16x16 maps with 64 output channels)
     for algo, slice_mb in ((32, None), (1, None), (32, "1"), (3, None)):
         pu = H.product_unet_like(ou).to(device)
         pu.conv_algo = algo
         if slice_mb is not None:
-            os.environ["KD_WINO_SLICE_MB"] = slice_mb
-        try:
-            got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
-        finally:
-            os.environ.pop("KD_WINO_SLICE_MB", None)
+            pu.wino_slice_mb = int(slice_mb)   # plan option (kd_unet_config_t::wino_slice_mb), not an environment switch
+        got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
         err = H.rel_l2(got, ref)
         assert err < FWD_REL_L2, f"conv_algo={algo} slice={slice_mb}: rel-L2 {err:.3e}"
         buf = C.create_string_buffer(1 << 20)
