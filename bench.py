@@ -38,6 +38,8 @@ import torch  # noqa: E402
 BATCH, SIZE, T_SCHED = 16, 256, 250
 DOMINANT = ("wino_fused_gn128_kernel: fused Winograd F(2x2,3x3) 3x3 convs of the ResnetBlocks, GroupNorm/FiLM/SiLU applied "
             "in the kernel (sixteen waves, persistent workgroups, items of 16x8 pixels x 128 output channels)")
+WINO4 = ("conv_buf_kernel: the 36 position GEMMs of Winograd F(4x4,3x3) - the ResnetBlock 3x3 convs with Cin >= 512 "
+         "(buffer-DMA implicit-GEMM kernel, batched over the positions)")
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix = vector peak (v_mfma_f32_32x32x2_f32, exact fp32)
 SR_UNET_KW = dict(dim=128, dim_mults=(1, 2, 4, 8), num_resnet_blocks=2, memory_efficient=True,
                   layer_attns=(False, False, False, True), layer_cross_attns=(False, False, True, True),
@@ -95,13 +97,19 @@ def kernel_classes(lib, handle, iters=3):
     for _, label, macs, us, mfma in rows:
         us, macs, mfma = float(us), int(macs), int(mfma)
         total_us += us
-        m = re.match(r"(wino_in|wino_out|wino gemm) M(\d+) Cin(\d+) Cout(\d+)", label)
+        m = re.match(r"(wino_in|wino_out|wino gemm|wino4_in|wino4_out|wino4 gemm) M(\d+) Cin(\d+) Cout(\d+)", label)
         if label.startswith("conv k3"):
             add("conv_buf_kernel: direct 3x3 convs", us, 2.0 * macs, 2.0 * mfma)
         elif label.startswith("wino fused"):
             add(DOMINANT, us, 2.0 * macs, 2.0 * mfma)
         elif m and m.group(1) == "wino gemm":
-            add("conv_buf_kernel: Winograd position GEMMs", us, 2.0 * macs, 2.0 * mfma)
+            add("conv_buf_kernel: Winograd F(2x2,3x3) position GEMMs", us, 2.0 * macs, 2.0 * mfma)
+        elif m and m.group(1) == "wino4 gemm":
+            add(WINO4, us, 2.0 * macs, 2.0 * mfma)
+        elif m and m.group(1).startswith("wino4"):  # transforms move 3.25x the map: read 1x / write 2.25x (in), the reverse (out)
+            ch = int(m.group(3)) if m.group(1) == "wino4_in" else int(m.group(4))
+            add("wino4_in_kernel + wino4_out_kernel (Winograd F(4x4,3x3) transforms, GroupNorm/FiLM/SiLU and statistics fused)", us,
+                nbytes=13.0 * int(m.group(2)) * ch)
         elif m:  # transforms move 5x the map: read 1x / write 4x (in), read 4x / write 1x (out)
             ch = int(m.group(3)) if m.group(1) == "wino_in" else int(m.group(4))
             add("wino_in_kernel + wino_out_kernel (Winograd transforms)", us, nbytes=20.0 * int(m.group(2)) * ch)
@@ -175,10 +183,10 @@ CPU_K0 = 125   # schedule index of the CPU baseline's first step: mid-schedule, 
 
 
 def cpu_baseline(unet_product, timed_steps=3):
-    """The oracle (CPU fp32 torch restatement of the reference's path) timed on this host: batch 8 (half the
-    headline batch), one warm-up step + `timed_steps` timed steps of p_sample with injected noise;
-    steps/s is scaled to batch 16.  Returns (json entry, inputs and outputs of the FIRST step for the parity
-    check against the engine)."""
+    """The oracle (CPU fp32 torch restatement of the reference's path) timed on this host: one warm-up step at the
+    headline batch 16, then `timed_steps` timed steps of p_sample at batch 8 (half the headline batch) with injected
+    noise; steps/s is scaled to batch 16.  Returns (json entry, inputs and outputs of the WARM-UP step for the parity
+    check against the engine - batch 16, the plan that was timed)."""
     from oracle import imagen_ref as R
     from oracle import sampler_ref as RS
 
@@ -189,35 +197,43 @@ def cpu_baseline(unet_product, timed_steps=3):
     ou.eval()
     oim = RS.Imagen([R.NullUnet(), ou], image_sizes=(64, SIZE), timesteps=(T_SCHED, T_SCHED),
                     pred_objectives=("noise", "noise"), condition_on_text=False)
+    # warm-up step at the HEADLINE batch (16): not timed, it is the reference of the parity check (the engine's plan
+    # depends on the batch - Winograd F(4x4,3x3) layers need whole 128-row tile slabs -, so the check runs the very
+    # plan that was timed); then `timed_steps` steps at batch 8 (half the work per step keeps the run bounded)
     b = CPU_BATCH
-    x, lowres, lowres_noise, cond = synthetic_inputs(b)
+    x16, lowres16, lowres_noise16, cond16 = synthetic_inputs(BATCH)
     sched = oim.noise_schedulers[1]
-    t_lr = torch.full((b,), 0.2)
-    lowres = oim.lowres_noise_schedule.q_sample(lowres, t_lr, lowres_noise)
-    times = sched.get_sampling_timesteps(b)
+    lowres16 = oim.lowres_noise_schedule.q_sample(lowres16, torch.full((BATCH,), 0.2), lowres_noise16)
     g = torch.Generator().manual_seed(99)
-    kw = dict(noise_scheduler=sched, text_embeds=None, text_mask=None, cond_images=cond, lowres_cond_img=lowres,
-              lowres_noise_times=t_lr, cond_scale=1.0, pred_objective="noise", dynamic_threshold=True)
-    dts, first = [], None
     preds = []
     fwd = ou.forward_with_cond_scale
 
-    def fwd_keep(*a, **k):   # the UNet's output of every timed step (the parity check reads the first)
+    def fwd_keep(*a, **k):   # the UNet's output of every step (the parity check reads the warm-up's)
         out = fwd(*a, **k)
         preds.append(out)
         return out
 
     ou.forward_with_cond_scale = fwd_keep
+
+    def step(xs, lr, cd, k):
+        n = xs.shape[0]
+        t, tn = sched.get_sampling_timesteps(n)[k]
+        noise = torch.randn(xs.shape, generator=g)
+        kw = dict(noise_scheduler=sched, text_embeds=None, text_mask=None, cond_images=cd, lowres_cond_img=lr,
+                  lowres_noise_times=torch.full((n,), 0.2), cond_scale=1.0, pred_objective="noise", dynamic_threshold=True)
+        t0 = time.perf_counter()
+        x_next, x0 = oim.p_sample(ou, xs, t, noise, t_next=tn, **kw)
+        return x_next, x0, noise, time.perf_counter() - t0
+
+    dts = []
     with torch.no_grad():
-        for k in range(CPU_K0, CPU_K0 + 1 + timed_steps):
-            t, tn = times[k]
-            noise = torch.randn(x.shape, generator=g)
-            t0 = time.perf_counter()
-            x_next, x0 = oim.p_sample(ou, x, t, noise, t_next=tn, **kw)
-            dts.append(time.perf_counter() - t0)
-            if first is None:
-                first = dict(x=x, noise=noise, lowres=lowres, cond=cond, x_next=x_next, pred=preds[0], x0=x0)
-            x = x_next
+        x_next, x0, noise, dt = step(x16, lowres16, cond16, CPU_K0)
+        dts.append(dt)
+        first = dict(x=x16, noise=noise, lowres=lowres16, cond=cond16, x_next=x_next, pred=preds[0], x0=x0)
+        x, lowres, cond = x_next[:b], lowres16[:b], cond16[:b]
+        for k in range(CPU_K0 + 1, CPU_K0 + 1 + timed_steps):
+            x, _, _, dt = step(x, lowres, cond, k)
+            dts.append(dt)
     timed = dts[1:]
     sec_per_step_b16 = (sum(timed) / len(timed)) * (BATCH / b)
     entry = {"value": 1.0 / sec_per_step_b16, "unit": "denoising-steps/s (batch 16)", "cores": info["threads"],
@@ -225,7 +241,7 @@ def cpu_baseline(unet_product, timed_steps=3):
              "cpu_model": info["model"],
              "host": {k: info[k] for k in ("logical", "physical", "affinity", "cgroup_quota")},
              "sample": f"oracle p_sample (UNet forward + x0 / dynamic threshold / posterior / noise) on CPU at batch {b} "
-                       f"(half the headline batch), 1 warm-up ({dts[0]:.2f} s) + {len(timed)} timed steps "
+                       f"(half the headline batch), 1 warm-up at batch {BATCH} ({dts[0]:.2f} s; the parity reference) + {len(timed)} timed steps "
                        f"({', '.join(f'{d:.2f}' for d in timed)} s), mean scaled x{BATCH // b} to batch 16; "
                        f"torch {torch.__version__} oneDNN fp32, torch.set_num_threads({info['threads']}) = "
                        f"min(physical cores, affinity, cgroup quota)"}
@@ -235,7 +251,7 @@ def cpu_baseline(unet_product, timed_steps=3):
 def engine_parity(unet, first, device, lib):
     """The engine's denoising step on the inputs of the CPU baseline's first step (same weights, same x_t,
     same conditioning, same injected noise, schedule index CPU_K0): relative L2 and max-abs of x_{t-1} against the
-    oracle's.  Uses a second plan of the same UNet at the CPU baseline's batch (shared packed weights)."""
+    oracle's, at the headline batch: the plan that was timed."""
     from imagen_pytorch import _engine as E
     from imagen_pytorch.imagen_pytorch import GaussianDiffusionContinuousTimes, beta_linear_log_snr
 

@@ -92,6 +92,10 @@ typedef struct kd_unet_config {
   /* Batched-GEMM Winograd layers: cap of the V + D transform buffers per slice of tiles in MiB (the map is walked in
    * slices, bit-identical results); 0 = one slice (default: fastest, largest workspace). */
   int wino_slice_mb;
+  /* Winograd F(4x4,3x3) (36 batched GEMMs over tiles of 4x4 outputs) for the ResnetBlock 3x3 convs with at least this
+   * many input channels whose GEMMs fill the chip; 0 = default (512), < 0 = never.  fp32 throughout; per-conv relative
+   * L2 against fp64 3-4e-6 (F(2x2,3x3): 5e-7) - inside the 2e-5 the UNet forward is held to. */
+  int wino43_min_cin;
 } kd_unet_config_t;
 
 /* One named parameter tensor of the UNet's state_dict (key WITHOUT the `unets.N.` prefix,
@@ -246,6 +250,14 @@ int kd_conv2d_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias,
  * only.  Needs even H, W; B*H*W/4 % 256 == 0; Cin % 32 == 0; Cout > 32. */
 int kd_conv3x3_winograd_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias, float* d_y,
                              int B, int H, int W, int Cin, int Cout, void* stream);
+/* The same convolution (+ optional residual d_res, NHWC with Cout channels) through the plan's Winograd F(4x4,3x3)
+ * path for the deepest layers (kernels_wino4.hip): weight transform, input transform, 36 batched GEMMs, output transform.
+ * Needs H % 4 == 0, W % 4 == 0, B (H/4) (W/4) % 128 == 0, Cin % 32 == 0, Cout % 64 == 0.  d_out_stats (may be NULL):
+ * [B, G, 2] = (mean, rstd) of y per image and group of Cout / G channels from the partial sums the output transform
+ * leaves for the next GroupNorm; needs (Cout / G) % 16 == 0. */
+int kd_conv3x3_winograd4_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias, const float* d_res,
+                              float* d_y, int B, int H, int W, int Cin, int Cout, int G, float eps,
+                              float* d_out_stats, void* stream);
 /* ResnetBlock `Block` in one pass over x: conv3x3(SiLU(FiLM(GroupNorm_G(x)))) + bias (+ d_res), the form the
  * plan uses for those layers: statistics, a per-(image, channel) affine fold, and the fused Winograd kernel
  * with the activation applied to the raw patch in LDS (the activated map is never written).  d_scale_shift

@@ -59,7 +59,7 @@ struct ConvParams {
   int out_mode;
   int ldy, yoff;          // OUT_NHWC: y[m*ldy + yoff + n]
   // batched 1x1 GEMM (Winograd positions): rows [z*wz_rows, (z+1)*wz_rows) use weight slab z of
-  // wz_count slabs [Cout][Cin]; 0 = one weight tensor.  wz_rows must be a multiple of 256.
+  // wz_count slabs [Cout][Cin]; 0 = one weight tensor.  wz_rows must be a multiple of 128.
   int wz_rows, wz_count;
   // split-K for small-M layers: scratch [conv_ksplit(p)][M][Cout] floats, or nullptr (never split);
   // ksplit is filled in by launch_conv_igemm
@@ -108,6 +108,15 @@ int launch_wino_in(const float* x, int ldx, const float* stats, const float* gam
 // y[b][2ty+i][2tx+j][n] = (A^T D A)[i][j] + bias[n] (+ res)
 int launch_wino_out(const float* D, const float* bias, const float* res, int ldres, float* y, int B, int H, int W,
                     int C, int64_t t0, int64_t nt, hipStream_t s);
+
+// ---- Winograd F(4x4,3x3) transforms (kernels_wino4.hip): U [36][O][I]; V [36][Mt][C] and D [36][Mt][N] over the
+// Mt = B (H/4) (W/4) tiles of 4x4 outputs; arguments as launch_wino_in / launch_wino_out (one slice).  seg_partial != nullptr:
+// wino4_out also leaves the GroupNorm partials of y, layout [B][N/16][(H/4)(W/4)][2] doubles (N % 64 == 0)
+int launch_wino4_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s);
+int launch_wino4_in(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
+                    const float* scale_shift, int ld_ss, float* V, int B, int H, int W, int C, int G, hipStream_t s);
+int launch_wino4_out(const float* D, const float* bias, const float* res, int ldres, float* y, int ldy, double* seg_partial,
+                     int B, int H, int W, int C, hipStream_t s);
 
 // ---- fused Winograd F(2x2,3x3) conv + GroupNorm / FiLM / SiLU, items of 64 output channels (kernels_wino_fused.hip)
 // U from launch_wino_fused_pack (16*N*C floats).  wino_fused_ok states the shapes it takes.

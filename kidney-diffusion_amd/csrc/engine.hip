@@ -432,7 +432,8 @@ struct Builder {
     bool rowrun = false;        // small-Cin wide-window conv: weights from pack_conv_rowrun
     int res_coff = 0;           // channel offset into res (res row stride stays res->C)
     int64_t macs_override = -1; // algorithmic MACs when the launch computes padded / re-associated work
-    int wz_rows = 0;            // batched 1x1 GEMM over 16 Winograd positions (ConvParams::wz_rows)
+    int wz_rows = 0;            // batched 1x1 GEMM over the Winograd positions (ConvParams::wz_rows)
+    int wz_count = 16;          // ... 16 positions of F(2x2,3x3), 36 of F(4x4,3x3)
     bool want_seg = false;      // the output feeds a GroupNorm: leave its partials in the epilogue where possible
     int seg_c0 = -1, seg_cn = 0;  // channel range of y the partial buffer spans (default: this launch's own range);
                                   // launches filling slices of one tensor name the same span and share the buffer
@@ -461,7 +462,7 @@ struct Builder {
       p.rr_cin = x.C;
     }
     p.wz_rows = o.wz_rows;
-    p.wz_count = o.wz_rows > 0 ? 16 : 0;
+    p.wz_count = o.wz_rows > 0 ? o.wz_count : 0;
     p.act = o.act; p.out_mode = o.out_mode;
     p.ldy = (o.out_mode == OUT_NHWC || o.out_mode == OUT_PIXSHUF) ? y.LD() : 0;
     p.yoff = y.coff + o.yoff;   // (a slice destination: channels count from the slice's first)
@@ -753,7 +754,7 @@ struct Builder {
   // the transforms: measured on MI355X, Cin >= 256 wins and Cin = 128 loses (profiles/README.md).
   // cfg.conv_algo: 0 auto, 1 never, >= 32 explicit Cin threshold (experiments, tests).
   bool wino_ok(const T& x, int cout) const {
-    if (cfg.conv_algo == 1) return false;
+    if (cfg.conv_algo == 1 || cfg.conv_algo == 4) return false;
     const int min_cin = cfg.conv_algo >= 32 ? cfg.conv_algo : 256;
     // the fused kernel (fwino_ok) takes every layer whose map it can tile and whose launch fills the chip, up to the
     // Cin its affine table holds.  Measured on the 64->256 UNet, ms/step with the hand-over at Cin <= 0 / 256 / 512 /
@@ -761,11 +762,74 @@ struct Builder {
     // to the batched GEMMs), 37.59 / 37.36 / 37.40 at <= 512 / 1024 / 2048 with the persistent sixteen-wave kernel
     // (300 us against 265 + 40 + 21 for GEMM + transforms).  KD_FWINO_MAX_CIN moves it for experiments, read per plan
     const int fw_max = kd_switch("KD_FWINO_MAX_CIN", 2048);
+    if (wino4_ok(x, cout)) return false;
     if (cfg.conv_algo < 32 && x.C <= fw_max && fwino_ok(x, cout)) return false;
     if ((x.H & 1) || (x.W & 1) || x.C < min_cin || x.C % 32 || cout <= 32 || cout % 4) return false;
     const int64_t Mt = (int64_t)x.B * (x.H / 2) * (x.W / 2);
     return Mt % 256 == 0 && 16 * Mt < 0x7fffffff && (int64_t)16 * cout * x.C * 4 < 0x7fffffff;
   }
+  // ---- Winograd F(4x4,3x3) (kernels_wino4.hip): 36 batched GEMMs over tiles of 4x4 outputs, 4x fewer MFMA issues than
+  // the direct conv and 1.78x fewer than F(2x2,3x3), for V / D transform buffers of 2.25x the map.  cfg.conv_algo 0:
+  // layers with Cin >= cfg.wino43_min_cin (default 512) whose GEMMs fill the chip - measured against the fused
+  // F(2x2,3x3) kernel at batch 16 (profiles/README.md); 4: wherever the shape fits (tests); 1 / 2 / 3 / >= 32: never.
+  bool wino4_ok(const T& x, int cout) const {
+    if (cfg.conv_algo != 0 && cfg.conv_algo != 4) return false;
+    if (cfg.wino43_min_cin < 0 && cfg.conv_algo == 0) return false;
+    if ((x.H & 3) || (x.W & 3) || x.C % 32 || cout % 64 || cout < 64) return false;
+    const int64_t Mt = (int64_t)x.B * (x.H / 4) * (x.W / 4);
+    if (Mt % 128 || 36 * Mt >= 0x7fffffff || (int64_t)36 * cout * x.C * 4 >= 0x7fffffff) return false;
+    if (cfg.conv_algo == 4) return true;
+    const int min_cin = cfg.wino43_min_cin > 0 ? cfg.wino43_min_cin : 512;
+    return x.C >= min_cin && (36 * Mt / 128) * (cout / 64) >= 512;
+  }
+  T wino4_block(const T& x, const std::string& gn_prefix, int ss_col, const std::string& conv_prefix, int Cout,
+                const T* res) {
+    const int Cin = x.C, G = cfg.resnet_groups, Bx = x.B, H = x.H, W = x.W, HW = x.HW();
+    const int64_t Mt = (int64_t)Bx * (H / 4) * (W / 4);
+    const float* gamma = P(gn_prefix + ".weight", Cin);
+    const float* beta = P(gn_prefix + ".bias", Cin);
+    const float* bias = P(conv_prefix + ".bias", Cout);
+    const float* wsrc = raw(conv_prefix + ".weight", (int64_t)Cout * Cin * 9);
+    float* U = cached("wino4:" + conv_prefix, (size_t)36 * Cout * Cin,
+                      [&](float* dst) { KD_THROW_IF(launch_wino4_pack(wsrc, dst, Cout, Cin, 0)); });
+    emit_gn_stats(x, gamma, beta, ss_col, nullptr);
+    T V = alloc(1, 1, (int)(36 * Mt), Cin);
+    T D = alloc(1, 1, (int)(36 * Mt), Cout);
+    T y = alloc(Bx, H, W, Cout);
+    const std::string shape = " M" + std::to_string((int64_t)Bx * HW) + " Cin" + std::to_string(Cin) + " Cout" +
+                              std::to_string(Cout);
+    kd_unet* uu = u;
+    {
+      size_t xo = x.at(), vo = V.off, so = gn_stats_t.off, sso = t_ss.off;
+      const int ld = tmlp_total, ldx = x.LD();
+      emit([=](hipStream_t s) {
+        const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
+        return launch_wino4_in(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s);
+      }, "wino4_in" + shape);
+    }
+    ConvOpt o;
+    o.wz_rows = (int)Mt;
+    o.wz_count = 36;
+    o.dst = &D;
+    o.macs_override = (int64_t)Bx * HW * Cout * Cin * 9;   // the algorithmic MACs of the 3x3 conv it replaces
+    conv(V, U, nullptr, Cout, 1, 1, 0, o);
+    if (!to_text && !to_static) u->op_label.back() = "wino4 gemm" + shape;
+    {
+      const bool sg = seg_on && Cout % 64 == 0;   // GroupNorm partials of y for whichever layer normalises it next
+      const size_t sgo = sg ? add_seg(y, 0, Cout / 16, (H / 4) * (W / 4)) : 0;
+      size_t d_o = D.off, yo = y.off, ro = res ? res->at() : 0;
+      const bool hr = res != nullptr;
+      const int ldres = res ? res->LD() : 0;
+      emit([=](hipStream_t s) {
+        return launch_wino4_out(uu->P(d_o), bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Cout,
+                                sg ? (double*)uu->P(sgo) : nullptr, Bx, H, W, Cout, s);
+      }, "wino4_out" + shape);
+    }
+    free(V);
+    free(D);
+    return y;
+  }
+
   T wino_block(const T& x, const std::string& gn_prefix, int ss_col, const std::string& conv_prefix, int Cout,
                const T* res) {
     const int Cin = x.C, G = cfg.resnet_groups, Bx = x.B, H = x.H, W = x.W, HW = x.HW();
@@ -919,7 +983,9 @@ struct Builder {
     if (has_cross && !ctx) throw std::runtime_error("cross-attention block without conditioning tokens: " + pre);
     int dim_in = x.C;
     T h;
-    if (wino_ok(x, dim_out)) {
+    if (wino4_ok(x, dim_out)) {
+      h = wino4_block(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
+    } else if (wino_ok(x, dim_out)) {
       h = wino_block(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
     } else if (fwino_gn_ok(x, dim_out)) {
       h = fwino_gn_conv(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
@@ -938,7 +1004,11 @@ struct Builder {
     int ss_col = it != tmlp_off.end() ? it->second : -1;
     bool has_res_conv = has(pre + ".res_conv.weight");
     T h2;
-    if (wino_ok(h, dim_out)) {
+    if (wino4_ok(h, dim_out)) {
+      h2 = wino4_block(h, pre + ".block2.groupnorm", ss_col, pre + ".block2.project", dim_out,
+                       (!use_gca && !has_res_conv) ? &x : nullptr);
+      free(h);
+    } else if (wino_ok(h, dim_out)) {
       h2 = wino_block(h, pre + ".block2.groupnorm", ss_col, pre + ".block2.project", dim_out,
                       (!use_gca && !has_res_conv) ? &x : nullptr);
       free(h);

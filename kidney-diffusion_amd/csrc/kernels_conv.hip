@@ -852,7 +852,45 @@ static int launch_conv_fast(const ConvParams& p, int64_t M, hipStream_t s) {
   // tile's epilogue with the other's loop (measured in the step: 3x3 Cin=128 layers still prefer 256x128)
   const int k_chunks = p.KH * p.KW * (p.Cin / BK);
   static const int shortk = kd_switch("KD_SHORTK_TILE", 0);   // experiment switch
-  if (p.KH * p.KW == 1 && k_chunks <= 8 && p.wz_rows == 0 && shortk == 1 &&
+  if (p.wz_rows > 0) {
+    // Batched position GEMMs of the Winograd layers: M = positions x tiles is a few thousand rows, so the launch is a
+    // handful of tile rounds and the last, partly filled round decides its time (36 x 256 rows x 1024 columns: 576
+    // tiles of 128 x 128 on 512 slots = two rounds for 1.1 rounds of work).  Pick the tile shape whose rounds are
+    // fullest, larger tiles winning ties by their better operand reuse (weights: per-tile efficiency seen in the step)
+    static int cus = 0;
+    if (!cus) {
+      hipDeviceProp_t prop;
+      int dev = 0;
+      KD_HIP_CHECK(hipGetDevice(&dev));
+      KD_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+      cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    struct Cand { int bm, bn, per_cu; double w; };
+    const Cand cands[3] = {{256, 128, 1, 1.00}, {128, 128, 2, 0.97}, {128, 64, 3, 0.92}};
+    int best = 2;
+    double best_eff = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      if (p.wz_rows % cands[i].bm) continue;   // a tile must lie in one weight slab
+      const int64_t tiles = ((M + cands[i].bm - 1) / cands[i].bm) * ((p.Cout + cands[i].bn - 1) / cands[i].bn);
+      const int64_t slots = (int64_t)cus * cands[i].per_cu;
+      const double eff = cands[i].w * (double)tiles / (double)(((tiles + slots - 1) / slots) * slots);
+      if (eff > best_eff + 1e-9) {
+        best_eff = eff;
+        best = i;
+      }
+    }
+    if (kd_switch("KD_WZ_TILE", 0) > 0 && p.wz_rows % 256 == 0) best = kd_switch("KD_WZ_TILE", 0) - 1;   // experiment: force a shape
+    if (best == 0) {
+      dim3 grid((unsigned)((M + 255) / 256), (p.Cout + 127) / 128);
+      hipLaunchKernelGGL((conv_buf_kernel<256, 128, 4, 2, 2>), grid, dim3(512), 0, s, p);
+    } else if (best == 1) {
+      dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 127) / 128);
+      hipLaunchKernelGGL((conv_buf_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, s, p);
+    } else {
+      dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 63) / 64);
+      hipLaunchKernelGGL((conv_buf_kernel<128, 64, 2, 2, 3>), grid, dim3(256), 0, s, p);
+    }
+  } else if (p.KH * p.KW == 1 && k_chunks <= 8 && p.wz_rows == 0 && shortk == 1 &&
       ((M + 127) / 128) * ((p.Cout + 127) / 128) >= 256) {
     dim3 grid((unsigned)((M + 127) / 128), (p.Cout + 127) / 128);
     hipLaunchKernelGGL((conv_buf_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, s, p);
@@ -899,8 +937,8 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
   int64_t M = (int64_t)p.B * p.Ho * p.Wo;
   KD_REQUIRE(M > 0 && p.Cout > 0, "empty conv");
   if (p.wz_rows > 0)
-    KD_REQUIRE(p.KH * p.KW == 1 && p.wz_rows % 256 == 0 && M == (int64_t)p.wz_rows * p.wz_count,
-               "batched GEMM: 1x1 only, slab rows a multiple of 256, M = rows x slabs");
+    KD_REQUIRE(p.KH * p.KW == 1 && p.wz_rows % 128 == 0 && M == (int64_t)p.wz_rows * p.wz_count,
+               "batched GEMM: 1x1 only, slab rows a multiple of 128, M = rows x slabs");
   const int ks = p.partial ? conv_ksplit(p) : 1;
   if (ks > 1) {
     KD_REQUIRE(((uintptr_t)p.partial & 15) == 0, "split-K partial buffer must be 16-B aligned");

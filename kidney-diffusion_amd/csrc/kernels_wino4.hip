@@ -1,0 +1,244 @@
+// Winograd F(4x4,3x3) transforms for the deepest 3x3 convolutions of the ResnetBlocks (Cin >= 512 on 16x16 .. 32x32
+// maps at the benchmark's batch).
+//
+//   y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A     with the interpolation points 0, +-1, +-2, inf (Lavin & Gray)
+//
+// A 3x3 / stride 1 / pad 1 conv over [B,H,W,Cin] becomes 36 independent GEMMs D_p[t][n] = sum_c V_p[t][c] U_p[n][c], one
+// per position p of the 6x6 transformed tile, over the Mt = B (H/4) (W/4) tiles of 4x4 outputs: 36 Mt Cin Cout MACs for
+// 144 Mt Cin Cout of the direct convolution - 4x fewer MFMA issues, 1.78x fewer than F(2x2,3x3).  The GEMMs run on the
+// buffer-DMA implicit-GEMM kernel (kernels_conv.hip, weight slab picked per tile row: ConvParams::wz_rows / wz_count);
+// this file holds the HBM-bound transforms:
+//
+//   wino4_pack (plan build)  OIHW weights            -> U [36][Cout][Cin]
+//   wino4_in   (per step)    GroupNorm+FiLM+SiLU(x)  -> V [36][Mt][Cin]     (the normalised map is never written)
+//   wino4_out  (per step)    D [36][Mt][Cout]        -> y NHWC + bias (+ residual), and the GroupNorm partial sums of y
+//                                                       for the layer that normalises it next (SegSrc, common.h)
+//
+// V and D are 2.25x the map each (4x for F(2x2,3x3)).  Accuracy: the transform matrices have entries up to 8 and
+// 1/24, so fp32 re-association costs more than in F(2x2,3x3): relative L2 against an fp64 convolution 3-4e-6 at
+// Cin = 512 .. 2048 (F(2x2,3x3): 5e-7, direct fp32 chain: 2.5e-7; scratch/wino43_accuracy.py), inside the 2e-5 the
+// UNet forward is held to (tests/test_fullsize_gpu.py).  The plan uses it where the 4x-smaller GEMM outweighs the
+// transform passes: Cin >= 512 (Builder::wino4_ok).
+#include "common.h"
+
+namespace kd {
+
+namespace {
+__device__ __forceinline__ float w4_silu(float v) { return v / (1.0f + expf(-v)); }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// B^T applied to six values (one column or one row of the 6x6 tile)
+template <class F>
+__device__ __forceinline__ void w4_bt(const F (&d)[6], F (&t)[6]) {
+  t[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
+  t[1] = (d[3] + d[4]) - 4.0f * (d[1] + d[2]);
+  t[2] = (d[4] - d[3]) + 4.0f * (d[1] - d[2]);
+  t[3] = (d[4] - d[2]) + 2.0f * (d[3] - d[1]);
+  t[4] = (d[4] - d[2]) + 2.0f * (d[1] - d[3]);
+  t[5] = 4.0f * d[1] - 5.0f * d[3] + d[5];
+}
+// A^T applied to six values -> four
+template <class F>
+__device__ __forceinline__ void w4_at(const F (&m)[6], F (&y)[4]) {
+  const F a = m[1] + m[2], b = m[1] - m[2], c = m[3] + m[4], d = m[3] - m[4];
+  y[0] = m[0] + a + c;
+  y[1] = b + 2.0f * d;
+  y[2] = a + 4.0f * c;
+  y[3] = b + 8.0f * d + m[5];
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int O, int I) {
+  const int64_t total = (int64_t)O * I;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const float* g = w + idx * 9;
+    float t[6][3];   // G g
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float g0 = g[k], g1 = g[3 + k], g2 = g[6 + k];
+      t[0][k] = g0 * 0.25f;
+      t[1][k] = -(g0 + g1 + g2) * (1.0f / 6.0f);
+      t[2][k] = -(g0 - g1 + g2) * (1.0f / 6.0f);
+      t[3][k] = g0 * (1.0f / 24.0f) + g1 * (1.0f / 12.0f) + g2 * (1.0f / 6.0f);
+      t[4][k] = g0 * (1.0f / 24.0f) - g1 * (1.0f / 12.0f) + g2 * (1.0f / 6.0f);
+      t[5][k] = g2;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {   // (G g) G^T
+      const float a0 = t[r][0], a1 = t[r][1], a2 = t[r][2];
+      const float u[6] = {a0 * 0.25f,
+                          -(a0 + a1 + a2) * (1.0f / 6.0f),
+                          -(a0 - a1 + a2) * (1.0f / 6.0f),
+                          a0 * (1.0f / 24.0f) + a1 * (1.0f / 12.0f) + a2 * (1.0f / 6.0f),
+                          a0 * (1.0f / 24.0f) - a1 * (1.0f / 12.0f) + a2 * (1.0f / 6.0f),
+                          a2};
+#pragma unroll
+      for (int s = 0; s < 6; ++s) U[(int64_t)(r * 6 + s) * total + idx] = u[s];
+    }
+  }
+}
+
+int launch_wino4_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s) {
+  const int64_t total = (int64_t)O * I;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(wino4_pack_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, U, O, I);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// One thread: one 6x6 input tile x TWO channels (8-byte accesses); threads run along the channels (a wave reads / writes
+// 512 contiguous bytes)
+__global__ __launch_bounds__(256) void wino4_in_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ scale_shift, int ld_ss,
+                                                       float* __restrict__ V, int B, int H, int W, int C, int G, int64_t nt) {
+  const int Ht = H >> 2, Wt = W >> 2, C2 = C >> 1;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nt * C2) return;
+  const int c = (int)(idx % C2) * 2;
+  const int64_t t = idx / C2;
+  const int tx = (int)(t % Wt);
+  const int ty = (int)((t / Wt) % Ht);
+  const int b = (int)(t / ((int64_t)Wt * Ht));
+  f32x2 A = {1.0f, 1.0f}, Bc = {0.0f, 0.0f};
+  const bool norm = stats != nullptr;
+  if (norm) {   // the folding of gn_apply_silu_kernel (kernels_norm.hip)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ce = c + e, g = ce / (C / G);
+      const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+      float a = rstd * gamma[ce];
+      float bb = beta[ce] - mean * a;
+      if (scale_shift) {
+        const float sc = scale_shift[(int64_t)b * ld_ss + ce] + 1.0f;
+        const float sh = scale_shift[(int64_t)b * ld_ss + C + ce];
+        a *= sc;
+        bb = bb * sc + sh;
+      }
+      A[e] = a;
+      Bc[e] = bb;
+    }
+  }
+  f32x2 u[6][6];   // B^T d: column by column
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const int ix = 4 * tx - 1 + s;
+    f32x2 d[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int iy = 4 * ty - 1 + r;
+      f32x2 v = {0.0f, 0.0f};
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        v = *(const f32x2*)(x + (((int64_t)b * H + iy) * W + ix) * ldx + c);
+        if (norm) {
+          v[0] = w4_silu(v[0] * A[0] + Bc[0]);
+          v[1] = w4_silu(v[1] * A[1] + Bc[1]);
+        }
+      }
+      d[r] = v;
+    }
+    f32x2 tcol[6];
+    w4_bt(d, tcol);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) u[r][s] = tcol[r];
+  }
+  float* out = V + t * C + c;
+  const int64_t pstride = nt * C;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {   // (B^T d) B: row by row
+    f32x2 trow[6];
+    w4_bt(u[r], trow);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) *(f32x2*)(out + (int64_t)(r * 6 + s) * pstride) = trow[s];
+  }
+}
+
+int launch_wino4_in(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
+                    const float* scale_shift, int ld_ss, float* V, int B, int H, int W, int C, int G, hipStream_t s) {
+  KD_REQUIRE(H % 4 == 0 && W % 4 == 0 && ldx >= C && C % 2 == 0 && ldx % 2 == 0 && ((uintptr_t)x & 7) == 0,
+             "Winograd F(4x4,3x3) input transform needs H % 4 == 0, W % 4 == 0 and even C / row stride");
+  const int64_t nt = (int64_t)B * (H / 4) * (W / 4), total = nt * (C / 2);
+  hipLaunchKernelGGL(wino4_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, stats, gamma, beta,
+                     scale_shift, ld_ss, V, B, H, W, C, G, nt);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// One thread: one tile x TWO channels -> 4x4 outputs (8-byte accesses); a wave = one tile x 128 consecutive channels
+// (C % 128 == 0) or a narrower run.  seg != nullptr: fp64 (sum, sum of squares) of the 16 outputs x 16 channels of every
+// 16-channel segment, entry [b][c / 16][tile of the image][2] (one chunk per tile: nchunk = (H/4)(W/4))
+__global__ __launch_bounds__(256) void wino4_out_kernel(const float* __restrict__ D, const float* __restrict__ bias,
+                                                        const float* __restrict__ res, int ldres, float* __restrict__ y,
+                                                        int ldy, double* __restrict__ seg, int B, int H, int W, int C,
+                                                        int64_t nt) {
+  const int Ht = H >> 2, Wt = W >> 2, C2 = C >> 1;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nt * C2) return;   // (whole waves: nt C / 2 % 64 == 0 is required when seg != nullptr)
+  const int c = (int)(idx % C2) * 2;
+  const int64_t t = idx / C2;
+  const int tx = (int)(t % Wt);
+  const int ty = (int)((t / Wt) % Ht);
+  const int b = (int)(t / ((int64_t)Wt * Ht));
+  const float* in = D + t * C + c;
+  const int64_t pstride = nt * C;
+  f32x2 u[4][6];   // A^T m: column by column
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    f32x2 m[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) m[r] = *(const f32x2*)(in + (int64_t)(r * 6 + s) * pstride);
+    f32x2 ycol[4];
+    w4_at(m, ycol);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i][s] = ycol[i];
+  }
+  f32x2 bv = {0.0f, 0.0f};
+  if (bias) bv = *(const f32x2*)(bias + c);
+  float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x2 o[4];
+    w4_at(u[i], o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t pix = ((int64_t)b * H + 4 * ty + i) * W + 4 * tx + j;
+      f32x2 v = o[j] + bv;
+      if (res) v += *(const f32x2*)(res + pix * ldres + c);
+      *(f32x2*)(y + pix * ldy + c) = v;
+      s1 += v[0] + v[1];
+      s2 = fmaf(v[0], v[0], fmaf(v[1], v[1], s2));
+    }
+  }
+  if (seg) {   // the thread's 32 values in fp32, fp64 from there on; the 8 lanes of a 16-channel segment are adjacent
+    double d1 = (double)s1, d2 = (double)s2;
+#pragma unroll
+    for (int off = 1; off <= 4; off <<= 1) {
+      d1 += __shfl_xor(d1, off, 64);
+      d2 += __shfl_xor(d2, off, 64);
+    }
+    if ((c & 15) == 0) {
+      const int nchunk = Ht * Wt;
+      double* op = seg + (((int64_t)b * (C >> 4) + (c >> 4)) * nchunk + (ty * Wt + tx)) * 2;
+      op[0] = d1;
+      op[1] = d2;
+    }
+  }
+}
+
+int launch_wino4_out(const float* D, const float* bias, const float* res, int ldres, float* y, int ldy, double* seg_partial,
+                     int B, int H, int W, int C, hipStream_t s) {
+  KD_REQUIRE(H % 4 == 0 && W % 4 == 0 && ldy >= C && C % 2 == 0 && ldy % 2 == 0 && ldres % 2 == 0 &&
+                 (((uintptr_t)y | (uintptr_t)res | (uintptr_t)bias) & 7) == 0,
+             "Winograd F(4x4,3x3) output transform needs H % 4 == 0, W % 4 == 0, even C / row strides, 8-byte aligned maps");
+  KD_REQUIRE(!seg_partial || C % 128 == 0 || (C % 16 == 0 && ((int64_t)B * (H / 4) * (W / 4) * (C / 2)) % 64 == 0),
+             "output statistics need whole waves of 16-channel segments");
+  const int64_t nt = (int64_t)B * (H / 4) * (W / 4), total = nt * (C / 2);
+  hipLaunchKernelGGL(wino4_out_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, D, bias, res, ldres, y, ldy,
+                     seg_partial, B, H, W, C, nt);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace kd

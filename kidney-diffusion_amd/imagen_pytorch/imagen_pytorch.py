@@ -543,7 +543,8 @@ class Unet(nn.Module):
         # engine extension (not a library kwarg): 0 = auto (Winograd for the deep 3x3 convs), 1 = direct only
         conv_algo = int(getattr(self, "conv_algo", os.environ.get("KD_CONV_ALGO", "0")))
         slice_mb = int(getattr(self, "wino_slice_mb", 0))   # engine extension: workspace cap of the batched Winograd layers
-        key = (batch, image_size, device.index, bool(with_text), conv_algo, self.attn_qk_norm, slice_mb) + \
+        w43 = int(getattr(self, "wino43_min_cin", 0))       # engine extension: F(4x4,3x3) threshold (0 = default, < 0 = never)
+        key = (batch, image_size, device.index, bool(with_text), conv_algo, self.attn_qk_norm, slice_mb, w43) + \
             ((replica,) if replica else ())   # (the structural forks drop every plan when they change)
         if self._engines:
             fp = self._weights_fingerprint()
@@ -579,6 +580,7 @@ class Unet(nn.Module):
         cfg.conv_algo = conv_algo
         cfg.attn_qk_norm = self.attn_qk_norm
         cfg.wino_slice_mb = slice_mb
+        cfg.wino43_min_cin = w43
         cfg.downsample_conv4 = int(self.downsample_form == "conv4x4")
         cfg.mid_attn_plain = int(self.mid_attn_form == "residual_attention")
 

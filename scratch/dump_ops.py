@@ -6,6 +6,8 @@ from imagen_pytorch import _engine as E
 lib=E.load(); dev=torch.device('cuda:0')
 B=int(sys.argv[1]) if len(sys.argv)>1 else 16
 u=bench.build_unet(0)
+import os
+if 'KD_W43' in os.environ: u.wino43_min_cin=int(os.environ['KD_W43'])
 h=u.engine(B, 256, dev, with_text=False)
 x,lowres,ln,cond=bench.synthetic_inputs(B, dev)
 t=torch.full((B,),0.3,device=dev); tl=torch.full((B,),-1.0,device=dev); out=torch.empty_like(x)

@@ -19,7 +19,8 @@ for path in sys.argv[1:]:
     print(f"== {path}: {len(rows)} launches, {tot / 1e3:.3f} ms")
     fused = sum(v[1] for k, v in cls.items() if k.startswith("wino fused"))
     fmf = sum(v[2] for k, v in cls.items() if k.startswith("wino fused"))
-    print(f"   fused Winograd convs: {fused / 1e3:.3f} ms, {2 * fmf / fused / 1e6 / 157.3:.3f} of peak")
+    if fused:
+        print(f"   fused Winograd convs: {fused / 1e3:.3f} ms, {2 * fmf / fused / 1e6 / 157.3:.3f} of peak")
     for k, (n, us, mf) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
         frac = f"{2 * mf / us / 1e6 / 157.3:.3f}" if mf else "     "
         print(f"   {us:9.1f} us {n:4d} x {us / n:8.1f}  {frac}  {k}")

@@ -121,6 +121,35 @@ def test_c3_sr_unet_forward_and_sampler_steps_match_oracle(device, c3, conv_algo
     assert (sgot.cpu() - c3["sref"]).abs().max() < SAMPLE_ABS
 
 
+def test_c3_sr_unet_at_the_benchmark_batch_matches_oracle(device, c3):
+    """The plan bench.py times: batch 16, where the 31 ResnetBlock 3x3 convs with Cin >= 512 (the 32x32 and 16x16 levels)
+    run as Winograd F(4x4,3x3) and the other 25 as the fused F(2x2,3x3) kernel (at batch 2, above, the deep levels do not
+    fill whole 128-row tile slabs and stay on F(2x2,3x3)).  One forward against the oracle (7.3 TFLOP on the host)."""
+    import ctypes as C
+    from imagen_pytorch import _engine as E
+
+    ou = c3["ou"]
+    B, S = 16, 256
+    x, lr, cond, t, tl = _fwd_inputs(B, S, True, 3, seed=15)
+    with torch.no_grad():
+        ref = ou(x, t, lowres_cond_img=lr, lowres_noise_times=tl, cond_images=cond)
+    dv = _dv(device)
+    errs = {}
+    for w43 in (0, -1):   # default plan, and the plan without F(4x4,3x3)
+        pu = H.product_unet_like(ou).to(device)
+        pu.wino43_min_cin = w43
+        got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
+        errs[w43] = H.rel_l2(got, ref)
+        buf = C.create_string_buffer(1 << 20)
+        E.check(E.load().kd_unet_profile(pu.engine(B, S, device, with_text=False), 1, buf, len(buf), E.current_stream()))
+        labels = buf.value.decode()
+        assert labels.count("wino4 gemm") == (31 if w43 == 0 else 0), labels.count("wino4 gemm")
+        assert labels.count("wino fused") == (25 if w43 == 0 else 56), labels.count("wino fused")
+        del pu
+    print(f"C3 forward at batch 16: rel-L2 {errs[0]:.3e} with F(4x4,3x3) on 31 layers, {errs[-1]:.3e} without")
+    assert errs[0] < FWD_REL_L2 and errs[-1] < FWD_REL_L2, errs
+
+
 # ------------------------------------------------------------------------------- C1: end to end
 def test_c1_uncond_base_unet_50_steps_end_to_end(device):
     """BASELINE configs[0]: unconditional base UNet 64x64, 50 DDPM steps, batch 1 - the whole sampler on both

@@ -168,6 +168,64 @@ def test_conv3x3_winograd_matches_direct(lib, device, B, H, W, Cin, Cout):
     assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), "element-wise outlier"
 
 
+# Winograd F(4x4,3x3): transform matrices with entries up to 8 and 1/24 - fp32 re-association error 6-8x that of
+# F(2x2,3x3) (scratch/wino43_accuracy.py: 3-4e-6 at Cin = 512 .. 2048); still inside the 2e-5 of one UNet forward
+WINO4_REL = 8e-6
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,res,stats", [
+    (16, 16, 16, 1024, 1024, False, True),   # the SR UNet's deepest level at the benchmark's batch: Mt = 256
+    (16, 32, 32, 512, 512, True, True),      # its 32x32 level, residual in the output transform
+    (4, 32, 32, 64, 192, True, False),       # Mt = 256 over four images, three 64-channel blocks
+    (1, 64, 64, 32, 64, False, True),        # one image, Mt = 256, short K
+    (16, 16, 16, 2048, 128, False, True),    # the concat convs' K
+    (8, 16, 16, 512, 256, True, True),       # Mt = 128: one 128-row tile per weight slab (batch 8 at the 16x16 level)
+])
+def test_conv3x3_winograd4_matches_direct(lib, device, B, H, W, Cin, Cout, res, stats):
+    E = _E()
+    h = torch.randn(B, Cin, H, W, generator=g(1)) * 1.2 + 0.2
+    x = F.silu(h)                       # what these layers see: an activated, normalised map
+    w = torch.randn(Cout, Cin, 3, 3, generator=g(2)) * (Cin * 9) ** -0.5
+    b = torch.randn(Cout, generator=g(3))
+    r = torch.randn(B, Cout, H, W, generator=g(4)) if res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if res:
+        ref = ref + r.double()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(device)
+    wd, bd = w.to(device), b.to(device)
+    rd = r.permute(0, 2, 3, 1).contiguous().to(device) if res else None
+    G = 8
+    want_stats = stats and (Cout // G) % 16 == 0
+    y = torch.full((B, H, W, Cout), float("nan"), device=device)
+    ostats = torch.full((B, G, 2), float("nan"), device=device)
+    call = lambda out: E.check(lib.kd_conv3x3_winograd4_nhwc(
+        E.ptr(xd), E.ptr(wd), E.ptr(bd), E.ptr(rd) if res else None, E.ptr(out), B, H, W, Cin, Cout, G, 1e-5,
+        E.ptr(ostats) if want_stats else None, E.current_stream()))
+    call(y)
+    got = y.permute(0, 3, 1, 2).cpu().double()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).norm() / ref.norm())
+    print(f"F(4x4,3x3) Cin {Cin} {H}x{W}: rel-L2 {err:.2e}, max {float((got - ref).abs().max() / ref.abs().max()):.2e}")
+    assert err <= WINO4_REL, err
+    assert float((got - ref).abs().max()) <= 5e-5 * float(ref.abs().max()), "element-wise outlier"
+    if want_stats:
+        grp = ref.reshape(B, G, -1)
+        got_s = ostats.cpu().double()
+        assert torch.allclose(got_s[..., 0], grp.mean(dim=-1), rtol=0, atol=1e-5 * float(ref.abs().max()))
+        assert torch.allclose(got_s[..., 1], (grp.var(dim=-1, unbiased=False) + 1e-5).rsqrt(), rtol=2e-5, atol=0)
+    y2 = torch.empty_like(y)
+    call(y2)
+    assert torch.equal(y, y2)
+
+
+def test_conv3x3_winograd4_rejects_unsupported_shapes(lib, device):
+    E = _E()
+    t = torch.zeros(16, device=device)
+    for shape in [(1, 18, 16, 32, 64), (1, 16, 16, 32, 64), (16, 16, 16, 48, 64), (16, 16, 16, 32, 96)]:
+        rc = lib.kd_conv3x3_winograd4_nhwc(E.ptr(t), E.ptr(t), None, None, E.ptr(t), *shape, 8, 1e-5, None, E.current_stream())
+        assert rc != 0 and b"F(4x4,3x3)" in lib.kd_last_error()
+
+
 def test_conv3x3_winograd_rejects_unsupported_shapes(lib, device):
     E = _E()
     t = torch.zeros(16, device=device)

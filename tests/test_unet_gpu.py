@@ -92,6 +92,38 @@ def test_unet_forward_with_winograd_levels_matches_oracle(device):
     assert torch.equal(outs[(32, "1")], outs[(32, None)]), "sliced and unsliced Winograd must be bit-identical"
 
 
+def test_unet_forward_with_winograd_f4_levels_matches_oracle(device):
+    """conv_algo = 4: every ResnetBlock 3x3 conv whose shape fits runs as Winograd F(4x4,3x3) (36 batched GEMMs, GroupNorm /
+    FiLM / SiLU in the input transform, bias / residual / next layer's GroupNorm partials in the output transform); the
+    default plan takes that form for Cin >= 512 only, which no reduced-dim model reaches.  ultra2 / ultra3 at dim 32,
+    batch 16, 128 x 128: the 32 x 32 (C = 64) and 16 x 16 (C = 128) levels qualify - skip concats, cross-attention
+    blocks and the blocks whose residual rides in the output transform included."""
+    import ctypes as C
+    from imagen_pytorch import _engine as E
+
+    for name in ("ultra2", "ultra3"):
+        B, S = 16, 128
+        ou = H.oracle_unet(name, lowres_cond=True, seed=23).eval()
+        x, lr, cond, t, tl = _inputs(name, B, S, True, seed=9)
+        with torch.no_grad():
+            ref = ou(x, t, lowres_cond_img=lr, lowres_noise_times=tl, cond_images=cond)
+        dv = lambda v: None if v is None else v.to(device)
+        outs = {}
+        for algo in (4, 1):
+            pu = H.product_unet_like(ou).to(device)
+            pu.conv_algo = algo
+            got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
+            err = H.rel_l2(got, ref)
+            assert err < FWD_REL_L2, f"{name} conv_algo={algo}: rel-L2 {err:.3e}"
+            outs[algo] = got.clone()   # (kd_unet_profile runs the plan again on the pointers of the last forward: `got` is its output)
+            buf = C.create_string_buffer(1 << 20)
+            E.check(E.load().kd_unet_profile(pu.engine(B, S, device, with_text=False), 1, buf, len(buf), E.current_stream()))
+            n4 = buf.value.decode().count("wino4 gemm")
+            assert (n4 >= 8) == (algo == 4), f"{name} conv_algo={algo}: {n4} F(4x4,3x3) layers in the plan"
+            print(f"{name} conv_algo={algo}: rel-L2 vs oracle {err:.2e} ({n4} F(4x4,3x3) layers)")
+        assert H.rel_l2(outs[4], outs[1]) < FWD_REL_L2
+
+
 def test_return_pil_images_truncates_like_the_library(device):
     """sample(return_pil_images=True) (sample_cond.py:42, sample.py:53): the library maps torchvision's
     ToPILImage over the float images, i.e. mul(255).byte() - truncation, not rounding."""
