@@ -172,6 +172,7 @@ struct kd_unet {
   std::vector<float> s_tables_host;  // what s_tables holds (9 x T): an unchanged schedule is not uploaded again
   float* s_tables_pinned = nullptr;  // staging for the asynchronous upload
   size_t s_tables_pinned_floats = 0;
+  hipEvent_t s_tables_ev = nullptr;  // recorded behind the last upload from the staging buffer (whatever stream it ran on)
   // cached graph of one iteration
   hipGraphExec_t graph_exec = nullptr;
   hipStream_t cap_stream = nullptr;
@@ -185,6 +186,7 @@ struct kd_unet {
     for (void* p : frees)
       if (p) (void)hipFree(p);
     if (s_tables_pinned) (void)hipHostFree(s_tables_pinned);
+    if (s_tables_ev) (void)hipEventDestroy(s_tables_ev);
   }
 };
 

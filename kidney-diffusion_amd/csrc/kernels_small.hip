@@ -239,12 +239,16 @@ __global__ __launch_bounds__(256) void gca_partial_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void gca_combine_kernel(const float* __restrict__ part, float* __restrict__ pooled,
                                                           int nchunks, int C) {
-  // grid (B, ceil(C/64)); 4 waves: lane = channel, wave = chunk subset
+  // grid (B, ceil(C/16)): a block merges 16 channels over all chunks - lane & 15 = channel, the other 4 thread-index
+  // bits = one of 16 chunk subsets (i = sub, sub + 16, ..).  (Round 2 ran 64 channels per block with 4 chunk subsets: a
+  // batch-1 patch with 1024 chunks then had C / 64 = 2 .. 16 blocks walking 256 dependent loads each - 40 of the 56 us
+  // of a stage-3 GlobalContext pooling.)  Fixed summation order: bit-identical from run to run.
   __shared__ float se[1024];   // exp(m_i - mg) per chunk (nchunks <= 1024)
   __shared__ float red[8];
-  __shared__ float sacc[4][64];
+  __shared__ float sacc[16][16];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + lane;
+  const int cl = threadIdx.x & 15, sub = threadIdx.x >> 4;
+  const int c = blockIdx.y * 16 + cl;
   const float* pb = part + (int64_t)b * nchunks * (C + 2);
   float m = -INFINITY;
   for (int i = threadIdx.x; i < nchunks; i += 256) m = fmaxf(m, pb[(int64_t)i * (C + 2)]);
@@ -265,10 +269,15 @@ __global__ __launch_bounds__(256) void gca_combine_kernel(const float* __restric
   const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
   float s = 0.f;
   if (c < C)
-    for (int i = wave; i < nchunks; i += 4) s += pb[(int64_t)i * (C + 2) + 2 + c] * se[i];
-  sacc[wave][lane] = s;
+    for (int i = sub; i < nchunks; i += 16) s += pb[(int64_t)i * (C + 2) + 2 + c] * se[i];
+  sacc[sub][cl] = s;
   __syncthreads();
-  if (wave == 0 && c < C) pooled[(int64_t)b * C + c] = ((sacc[0][lane] + sacc[1][lane]) + (sacc[2][lane] + sacc[3][lane])) * inv;
+  if (sub == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sacc[k][cl];
+    pooled[(int64_t)b * C + c] = t * inv;
+  }
 }
 
 size_t gca_scratch_floats(int B, int HW, int C) {
@@ -288,7 +297,7 @@ int launch_gca_pool(const float* x, const float* wk, const float* bk, float* /*l
   else if (C4 <= 128) hipLaunchKernelGGL((gca_partial_kernel<2, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
   else if (C4 <= 256) hipLaunchKernelGGL((gca_partial_kernel<4, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
   else hipLaunchKernelGGL((gca_partial_kernel<8, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
-  hipLaunchKernelGGL(gca_combine_kernel, dim3(B, (C + 63) / 64), dim3(256), 0, s, scratch, pooled, chunks, C);
+  hipLaunchKernelGGL(gca_combine_kernel, dim3(B, (C + 15) / 16), dim3(256), 0, s, scratch, pooled, chunks, C);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -18,8 +18,13 @@ DOMINANT = "wino_fused_gn128_kernel"
 
 def main():
     src, tag = Path(sys.argv[1]), sys.argv[2]
-    for name in ("kernel_stats.csv", "pmc_fetch.csv", "pmc_write.csv", "sq_summary.json", "stats_bench.json"):
+    import gzip
+
+    for name in ("kernel_stats.csv", "sq_summary.json", "stats_bench.json"):
         shutil.copy(src / name, HERE / f"{tag}_{name}")
+    for name in ("pmc_fetch.csv", "pmc_write.csv"):   # the raw per-dispatch tables: compressed (their reduction is <tag>_hbm_traffic.json)
+        with open(src / name, "rb") as fi, gzip.open(HERE / f"{tag}_{name}.gz", "wb", compresslevel=9) as fo:
+            shutil.copyfileobj(fi, fo)
     out = subprocess.run([sys.executable, str(HERE / "reduce_pmc.py"), str(src / "pmc_fetch.csv"), str(src / "pmc_write.csv"), "4"],
                          capture_output=True, text=True, check=True).stdout
     traffic = json.loads(out)
@@ -41,7 +46,7 @@ def main():
         "dominant_mfma_util": dom_sq["mfma_util"],
         "bytes_per_step": traffic["bytes_per_step"],
         "source": f"profiles/{tag}_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 2 "
-                  f"--no-cpu-baseline --no-kernel-classes`), profiles/{tag}_pmc_fetch.csv + {tag}_pmc_write.csv (separate "
+                  f"--no-cpu-baseline --no-kernel-classes`), profiles/{tag}_pmc_fetch.csv.gz + {tag}_pmc_write.csv.gz (separate "
                   "--pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md), "
                   f"profiles/{tag}_sq_summary.json (SQ_VALU_MFMA_BUSY_CYCLES pass)",
     }
