@@ -93,6 +93,28 @@ def kernel_classes(lib, handle, iters=3):
         c[3] += issued
         c[4] += nbytes
 
+    def hbm_bytes(label):
+        """Algorithmic HBM bytes of an HBM-bound launch from its label (every map read / written once; fp32)."""
+        g = lambda pat: [int(v) for v in re.match(pat, label).groups()] if re.match(pat, label) else None
+        v = g(r"gate_add HW(\d+) C(\d+)")
+        if v: return 3 * 4.0 * BATCH * v[0] * v[1]                  # h2, x in; out
+        v = g(r"gca_pool HW(\d+) C(\d+)")
+        if v: return 4.0 * BATCH * v[0] * v[1]                      # one read of the map
+        v = g(r"gn stats HW(\d+) C(\d+)")
+        if v: return 4.0 * BATCH * v[0] * v[1]
+        v = g(r"gn apply HW(\d+) C(\d+)")
+        if v: return 2 * 4.0 * BATCH * v[0] * v[1]
+        v = g(r"ln rows(\d+) C(\d+)")
+        if v: return 2 * 4.0 * v[0] * v[1]
+        v = g(r"(?:scale slice|skip copy|concat head|concat tail|concat) rows(\d+) C(\d+)")
+        if v: return 2 * 4.0 * v[0] * v[1]
+        v = g(r"attn N(\d+)")
+        if v: return 4.0 * BATCH * v[0] * (2 * 512 + 2 * 64)      # q, o: 8 heads x 64; k, v: one shared head
+        v = g(r"xattn Nq(\d+) Nk(\d+)")
+        if v: return 4.0 * BATCH * (2 * v[0] * 512 + 2 * v[1] * 512)
+        if label.startswith("final gather"): return 4.0 * BATCH * SIZE * SIZE * (32 + 3 + 3)
+        return 0.0   # GroupNorm folds, tiny element-wise launches: latency, not bytes
+
     total_us = 0.0
     for _, label, macs, us, mfma in rows:
         us, macs, mfma = float(us), int(macs), int(mfma)
@@ -121,7 +143,7 @@ def kernel_classes(lib, handle, iters=3):
             add("conv_buf_kernel / conv_igemm_kernel / init_conv_kernel: 1x1, 2x2-s2, init and final convs, token GEMMs", us,
                 2.0 * macs, 2.0 * (mfma or macs))
         else:
-            add("GroupNorm, LayerNorm, attention core, GlobalContext, concat, gate (HBM-bound)", us)
+            add("GroupNorm, LayerNorm, attention core, GlobalContext, concat, gate (HBM-bound)", us, nbytes=hbm_bytes(label))
     out = []
     for key, (n, us, flop, issued, nbytes) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
         e = {"kernel": key, "launches": n, "ms": us / 1e3, "avg_us": us / n, "share": us / total_us}
@@ -335,15 +357,28 @@ def grid_workload(args, world, rank, device, distributed, barrier, canvases_list
     imagens = {}
 
     def load_imagen(stage):  # train_ultra_res.py:79-90 with one real UNet resident per Imagen
-        torch.manual_seed(100 + stage)
-        unets = tuple(ip.Unet(**ULTRA_UNETS[i]) if i == stage else FixedNullUnet(lowres_cond=i > 1) for i in (1, 2, 3))
+        # Built on the meta device and initialised ON THE GPU from a per-stage seed: every rank gets bit-identical
+        # weights (patches sampled on different ranks must agree) without 8 ranks each drawing 2 x 10^9 numbers on
+        # the host cores they share.  Matrices N(0, 1 / fan_in), norm gains 1, biases 0, final conv N(0, 0.02).
+        with torch.device("meta"):
+            unets = tuple(ip.Unet(**ULTRA_UNETS[i]) if i == stage else FixedNullUnet(lowres_cond=i > 1) for i in (1, 2, 3))
+            im = ip.Imagen(unets=unets, image_sizes=(64, 256, 1024), timesteps=(T, T, T),
+                           pred_objectives=("noise", "noise", "noise"), random_crop_sizes=(None, None, 256),
+                           condition_on_text=False)
+        im = im.to_empty(device=device)
+        gen = torch.Generator(device=device).manual_seed(100 + stage)
         with torch.no_grad():
-            fc = unets[stage - 1].final_conv
-            fc.weight.normal_(0, 0.02)
-            fc.bias.normal_(0, 0.02)
-        im = ip.Imagen(unets=unets, image_sizes=(64, 256, 1024), timesteps=(T, T, T),
-                       pred_objectives=("noise", "noise", "noise"), random_crop_sizes=(None, None, 256),
-                       condition_on_text=False)
+            for name, p_ in im.named_parameters():
+                if "final_conv" in name:
+                    p_.normal_(0, 0.02, generator=gen)
+                elif p_.dim() > 1:
+                    p_.normal_(0, float(p_[0].numel()) ** -0.5, generator=gen)
+                elif name.endswith("weights"):             # LearnedSinusoidalPosEmb frequencies
+                    p_.normal_(0, 1.0, generator=gen)
+                elif name.endswith((".g", "weight")):      # 1-D: GroupNorm / LayerNorm gains
+                    p_.fill_(1.0)
+                else:                                      # biases, placeholders
+                    p_.zero_()
         imagens[stage] = im
         return im
 

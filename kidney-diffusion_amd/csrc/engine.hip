@@ -781,8 +781,11 @@ struct Builder {
     const int64_t Mt = (int64_t)x.B * (x.H / 4) * (x.W / 4);
     if (Mt % 128 || 36 * Mt >= 0x7fffffff || (int64_t)36 * cout * x.C * 4 >= 0x7fffffff) return false;
     if (cfg.conv_algo == 4) return true;
-    const int min_cin = cfg.wino43_min_cin > 0 ? cfg.wino43_min_cin : 512;
-    return x.C >= min_cin && (36 * Mt / 128) * (cout / 64) >= 512;
+    if ((36 * Mt / 128) * (cout / 64) < 512) return false;   // the 36 GEMMs must fill the chip
+    // default threshold Cin >= 512.  Below it the transform passes (6.5 x the map through HBM) eat the GEMM saving:
+    // same-box A/B against the fused F(2x2,3x3) kernel at batch 16: 256 -> 256 at 64 x 64 299 -> 286 us (-4 %, not
+    // worth six times the per-conv rounding error), 256 -> 128 at 128 x 128 626 -> 737 (+18 %), at 256 x 256 +17 %
+    return x.C >= (cfg.wino43_min_cin > 0 ? cfg.wino43_min_cin : 512);
   }
   T wino4_block(const T& x, const std::string& gn_prefix, int ss_col, const std::string& conv_prefix, int Cout,
                 const T* res) {

@@ -388,6 +388,46 @@ def test_makefile_tracks_header_dependencies(tmp_path):
     assert planned() == []
 
 
+def test_bench_launches_its_own_ranks_when_called_without_a_launcher(monkeypatch):
+    """`python bench.py --gpus N` is how the driver may call the benchmark: without WORLD_SIZE it must start N ranks itself
+    (torch.distributed.run as a CHILD process, before any GPU call, rendezvous on 127.0.0.1), hand them its own arguments
+    and exit with their code; under a launcher (WORLD_SIZE set) it must not spawn."""
+    import importlib
+    import subprocess
+    import sys
+
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    calls = []
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        calls.append((cmd, env))
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # one rank needs no launcher: main() goes on (and stops at the first GPU call on this box)
+    calls.clear()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1"])
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            bench.main()
+    assert not calls
+
+
 def test_philox_host_reference_is_standard_normal_and_keyed():
     from oracle.philox_ref import philox4x32_10, philox_normal
 
