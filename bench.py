@@ -291,6 +291,7 @@ def engine_parity(unet, first, device, lib):
     sa = E.kd_sample_args_t()
     sa.objective, sa.dynamic_threshold, sa.percentile, sa.resample_times = 0, 1, 0.95, 1
     sa.d_lowres, sa.d_lowres_log_snr, sa.d_cond_images = E.ptr(lowres), E.ptr(ls_lr), E.ptr(cond)
+    sa.lowres_log_snr_uniform, sa.lowres_log_snr_value = 1, float(ls_lr[0])
     sa.d_noise_step = E.ptr(noise)   # index 0 of the [T*R, B, 3, S, S] layout
     sa.use_graph = 1
     E.check(lib.kd_sample_steps(h, C.byref(sc), C.byref(sa), E.ptr(x), 0, 1, E.current_stream()))
@@ -595,6 +596,7 @@ def main():
     sa = E.kd_sample_args_t()
     sa.objective, sa.dynamic_threshold, sa.percentile, sa.resample_times = 0, 1, 0.95, 1
     sa.d_lowres, sa.d_lowres_log_snr, sa.d_cond_images = E.ptr(lowres), E.ptr(lowres_log_snr), E.ptr(cond)
+    sa.lowres_log_snr_uniform, sa.lowres_log_snr_value = 1, float(ls_lr[0])   # one augmentation level (0.2) for the batch
     sa.seed = 1234 + rank  # per-step noise: on-device Philox inside the fused DDPM-update kernel
     sa.use_graph = 0 if args.no_graph else 1
 

@@ -214,6 +214,14 @@ typedef struct kd_sample_args {
   float cond_scale;           /* 1.0 = off */
   const float* d_null_text_tokens;
   const float* d_null_text_hiddens;
+  /* Conditioning table: when the UNet has no text conditioning and (if it is low-res conditioned) the caller states that
+   * all B entries of d_lowres_log_snr hold ONE value (what Imagen.sample passes), the time conditioning of a step - time
+   * embeddings, FiLM scale / shift of every ResnetBlock, time tokens and their cross-attention K / V - is a function of
+   * the schedule index alone: it is computed once per (schedule, value) into a table and restored per iteration by one
+   * gather.  Bit-identical results either way.  cond_table: 0 = use it when possible, < 0 = never. */
+  int lowres_log_snr_uniform;   /* 1: all entries of d_lowres_log_snr equal lowres_log_snr_value */
+  float lowres_log_snr_value;
+  int cond_table;
 } kd_sample_args_t;
 
 /* In: d_img = x_T [B,3,S,S].  Out: d_img = unnormalised sample in [0,1] (clamp, final inpaint

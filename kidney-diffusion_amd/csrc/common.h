@@ -270,6 +270,7 @@ int launch_seed_set(uint64_t* d_seed, uint64_t value, hipStream_t s);
 int launch_renoise(float* x, const float* noise, int64_t noise_stride, const uint64_t* d_seed, const StepTables& tb,
                    const int* d_iter, int R, int T, int B, int64_t per, hipStream_t s);
 int launch_iter_set(int* d_iter, int value, hipStream_t s);
+int launch_cond_gather(const void* tab, void* dst, size_t bytes, const int* d_iter, int R, hipStream_t s);
 int launch_finalize(float* x, const float* inp, const float* mask, int B, int C, int64_t hw, hipStream_t s);
 int launch_iter_inc(int* d_iter, hipStream_t s);
 int launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, hipStream_t s);

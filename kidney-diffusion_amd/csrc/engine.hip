@@ -178,11 +178,25 @@ struct kd_unet {
   hipStream_t cap_stream = nullptr;
   std::vector<uint64_t> graph_key;
 
-  float* P(size_t off) const { return (float*)(ws + off); }
+  // ---- step-invariant-per-schedule-index conditioning (time embeddings, FiLM scale / shift, time tokens and their
+  // cross-attention K / V): ops flagged op_is_cond write only into the `cond_ws` region (offsets carry COND_FLAG); the
+  // sampler can run them once per schedule step into `cond_tab` and replay a step with one gather instead
+  static constexpr size_t COND_FLAG = size_t(1) << 62;
+  std::vector<char> op_is_cond;
+  char* cond_ws = nullptr;
+  size_t cond_bytes = 0;
+  char* cond_tab = nullptr;        // [T][cond_bytes]
+  size_t cond_tab_bytes = 0;
+  std::vector<float> cond_tab_sched;   // the schedule (9 x T) the table was built for
+  int cond_tab_T = 0;
+  float cond_tab_lowres = 0.f;
+  bool cond_tab_valid = false;
+
+  float* P(size_t off) const { return (float*)((off & COND_FLAG) ? cond_ws + (off & ~COND_FLAG) : ws + off); }
   ~kd_unet() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
-    void* frees[] = {ws, s_pred, s_x0, s_thresh, s_time, s_tables, s_iter, s_seed, s_qws, s_pred_null};
+    void* frees[] = {ws, s_pred, s_x0, s_thresh, s_time, s_tables, s_iter, s_seed, s_qws, s_pred_null, cond_ws, cond_tab};
     for (void* p : frees)
       if (p) (void)hipFree(p);
     if (s_tables_pinned) (void)hipHostFree(s_tables_pinned);
@@ -269,16 +283,37 @@ struct Builder {
   }
 
   // ---- activations
+  // to_cond: the ops being emitted compute conditioning that depends on the inputs log_snr / lowres_log_snr / text only
+  // (never on x): they are flagged, and everything they allocate lives in the permanent cond region (bump-allocated,
+  // never reused), so the sampler can snapshot / restore that region per schedule step (kd_unet::cond_tab)
+  bool to_cond = false;
+  size_t cond_end = 0;
+  size_t cond_alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~size_t(255);
+    if (bytes == 0) bytes = 256;
+    const size_t off = cond_end;
+    cond_end += bytes;
+    return kd_unet::COND_FLAG | off;
+  }
   T alloc(int b, int h, int w, int c) {
     T t;
     t.B = b; t.H = h; t.W = w; t.C = c;
-    t.off = arena.alloc((size_t)b * h * w * c * sizeof(float));
+    const size_t bytes = (size_t)b * h * w * c * sizeof(float);
+    if (to_cond) {
+      t.off = cond_alloc(bytes);
+      return t;
+    }
+    t.off = arena.alloc(bytes);
     refs[t.off] = 1;
     return t;
   }
   T alloc_bytes(size_t bytes) {
     T t;
     t.B = 1; t.H = 1; t.W = 1; t.C = (int)((bytes + 3) / 4);
+    if (to_cond) {
+      t.off = cond_alloc(bytes);
+      return t;
+    }
     t.off = arena.alloc(bytes);
     refs[t.off] = 1;
     return t;
@@ -286,8 +321,12 @@ struct Builder {
   // every builder function returns a tensor owned by the caller (refcount 1) and never releases
   // its inputs; skip connections take an extra reference with retain().
   std::unordered_map<size_t, int> refs;
-  void retain(const T& t) { refs[t.off] += 1; }
+  void retain(const T& t) {
+    if (t.off & kd_unet::COND_FLAG) return;
+    refs[t.off] += 1;
+  }
   void free(const T& t) {
+    if (t.off & kd_unet::COND_FLAG) return;   // the cond region is permanent
     auto it = refs.find(t.off);
     if (it == refs.end() || it->second <= 0) throw std::runtime_error("plan: release of a dead tensor");
     if (--it->second == 0) {
@@ -402,6 +441,7 @@ struct Builder {
     }, "gn stats HW" + std::to_string(HW) + " C" + std::to_string(C));
     return false;
   }
+  bool cond_hoist = true;  // (false inside the text sub-plan)
   bool to_text = false;    // building the text-conditioning sub-plan: ops go to u->text_ops
   bool to_static = false;  // emitting step-invariant work (run once per sampling call): u->static_ops
   const float* P_(const std::string& n) { return P(n); }
@@ -418,6 +458,7 @@ struct Builder {
     u->op_label.push_back(std::move(label));
     u->op_macs.push_back(macs);
     u->op_mfma.push_back(0);
+    u->op_is_cond.push_back(to_cond ? 1 : 0);
   }
 
   // ---- conv / GEMM emission
@@ -634,12 +675,14 @@ struct Builder {
     T xn = layernorm(x, P(pre + ".norm.g", dim), nullptr);
     T q = linear(xn, P(pre + ".to_q.weight", (int64_t)inner * dim), nullptr, inner);
     free(xn);
+    // K / V of the conditioning tokens: a function of c alone (cond region, see to_cond)
+    const bool was_cond = to_cond;
+    to_cond = cond_hoist;
     T kv = linear(c, P(pre + ".to_kv.weight", (int64_t)2 * inner * c.C), nullptr, 2 * inner);
+    if (cfg.attn_qk_norm) qk_norm(kv, 2 * inner, H, k_scale_of(pre));
+    to_cond = was_cond;
     const float* nkv = null_kv_of(pre);
-    if (cfg.attn_qk_norm) {
-      qk_norm(q, inner, H, q_scale_of(pre));
-      qk_norm(kv, 2 * inner, H, k_scale_of(pre));
-    }
+    if (cfg.attn_qk_norm) qk_norm(q, inner, H, q_scale_of(pre));
     T o = alloc(x.B, x.H, x.W, inner);
     {
       size_t qo = q.off, kvo = kv.off, oo = o.off;
@@ -674,17 +717,20 @@ struct Builder {
     free(xn);
     T ckv;
     bool has_ctx = ctx != nullptr;
-    if (has_ctx) {
+    if (has_ctx) {   // K / V of the context tokens: a function of c alone (cond region)
+      const bool was_cond = to_cond;
+      to_cond = cond_hoist;
       T cn = layernorm(*ctx, P(a + ".to_context.0.weight", ctx->C), P(a + ".to_context.0.bias", ctx->C));
       ckv = linear(cn, P(a + ".to_context.1.weight", (int64_t)2 * D * ctx->C), P(a + ".to_context.1.bias", 2 * D),
                    2 * D);
       free(cn);
+      if (cfg.attn_qk_norm) qk_norm(ckv, 2 * D, 1, k_scale_of(a));
+      to_cond = was_cond;
     }
     const float* nkv = null_kv_of(a);
     if (cfg.attn_qk_norm) {
       qk_norm(q, inner, H, q_scale_of(a));
       qk_norm(kv, 2 * D, 1, k_scale_of(a));
-      if (has_ctx) qk_norm(ckv, 2 * D, 1, k_scale_of(a));
     }
     T o = alloc(x.B, x.H, x.W, inner);
     {

@@ -91,6 +91,21 @@ int launch_fill_time(const float* table, const int* d_iter, int R, float* out, i
   return 0;
 }
 
+// cond region of schedule step (*d_iter / R) out of the per-schedule table -> the live cond region (16 bytes per thread)
+__global__ __launch_bounds__(256) void cond_gather_kernel(const float4* __restrict__ tab, float4* __restrict__ dst, int64_t n16,
+                                                          const int* __restrict__ d_iter, int R) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) dst[i] = tab[(int64_t)(*d_iter / R) * n16 + i];
+}
+int launch_cond_gather(const void* tab, void* dst, size_t bytes, const int* d_iter, int R, hipStream_t s) {
+  KD_REQUIRE(bytes % 16 == 0 && (((uintptr_t)tab | (uintptr_t)dst) & 15) == 0, "cond gather: 16-byte granules");
+  const int64_t n16 = (int64_t)(bytes / 16);
+  hipLaunchKernelGGL(cond_gather_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (const float4*)tab, (float4*)dst, n16,
+                     d_iter, R);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 __global__ void iter_inc_kernel(int* d_iter) { *d_iter += 1; }
 __global__ void iter_set_kernel(int* d_iter, int v) { *d_iter = v; }
 __global__ void seed_set_kernel(uint64_t* d_seed, uint64_t v) { *d_seed = v; }

@@ -89,6 +89,9 @@ class kd_sample_args_t(C.Structure):
         ("cond_scale", C.c_float),
         ("d_null_text_tokens", C.c_void_p),
         ("d_null_text_hiddens", C.c_void_p),
+        ("lowres_log_snr_uniform", C.c_int),
+        ("lowres_log_snr_value", C.c_float),
+        ("cond_table", C.c_int),
     ]
 
 

@@ -951,6 +951,10 @@ class Imagen(nn.Module):
             args.d_inpaint_images, args.d_inpaint_masks = E.ptr(inp), E.ptr(msk)
             args.seed = stage_seed
             args.use_graph = int(bool(use_graph))
+            if unet.lowres_cond:   # one augmentation level for the whole batch (the library's sample() has no other form):
+                args.lowres_log_snr_uniform = 1          # lets the engine table the time conditioning per schedule step
+                args.lowres_log_snr_value = float(ls[0])
+            args.cond_table = int(getattr(self, "cond_table", 0))   # engine extension: < 0 switches the table off
             keep = []
             if exists(noise_fn):
                 def stack(kind):

@@ -124,6 +124,48 @@ def test_unet_forward_with_winograd_f4_levels_matches_oracle(device):
         assert H.rel_l2(outs[4], outs[1]) < FWD_REL_L2
 
 
+def test_conditioning_table_gives_bit_identical_samples(device):
+    """The time conditioning of a step (embeddings, FiLM scale / shift, time tokens, their cross-attention K / V) depends
+    on the schedule index alone when there is no text: the sampler computes it once per schedule into a table and an
+    iteration restores its row with one gather (include/kd_engine.h: kd_sample_args_t::cond_table).  Same kernels, same
+    inputs: samples must be bit-identical with the table off - base and low-res-conditioned UNets, with inpainting
+    resampling (two iterations per schedule step), graph and eager - and a second call (table reused), a call with another
+    low-res level (table rebuilt) and a call with another number of steps must each equal their table-off run."""
+    import imagen_pytorch as ip
+
+    _, pim = _imagen_pair(device, ["ultra1", "ultra2"], (16, 32), (5, 4), ("noise", "v"))
+    g = torch.Generator().manual_seed(21)
+    cond = torch.rand(2, 3, 32, 32, generator=g).to(device)
+    low = torch.rand(2, 3, 16, 16, generator=g).to(device)
+    ipt = torch.rand(2, 3, 32, 32, generator=g).to(device)
+    msk = torch.zeros(2, 32, 32, device=device)
+    msk[:, :8] = 1
+
+    def run(table, **kw):
+        pim.cond_table = 0 if table else -1
+        return pim.sample(batch_size=2, cond_images=cond, device=device, seed=11, **kw)
+
+    cases = [dict(stop_at_unet_number=1),
+             dict(stop_at_unet_number=1, use_graph=False),
+             dict(start_at_unet_number=2, start_image_or_video=low),
+             dict(start_at_unet_number=2, start_image_or_video=low, inpaint_images=ipt, inpaint_masks=msk, inpaint_resample_times=2),
+             dict(start_at_unet_number=2, start_image_or_video=low),                                   # table reused
+             dict(start_at_unet_number=2, start_image_or_video=low, lowres_sample_noise_level=0.35),   # other level: rebuilt
+             dict(start_at_unet_number=2, start_image_or_video=low)]
+    for n, kw in enumerate(cases):
+        a, b = run(True, **kw), run(False, **kw)
+        assert torch.isfinite(a).all() and torch.equal(a, b), (n, float((a - b).abs().max()))
+    assert not torch.equal(run(True, **cases[5]), run(True, **cases[6])), "the low-res level must matter"
+    # another schedule length on the same plan
+    pim2 = ip.Imagen([pim.unets[0], pim.unets[1]], image_sizes=(16, 32), timesteps=(3, 6), pred_objectives=("noise", "v"),
+                     condition_on_text=False).to(device)
+    for table in (0, -1):
+        pim2.cond_table = table
+        out = pim2.sample(batch_size=2, cond_images=cond, start_at_unet_number=2, start_image_or_video=low, device=device, seed=11)
+        ref = out if table == 0 else ref
+        assert torch.equal(out, ref)
+
+
 def test_return_pil_images_truncates_like_the_library(device):
     """sample(return_pil_images=True) (sample_cond.py:42, sample.py:53): the library maps torchvision's
     ToPILImage over the float images, i.e. mul(255).byte() - truncation, not rounding."""
