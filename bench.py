@@ -521,6 +521,9 @@ def main():
                          "on a side stream beside stage 3)")
     ap.add_argument("--grid-batch", type=int, default=1,
                     help="--workload grid: patches of a wave per sample() call in stages 1-2 (1 = the reference's way)")
+    ap.add_argument("--no-cond-table", action="store_true",
+                    help="compute the time conditioning in every step instead of restoring it from the per-schedule table "
+                         "(profiles: keeps the one-off table build, 250 x 24 launches, out of a 7-step trace)")
     ap.add_argument("--no-line-grid", action="store_true",
                     help="sr: leave the nested `grid` object (8x8 grid patches/s for 1 and 3 canvases) out of the line")
     ap.add_argument("--line-grid-steps", type=int, default=4, help="timesteps per stage of the nested grid runs")
@@ -597,6 +600,7 @@ def main():
     sa.objective, sa.dynamic_threshold, sa.percentile, sa.resample_times = 0, 1, 0.95, 1
     sa.d_lowres, sa.d_lowres_log_snr, sa.d_cond_images = E.ptr(lowres), E.ptr(lowres_log_snr), E.ptr(cond)
     sa.lowres_log_snr_uniform, sa.lowres_log_snr_value = 1, float(ls_lr[0])   # one augmentation level (0.2) for the batch
+    sa.cond_table = -1 if args.no_cond_table else 0
     sa.seed = 1234 + rank  # per-step noise: on-device Philox inside the fused DDPM-update kernel
     sa.use_graph = 0 if args.no_graph else 1
 
