@@ -212,6 +212,8 @@ struct KVSeg {
 int launch_attention(const float* q, int ldq, const float* null_k, const float* null_v, KVSeg s0, KVSeg s1,
                      float* out, int ldo, int B, int Nq, int H, int Hkv, float scale, hipStream_t s);
 // y[m][n] = act( sum_k f(x[m][k]) * w[n][k] + bias[n] ) for small M (<= 64); in_act applied to x
+int launch_linear_gemv(const float* x, const float* w, const float* bias, float* y, int K, int N, int in_act, int act,
+                       hipStream_t s);
 int launch_linear_skinny(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int M,
                          int K, int N, int in_act, int act, hipStream_t s);
 int launch_linear_skinny_valu(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int M,

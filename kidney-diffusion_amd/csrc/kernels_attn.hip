@@ -403,6 +403,41 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restr
   }
 }
 
+// One row of x (a batch-1 patch: GlobalContext FCs, time MLPs): a GEMV.  One wave per output row, 16-byte loads along K, x
+// from LDS; N / 4 workgroups (the MFMA form below runs N / 32 workgroups of 32 rows and spends 31 of its 32 MFMA columns on
+// padding: 19 us per launch for 2 MB of weights on a grid of 16 - launch-latency bound)
+__global__ __launch_bounds__(256) void linear_gemv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int K, int N,
+                                                          int in_act, int act) {
+  extern __shared__ __attribute__((aligned(16))) float xs1[];   // K floats
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < K; k += 256) xs1[k] = act_f(x[k], in_act);
+  __syncthreads();
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  const float* wr = w + (int64_t)n * K;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int kk = lane * 4; kk < K; kk += 256) {   // (K % 4 == 0, 16-byte aligned rows: checked at launch)
+    const f32x4 wv = *(const f32x4*)(wr + kk);
+    const f32x4 xv = *(const f32x4*)(xs1 + kk);
+    a0 = fmaf(xv[0], wv[0], a0);
+    a1 = fmaf(xv[1], wv[1], a1);
+    a2 = fmaf(xv[2], wv[2], a2);
+    a3 = fmaf(xv[3], wv[3], a3);
+  }
+  float t = wave_sum((a0 + a1) + (a2 + a3));
+  if (lane == 0) y[n] = act_f(t + (bias ? bias[n] : 0.f), act);
+}
+
+int launch_linear_gemv(const float* x, const float* w, const float* bias, float* y, int K, int N, int in_act, int act,
+                       hipStream_t s) {
+  KD_REQUIRE(K > 0 && N > 0 && (K & 3) == 0 && (((uintptr_t)w) & 15) == 0, "gemv: K % 4 == 0 and 16-byte aligned weights");
+  hipLaunchKernelGGL(linear_gemv_kernel, dim3((N + 3) / 4), dim3(256), (size_t)K * sizeof(float), s, x, w, bias, y, K, N, in_act,
+                     act);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int launch_linear_skinny_valu(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int M,
                               int K, int N, int in_act, int act, hipStream_t s) {
   KD_REQUIRE(M > 0 && N > 0 && K > 0, "skinny linear: empty");

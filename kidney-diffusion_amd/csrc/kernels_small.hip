@@ -111,6 +111,7 @@ int launch_linear_skinny(const float* x, int ldx, const float* w, const float* b
   KD_REQUIRE(M > 0 && N > 0 && K > 0, "skinny linear: empty");
   const bool mfma_ok = (K & 3) == 0 && (ldx & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)w) & 15) == 0;
   if (!mfma_ok) return launch_linear_skinny_valu(x, ldx, w, bias, y, ldy, M, K, N, in_act, act, s);
+  if (M == 1 && K <= 16384) return launch_linear_gemv(x, w, bias, y, K, N, in_act, act, s);
   dim3 grid((N + 31) / 32, (M + 31) / 32);
   if (K >= 512)
     hipLaunchKernelGGL(linear_skinny_mfma_kernel<4>, grid, dim3(256), 0, s, x, ldx, w, bias, y, ldy, M, K, N, in_act, act);
