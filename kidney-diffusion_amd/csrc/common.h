@@ -106,8 +106,9 @@ int launch_wino_in(const float* x, int ldx, const float* stats, const float* gam
                    const float* scale_shift, int ld_ss, float* V, int B, int H, int W, int C, int G, int64_t t0,
                    int64_t nt, hipStream_t s);
 // y[b][2ty+i][2tx+j][n] = (A^T D A)[i][j] + bias[n] (+ res)
+// seg_partial != nullptr (C % 16 == 0): also the GroupNorm partials of y, layout [B][C/16][(H/2)(W/2)][2] doubles
 int launch_wino_out(const float* D, const float* bias, const float* res, int ldres, float* y, int B, int H, int W,
-                    int C, int64_t t0, int64_t nt, hipStream_t s);
+                    int C, int64_t t0, int64_t nt, hipStream_t s, double* seg_partial = nullptr);
 
 // ---- Winograd F(4x4,3x3) transforms (kernels_wino4.hip): U [36][O][I]; V [36][Mt][C] and D [36][Mt][N] over the
 // Mt = B (H/4) (W/4) tiles of 4x4 outputs; arguments as launch_wino_in / launch_wino_out (one slice).  seg_partial != nullptr:

@@ -526,7 +526,7 @@ struct Builder {
     // shuffled channels): several launches filling slices of one tensor (init conv) share the chunk count
     size_t sego = 0;
     int seg_nseg = 0, seg_c0 = 0;
-    if (o.want_seg && seg_on && !ext && !to_text && !to_static && ks == 1) {
+    if (o.want_seg && seg_on && !ext && !to_text && !to_static && !to_cond) {
       const int cw = o.out_mode == OUT_PIXSHUF ? Cout / 4 : Cout;
       seg_c0 = o.seg_c0 >= 0 ? o.seg_c0 : o.yoff;   // in channels of the tensor y (a slice counts from its own first)
       const int span = o.seg_c0 >= 0 ? o.seg_cn : cw;
@@ -534,6 +534,7 @@ struct Builder {
       probe.res = has_res ? (const float*)16 : nullptr;
       probe.gate_src = has_gs ? (const float*)16 : nullptr;
       probe.seg_c0 = y.coff + seg_c0;
+      probe.partial = ks > 1 ? (float*)16 : nullptr;   // split-K: statistics from the reduction kernel, one chunk per pixel
       const int nchunk = conv_seg_chunks(probe);
       if (nchunk > 0 && cw % 16 == 0 && span % 16 == 0 && o.yoff >= seg_c0 && o.yoff + cw <= seg_c0 + span) {
         SegPart* have = nullptr;
@@ -905,6 +906,9 @@ struct Builder {
     T V = alloc(1, 1, (int)(16 * nt_slice), Cin);
     T D = alloc(1, 1, (int)(16 * nt_slice), Cout);
     T y = alloc(Bx, H, W, Cout);
+    // GroupNorm partials of y from the output transform (one chunk per 2x2 tile) for whichever layer normalises it next
+    const bool sg = seg_on && Cout % 16 == 0;
+    const size_t sgo = sg ? add_seg(y, 0, Cout / 16, (H / 2) * (W / 2)) : 0;
     const std::string shape = " M" + std::to_string((int64_t)Bx * HW) + " Cin" + std::to_string(Cin) + " Cout" +
                               std::to_string(Cout);
     for (int64_t t0 = 0; t0 < Mt; t0 += nt_slice) {
@@ -935,7 +939,7 @@ struct Builder {
         kd_unet* uu = u;
         emit([=](hipStream_t s) {
           return launch_wino_out(uu->P(d_o), bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W, Cout, t0, nt,
-                                 s);
+                                 s, sg ? (double*)uu->P(sgo) : nullptr);
         }, "wino_out" + shape);
       }
     }
@@ -1042,8 +1046,10 @@ struct Builder {
       h = fwino_gn_conv(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
     } else {
       T y1 = gn_silu(x, pre + ".block1.groupnorm", -1);
+      ConvOpt o1;
+      o1.want_seg = true;   // block2's GroupNorm (or the cross-attention's input has none: harmless) reads h next
       h = conv(y1, pack_conv(pre + ".block1.project.weight", dim_out, dim_in, dim_in, 3),
-               P(pre + ".block1.project.bias", dim_out), dim_out, 3, 1, 1, ConvOpt());
+               P(pre + ".block1.project.bias", dim_out), dim_out, 3, 1, 1, o1);
       free(y1);
     }
     if (has_cross) {

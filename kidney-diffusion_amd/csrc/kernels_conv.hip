@@ -785,6 +785,24 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvParams p, i
   if (vec_ok) {
     float v[4] = {s[0], s[1], s[2], s[3]};
     epilogue_store<4>(p, m, n, v);
+    if (p.seg_partial) {
+      // GroupNorm partials of the finished rows (conv_seg_chunks: NHWC, Cout % 16 == 0): one chunk per output pixel, the
+      // four lanes that hold a 16-channel segment of a row are adjacent (idx = m C4 + n / 4, C4 % 4 == 0)
+      double d1 = (double)((v[0] + v[1]) + (v[2] + v[3]));
+      double d2 = (double)fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+      d1 += __shfl_xor(d1, 1, 64);
+      d2 += __shfl_xor(d2, 1, 64);
+      d1 += __shfl_xor(d1, 2, 64);
+      d2 += __shfl_xor(d2, 2, 64);
+      if ((n & 15) == 0) {
+        const int hw_o = p.Ho * p.Wo;
+        const int b = (int)(m / hw_o);
+        const int seg = (p.yoff + n - p.seg_c0) >> 4;
+        double* op = p.seg_partial + (((int64_t)b * p.seg_nseg + seg) * hw_o + (m - (int64_t)b * hw_o)) * 2;
+        op[0] = d1;
+        op[1] = d2;
+      }
+    }
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -831,7 +849,12 @@ int conv_ksplit(const ConvParams& p) {
 // when its epilogue cannot (split-K, the LDS-staged epilogue, ragged shapes): the plan then keeps the statistics pass.
 int conv_seg_chunks(const ConvParams& p) {
   const int64_t hw = (int64_t)p.Ho * p.Wo, M = (int64_t)p.B * hw;
-  if ((hw & 31) || (p.Cout & 15) || ((p.yoff - p.seg_c0) & 15) || (p.partial && conv_ksplit(p) > 1)) return 0;
+  if (p.partial && conv_ksplit(p) > 1)   // split-K: the reduction kernel leaves one chunk per output pixel (16-byte path)
+    return (p.out_mode == OUT_NHWC && !(p.Cout & 15) && !((p.yoff - p.seg_c0) & 15) && !(p.ldy & 3) && !(p.yoff & 3) &&
+            (!p.res || !(p.ldres & 3)) && (!p.gate_src || !(p.ldgs & 3)) && hw < 0x7fffffff)
+               ? (int)hw
+               : 0;
+  if ((hw & 31) || (p.Cout & 15) || ((p.yoff - p.seg_c0) & 15)) return 0;
   if (p.out_mode == OUT_NHWC) {
     if (p.act != ACT_NONE || (p.gate_src && p.res)) return 0;
     return (int)(hw >> 5);
@@ -942,6 +965,8 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s) {
   const int ks = p.partial ? conv_ksplit(p) : 1;
   if (ks > 1) {
     KD_REQUIRE(((uintptr_t)p.partial & 15) == 0, "split-K partial buffer must be 16-B aligned");
+    KD_REQUIRE(!p.seg_partial || ((((uintptr_t)p.y | (uintptr_t)p.res) & 15) == 0),
+               "split-K conv: GroupNorm partials come from the 16-byte path of the reduction (aligned output / residual)");
     ConvParams q = p;
     q.ksplit = ks;
     q.wide_epilogue = p.Cout % 4 == 0 &&   // the raw partial tiles [z][M][Cout] with 16-byte stores

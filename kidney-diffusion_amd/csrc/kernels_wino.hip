@@ -150,10 +150,12 @@ int launch_wino_in(const float* x, int ldx, const float* stats, const float* gam
   return 0;
 }
 
+// seg != nullptr (C % 16 == 0): fp64 (sum, sum of squares) of the tile's 4 outputs x 16 channels of every 16-channel segment,
+// entry [b][c / 16][tile of the image][2] - the GroupNorm partials of y for the layer that normalises it next (SegSrc)
 __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ D, const float* __restrict__ bias,
                                                        const float* __restrict__ res, int ldres,
                                                        float* __restrict__ y, int B, int H, int W, int C,
-                                                       int64_t t0, int64_t nt) {
+                                                       int64_t t0, int64_t nt, double* __restrict__ seg) {
   const int C4 = C >> 2;
   const int Ht = H >> 1, Wt = W >> 1;
   const int64_t Mt = nt;  // tiles of this slice: D is [16][nt][C]
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
   }
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
   if (bias) bv = *(const f32x4*)(bias + c4 * 4);
+  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     f32x4 o0 = u[i][0] + u[i][1] + u[i][2] + bv;
@@ -191,16 +194,34 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
     }
     *(f32x4*)(y + pix * C + c4 * 4) = o0;
     *(f32x4*)(y + (pix + 1) * C + c4 * 4) = o1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s1 += o0[e] + o1[e];
+      s2 = fmaf(o0[e], o0[e], fmaf(o1[e], o1[e], s2));
+    }
+  }
+  if (seg) {   // the thread's 16 values in fp32, fp64 from there on; the 4 lanes of a segment are adjacent (C4 % 4 == 0)
+    double d1 = (double)s1, d2 = (double)s2;
+    d1 += __shfl_xor(d1, 1, 64);
+    d2 += __shfl_xor(d2, 1, 64);
+    d1 += __shfl_xor(d1, 2, 64);
+    d2 += __shfl_xor(d2, 2, 64);
+    if ((c4 & 3) == 0) {
+      double* op = seg + (((int64_t)b * (C >> 4) + (c4 >> 2)) * ((int64_t)Ht * Wt) + ((int64_t)ty * Wt + tx)) * 2;
+      op[0] = d1;
+      op[1] = d2;
+    }
   }
 }
 
 int launch_wino_out(const float* D, const float* bias, const float* res, int ldres, float* y, int B, int H, int W,
-                    int C, int64_t t0, int64_t nt, hipStream_t s) {
+                    int C, int64_t t0, int64_t nt, hipStream_t s, double* seg_partial) {
   KD_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "Winograd output transform needs even H, W and C % 4 == 0");
+  KD_REQUIRE(!seg_partial || C % 16 == 0, "Winograd output transform: statistics need C % 16 == 0");
   KD_REQUIRE(t0 >= 0 && nt > 0 && t0 + nt <= (int64_t)B * (H / 2) * (W / 2), "tile slice out of range");
   int64_t total = nt * (C / 4);
   hipLaunchKernelGGL(wino_out_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, D, bias, res, ldres, y,
-                     B, H, W, C, t0, nt);
+                     B, H, W, C, t0, nt, seg_partial);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
