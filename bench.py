@@ -400,7 +400,7 @@ def grid_workload(args, world, rank, device, distributed, barrier, canvases_list
     slab_dev = device if (not distributed or dist.get_backend() == "nccl") else torch.device("cpu")
 
     # deal order inside a generalised wave: batch-1 step times per stage (profiles/README.md) x this run's timesteps
-    stage_cost = {1: 9.7 * T, 2: 7.5 * T, 3: 68.0 * T}
+    stage_cost = {1: 6.9 * T, 2: 5.7 * T, 3: 46.4 * T}
 
     def run(positions, cond_images, canvases):
         out = D.sample_grids(sample_fn, (1, 2, 3), [positions] * canvases, [cond_images] * canvases, 0.25,
@@ -446,6 +446,12 @@ def grid_workload(args, world, rank, device, distributed, barrier, canvases_list
         waves = D.merged_waves([pos] * ncan, orient)
         achieved = patches * issued_patch / elapsed / 1e12 / world
         direct_equiv = patches * flop_patch / elapsed / 1e12 / world
+        # what the schedule itself allows: generalised waves dealt by assign_tasks, a wave lasting as long as its most
+        # loaded rank (additive task costs, no overlap of the light stages credited), relative to one rank
+        def makespan(nranks):
+            return sum(max(sum(stage_cost[t[0]] for t in part) for part in D.assign_tasks(w, nranks, stage_cost))
+                       for w in D.stage_waves([pos] * ncan, orient, (1, 2, 3), not args.no_pipeline))
+        schedule_bound = {str(k): makespan(1) / makespan(k) for k in (1, 2, 4, 8)}
         results.append({
             "metric": "patches/sec (ultra-res outpainting grid, 1024-px patches, 3-stage cascade)",
             "value": patches / elapsed, "unit": "patches/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -456,6 +462,7 @@ def grid_workload(args, world, rank, device, distributed, barrier, canvases_list
                                    f"timesteps ({T},{T},{T}) [reference default (1024,256,256)], inpaint_resample {R}, "
                                    f"stage-1/2 patches per sample() call <= {args.grid_batch}, random-init weights",
                        "canvases": ncan, "patches": len(pos) * ncan, "schedule_slots": D.schedule_length(waves, world),
+                       "schedule_speedup_bound": schedule_bound,
                        "pipeline_steps": len(D.stage_waves([pos] * ncan, orient, (1, 2, 3), not args.no_pipeline)),
                        "parallelism": f"{world} rank(s): anti-diagonal waves of the three stages pipelined (a patch's "
                                       "stage s starts once its stage s-1 and its neighbours' stage s are done), dealt "
@@ -703,6 +710,7 @@ def main():
                 **{f"canvases_{r['config']['canvases']}": {
                     "patches_per_s": r["value"], "patches": r["config"]["patches"], "seconds": r["ms_per_step"] / 1e3,
                     "schedule_slots": r["config"]["schedule_slots"], "pipeline_steps": r["config"]["pipeline_steps"],
+                    "schedule_speedup_bound": r["config"]["schedule_speedup_bound"],
                     "mfma_frac_per_gpu": r["roofline"]["frac"]} for r in grid_res}}
         if world == 1 and not args.no_cpu_baseline:
             cpu, first = cpu_baseline(unet)
