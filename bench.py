@@ -591,6 +591,7 @@ def main():
     mfma_macs = lib.kd_unet_mfma_macs(handle)  # issued on the matrix cores (Winograd layers: 16/36 of theirs)
     flop_per_step = 2.0 * macs
     launches = lib.kd_unet_num_launches(handle)
+    cond_launches = lib.kd_unet_num_cond_launches(handle)
 
     x, lowres, lowres_noise, cond = synthetic_inputs(BATCH, device, seed=1234 + rank)
     ls_lr = beta_linear_log_snr(torch.full((BATCH,), 0.2))
@@ -697,6 +698,10 @@ def main():
                                    "3 cond channels), batch 16 per GPU, cosine schedule T=250, dynamic thresholding, "
                                    "random-init weights, Philox noise on device, hipGraph-replayed step",
                        "batch_per_gpu": BATCH, "image_size": SIZE, "launches_per_step": launches,
+                       "launches_per_step_from_cond_table": launches if args.no_cond_table else launches - cond_launches + 1,
+                       "cond_table": ("off" if args.no_cond_table else
+                                      f"{cond_launches} conditioning launches (time MLPs, FiLM scale / shift GEMM, tokens, cross-attention K / V) "
+                                      "replaced by one gather per step; the per-launch profile in roofline.kernels runs all of them"),
                        "parallelism": f"{world} independent batch replicas (no data-path collective)"},
             "roofline": roof,
             "rccl_ranks": nranks, "collective_backend": coll,

@@ -128,6 +128,9 @@ int64_t kd_unet_macs(const kd_unet_t* u);
  * step-invariant share of the init / final conv that is hoisted out of the step */
 int64_t kd_unet_mfma_macs(const kd_unet_t* u);
 int kd_unet_num_launches(const kd_unet_t* u);
+/* ... of which conditioning launches (functions of log_snr / lowres_log_snr / text only): the sampler replaces them by ONE
+ * gather per iteration when it runs from the conditioning table (kd_sample_args_t::cond_table). */
+int kd_unet_num_cond_launches(const kd_unet_t* u);
 
 /* Step-invariant text conditioning (the text branch of Unet.forward; reached by the
  * reference through sample_cond.py:36-48 / sample.py:51-60): text_to_cond, null-embedding select,
