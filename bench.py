@@ -530,7 +530,7 @@ def main():
                     help="--workload grid: patches of a wave per sample() call in stages 1-2 (1 = the reference's way)")
     ap.add_argument("--no-cond-table", action="store_true",
                     help="compute the time conditioning in every step instead of restoring it from the per-schedule table "
-                         "(profiles: keeps the one-off table build, 250 x 24 launches, out of a 7-step trace)")
+                         "(profiles: keeps the one-off table build, 250 x 21 launches, out of a 7-step trace)")
     ap.add_argument("--no-line-grid", action="store_true",
                     help="sr: leave the nested `grid` object (8x8 grid patches/s for 1 and 3 canvases) out of the line")
     ap.add_argument("--line-grid-steps", type=int, default=4, help="timesteps per stage of the nested grid runs")

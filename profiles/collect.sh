@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# --no-cond-table: the table of the time conditioning is built once per schedule (250 x 24 small launches + 28 GB of weight
+# --no-cond-table: the table of the time conditioning is built once per schedule (250 x 21 small launches + 28 GB of weight
 # reads); in a 4-7 step trace that one-off work would be booked as per-step time and traffic
 BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-kernel-classes --no-line-grid --no-cond-table"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH --steps 5 --warmup 2 > $OUT/stats_bench.json 2> $OUT/stats.err || exit 1

@@ -46,7 +46,7 @@ def main():
         "dominant_mfma_util": dom_sq["mfma_util"],
         "bytes_per_step": traffic["bytes_per_step"],
         "source": f"profiles/{tag}_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 2 "
-                  f"--no-cpu-baseline --no-kernel-classes --no-line-grid --no-cond-table`: the step without the one-off table of the time conditioning, which removes 24 small launches / 0.37 ms per step), profiles/{tag}_pmc_fetch.csv.gz + {tag}_pmc_write.csv.gz (separate "
+                  f"--no-cpu-baseline --no-kernel-classes --no-line-grid --no-cond-table`: the step without the one-off table of the time conditioning, which removes 21 small launches / 0.37 ms per step), profiles/{tag}_pmc_fetch.csv.gz + {tag}_pmc_write.csv.gz (separate "
                   "--pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md), "
                   f"profiles/{tag}_sq_summary.json (SQ_VALU_MFMA_BUSY_CYCLES pass)",
     }
