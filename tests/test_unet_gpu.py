@@ -166,6 +166,46 @@ def test_conditioning_table_gives_bit_identical_samples(device):
         assert torch.equal(out, ref)
 
 
+def test_sample_last_returns_what_the_step_computed(device):
+    """kd_sample_last (include/kd_engine.h): after one sampler iteration, the UNet output it reports is bit-equal to
+    kd_unet_forward on the same x_t / log-SNR, x0-hat follows from it by the library's formula, and the thresholds are
+    max(1, quantile_0.95 |x0|) per sample (torch.quantile's interpolation)."""
+    import ctypes as C
+
+    from imagen_pytorch import _engine as E
+    from imagen_pytorch.imagen_pytorch import GaussianDiffusionContinuousTimes
+
+    lib = E.load()
+    ou = H.oracle_unet("small1", seed=4)
+    pu = H.product_unet_like(ou).to(device)
+    B, S, T, k = 2, 16, 6, 2
+    h = pu.engine(B, S, device, with_text=False)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(B, 3, S, S, generator=g) * 1.5).to(device)
+    x_in = x.clone()
+    tables = GaussianDiffusionContinuousTimes(noise_schedule="cosine", timesteps=T).step_tables()
+    sc = E.kd_schedule_t()
+    sc.T = T
+    for name, v in tables.items():
+        setattr(sc, name, v.numpy().ctypes.data_as(C.POINTER(C.c_float)))
+    sa = E.kd_sample_args_t()
+    sa.objective, sa.dynamic_threshold, sa.percentile, sa.resample_times, sa.seed, sa.use_graph = 0, 1, 0.95, 1, 9, 1
+    E.check(lib.kd_sample_steps(h, C.byref(sc), C.byref(sa), E.ptr(x), k, k + 1, E.current_stream()))
+    pred, x0, thr = torch.empty_like(x), torch.empty_like(x), torch.empty(B, device=device)
+    for which, dst in ((0, pred), (1, x0), (2, thr)):
+        E.check(lib.kd_sample_last(h, which, E.ptr(dst), E.current_stream()))
+    torch.cuda.synchronize()
+    ls = tables["log_snr"][k].item()
+    fwd = pu(x_in, torch.full((B,), ls, device=device))
+    assert torch.equal(pred, fwd)
+    alpha, sigma = tables["alpha"][k].item(), tables["sigma"][k].item()
+    want_x0 = (x_in - sigma * pred) / max(alpha, 1e-8)
+    assert H.rel_l2(x0, want_x0) < 1e-6
+    want_thr = torch.quantile(x0.flatten(1).abs(), 0.95, dim=-1).clamp(min=1.0)
+    assert torch.equal(thr, want_thr), (thr, want_thr)
+    assert lib.kd_sample_last(h, 3, E.ptr(pred), E.current_stream()) != 0 and b"which" in lib.kd_last_error()
+
+
 def test_return_pil_images_truncates_like_the_library(device):
     """sample(return_pil_images=True) (sample_cond.py:42, sample.py:53): the library maps torchvision's
     ToPILImage over the float images, i.e. mul(255).byte() - truncation, not rounding."""
