@@ -333,8 +333,8 @@ ULTRA_UNETS = {  # train_ultra_res.py:29-60 (magnification level > 0: 3 conditio
 
 def grid_workload(args, world, rank, device, distributed, barrier, canvases_list, T, steps, warmup):
     """BASELINE configs[4]: the 8x8 ultra-res outpainting grid of 1024-px patches through the 3-stage
-    cascade (sample_ultra_res.py:264-448), sharded over the ranks by anti-diagonal waves with one
-    all-gather per wave (ultra_res/distributed.py).  One "step" = one full set of `canvases` grids.
+    cascade (sample_ultra_res.py:264-448), sharded over the ranks by anti-diagonal waves with point-to-point
+    strip exchange and one final all-gather (ultra_res/distributed.py).  One "step" = one full set of `canvases` grids.
     Strong scaling: the same 64 x canvases patches whatever N is.  Returns, on rank 0, one result
     dict per entry of canvases_list (the models are loaded and warmed once)."""
     import torch.distributed as dist
@@ -402,11 +402,16 @@ def grid_workload(args, world, rank, device, distributed, barrier, canvases_list
     # deal order inside a generalised wave: batch-1 step times per stage (profiles/README.md) x this run's timesteps
     stage_cost = {1: 6.9 * T, 2: 5.7 * T, 3: 46.4 * T}
 
+    xstats = {}
+
     def run(positions, cond_images, canvases):
         out = D.sample_grids(sample_fn, (1, 2, 3), [positions] * canvases, [cond_images] * canvases, 0.25,
                              [n] * canvases, patch_width=geom.patch_width, device=slab_dev,
                              pipeline=not args.no_pipeline, stage_cost=stage_cost,
-                             overlap_stages=None if (args.no_overlap or args.no_pipeline) else device)
+                             overlap_stages=None if (args.no_overlap or args.no_pipeline) else device,
+                             gather=args.grid_gather, stats=xstats)
+        if args.grid_gather == "root" and rank != 0:
+            return None
         sub = G.GridGeometry(geom.patch_width, geom.patch_dist, n, geom.out_patch_dist,
                              1024 + (n - 1) * geom.out_patch_dist)
         return [G.stitch_canvas(o, positions, sub, background=zoomed.to(o[0].device)) for o in out]
@@ -435,8 +440,9 @@ def grid_workload(args, world, rank, device, distributed, barrier, canvases_list
             canv = run(pos, cond, ncan)
         barrier()
         elapsed = time.perf_counter() - t0
-        assert all(torch.isfinite(c).all() for c in canv)
-        assert all(tuple(c.shape[-2:]) == (1024 + (n - 1) * geom.out_patch_dist,) * 2 for c in canv)
+        if canv is not None:
+            assert all(torch.isfinite(c).all() for c in canv)
+            assert all(tuple(c.shape[-2:]) == (1024 + (n - 1) * geom.out_patch_dist,) * 2 for c in canv)
         if distributed:
             tmax = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -446,12 +452,13 @@ def grid_workload(args, world, rank, device, distributed, barrier, canvases_list
         waves = D.merged_waves([pos] * ncan, orient)
         achieved = patches * issued_patch / elapsed / 1e12 / world
         direct_equiv = patches * flop_patch / elapsed / 1e12 / world
-        # what the schedule itself allows: generalised waves dealt by assign_tasks, a wave lasting as long as its most
-        # loaded rank (additive task costs, no overlap of the light stages credited), relative to one rank
+        # what the schedule itself allows: generalised waves dealt by assign_tasks; a rank starts its share of a wave
+        # when it has finished the previous one and the producers of that share are done - no barrier between the
+        # waves (additive task costs, free exchange, no overlap of the light stages credited), relative to one rank
         def makespan(nranks):
-            return sum(max(sum(stage_cost[t[0]] for t in part) for part in D.assign_tasks(w, nranks, stage_cost))
-                       for w in D.stage_waves([pos] * ncan, orient, (1, 2, 3), not args.no_pipeline))
+            return D.ExchangePlan([pos] * ncan, orient, (1, 2, 3), nranks, not args.no_pipeline, stage_cost).makespan(stage_cost)
         schedule_bound = {str(k): makespan(1) / makespan(k) for k in (1, 2, 4, 8)}
+        plan8 = {k: D.ExchangePlan([pos] * ncan, orient, (1, 2, 3), k, not args.no_pipeline, stage_cost) for k in (world, 8)}
         results.append({
             "metric": "patches/sec (ultra-res outpainting grid, 1024-px patches, 3-stage cascade)",
             "value": patches / elapsed, "unit": "patches/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -463,10 +470,23 @@ def grid_workload(args, world, rank, device, distributed, barrier, canvases_list
                                    f"stage-1/2 patches per sample() call <= {args.grid_batch}, random-init weights",
                        "canvases": ncan, "patches": len(pos) * ncan, "schedule_slots": D.schedule_length(waves, world),
                        "schedule_speedup_bound": schedule_bound,
+                       "exchange": {
+                           "p2p_strip_bytes_per_canvas": xstats.get("p2p_bytes_total", 0) / ncan,
+                           "p2p_messages": xstats.get("p2p_messages_total", 0),
+                           "final_gather_bytes_per_rank": xstats.get("final_gather_bytes_per_rank", 0),
+                           "blocking_syncs_per_job": xstats.get("blocking_collectives", 0),
+                           "gather": args.grid_gather,
+                           "at_8_ranks": {"p2p_strip_bytes_per_canvas": plan8[8].p2p_bytes(0.25) / ncan,
+                                          "p2p_messages": plan8[8].p2p_messages(),
+                                          "whole_patch_allgather_bytes_per_canvas_round3": sum(
+                                              4 * 3 * G.PATCH_SIZES[t[0]] ** 2 * 7 for w in plan8[8].waves for t in w) / ncan,
+                                          "blocking_syncs_round3": len(plan8[8].waves)}},
                        "pipeline_steps": len(D.stage_waves([pos] * ncan, orient, (1, 2, 3), not args.no_pipeline)),
                        "parallelism": f"{world} rank(s): anti-diagonal waves of the three stages pipelined (a patch's "
                                       "stage s starts once its stage s-1 and its neighbours' stage s are done), dealt "
-                                      "heaviest first with column affinity, one all-gather per stage and wave"},
+                                      "heaviest first with column affinity; finished patches stay on their rank, only the "
+                                      "overlap strips travel (async point-to-point bundles per wave, waited for by the "
+                                      "consuming task), one collective after the last wave"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "achieved_direct_equiv": direct_equiv, "traffic": None,
                          "kernel": f"whole patch pipeline per GPU: {issued_patch / 1e12:.2f} TFLOP issued on the matrix cores per "
@@ -526,6 +546,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="grid: run the stage groups of a wave one after the other (default: the light stage-1/2 groups "
                          "on a side stream beside stage 3)")
+    ap.add_argument("--grid-gather", choices=("all", "root"), default="all",
+                    help="grid: the one collective after the last wave - all-gather of the final patches to every rank "
+                         "(default; BASELINE's 'RCCL all-gather ... to reassemble the stitched canvas') or a gather to rank 0")
     ap.add_argument("--grid-batch", type=int, default=1,
                     help="--workload grid: patches of a wave per sample() call in stages 1-2 (1 = the reference's way)")
     ap.add_argument("--no-cond-table", action="store_true",
@@ -716,6 +739,7 @@ def main():
                     "patches_per_s": r["value"], "patches": r["config"]["patches"], "seconds": r["ms_per_step"] / 1e3,
                     "schedule_slots": r["config"]["schedule_slots"], "pipeline_steps": r["config"]["pipeline_steps"],
                     "schedule_speedup_bound": r["config"]["schedule_speedup_bound"],
+                    "exchange": r["config"]["exchange"],
                     "mfma_frac_per_gpu": r["roofline"]["frac"]} for r in grid_res}}
         if world == 1 and not args.no_cpu_baseline:
             cpu, first = cpu_baseline(unet)

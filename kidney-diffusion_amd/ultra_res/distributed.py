@@ -5,15 +5,22 @@ patch's three neighbours are done and publish results through a `Manager().dict(
 (sample_ultra_res.py:213-261).  Here the dependency structure is made explicit instead:
 
   * patches are grouped into anti-diagonal WAVES (grid.wavefronts); inside a wave they are
-    independent and are dealt round-robin to the ranks (one process per GPU);
-  * after a wave, every rank contributes its finished patches to ONE all-gather (RCCL over xGMI on
-    the GPU node, gloo in the CPU tests) so that each rank holds the neighbours it needs for the
-    next wave — and, after the last wave, the whole canvas;
+    independent and are dealt to the ranks (one process per GPU);
+  * what a patch needs from a finished neighbour is three overlap STRIPS (sample_ultra_res.py:156-170:
+    the bottom rows of the patch above, the facing columns of the patch beside it, the facing corner of
+    the diagonal one; <= 3.1 MB each at stage 3) - so a finished patch stays on the rank that sampled it and
+    only those strips travel, point to point, to the <= 3 ranks that consume them (`ExchangePlan`: the whole
+    deal is a pure function of the grid, so every rank knows every message in advance).  A rank posts the
+    sends and receives of a wave in one asynchronous batch when its wave is done and waits for a bundle only
+    when a task that needs it is about to start: there is no barrier between waves (RCCL send/recv over xGMI on
+    the GPU node, gloo in the CPU tests);
+  * ONE all-gather of equal-sized slabs after the last wave gives every rank the final-stage patches of the
+    whole canvas (SURVEY.md §8e; the north star's "RCCL all-gather to reassemble the stitched canvas");
   * several canvases can be scheduled together: their waves are merged, which is what lifts the
     8x8-grid bound of 64/15 = 4.27x on 8 GPUs.
 
 The reference runs the stages 1 -> 2 -> 3 with a barrier (and a model reload) between them (:264-270).
-Here a patch's stage s only waits for what it needs - its own stage s-1 output and the stage-s outputs
+Here a patch's stage s only waits for what it needs - its own stage s-1 output and the stage-s strips
 of its three neighbours - so the stages are PIPELINED: generalised wave g holds the stage-s tasks of
 patch wave g - (s - 1) for every stage (`stage_waves`), 2n+1 steps for an n x n grid through three
 stages instead of 3 (2n - 1), and the light stage-1/2 tasks fill ranks that the anti-diagonal leaves idle.
@@ -101,29 +108,100 @@ def assign_tasks(wave: Sequence[STask], world: int, stage_cost: Optional[Dict[in
     return out
 
 
-def _all_gather_start(mine: torch.Tensor, counts: List[int], group):
-    """All-gather of per-rank patch slabs with unequal counts (padded to the max count), started asynchronously:
-    returns a function that waits and gives the per-rank slabs."""
-    world = len(counts)
-    if world == 1:
-        return lambda: [mine]
-    mx = max(counts)
-    shape = (mx,) + tuple(mine.shape[1:])
-    send = torch.zeros(shape, device=mine.device, dtype=mine.dtype)
-    if mine.shape[0]:
-        send[: mine.shape[0]] = mine
-    recv = [torch.empty_like(send) for _ in range(world)]
-    work = dist.all_gather(recv, send, group=group, async_op=True)
-
-    def finish():
-        work.wait()
-        return [r[:c] for r, c in zip(recv, counts)]
-
-    return finish
+Item = Tuple[str, STask]   # (kind, producer): kind in grid.STRIP_KINDS or "low" (the whole previous-stage patch)
 
 
-def _all_gather_patches(mine: torch.Tensor, counts: List[int], group) -> List[torch.Tensor]:
-    return _all_gather_start(mine, counts, group)()
+class ExchangePlan:
+    """Everything about a run that does not depend on the data: the generalised waves, who samples what, which
+    strips each task needs from whom, and the point-to-point bundles of every wave.  Built identically on every rank.
+
+      waves[g]            tasks of generalised wave g
+      parts[g][r]         the tasks of wave g dealt to rank r (in the order they are handed to sample_fn)
+      owner[t], wave_of[t]
+      needs[t]            [(kind, producer task)] for the neighbours / previous stage that exist
+      bundles[g][(src, dst)]   [(kind, producer)] produced on src in wave g and consumed on dst, in send order
+    """
+
+    def __init__(self, patch_pos, orientations, stages, world, pipeline=True, stage_cost=None):
+        self.world = world
+        self.stages = list(stages)
+        self.waves = stage_waves(patch_pos, orientations, self.stages, pipeline)
+        self.parts = [assign_tasks(w, world, stage_cost) for w in self.waves]
+        self.owner: Dict[STask, int] = {}
+        self.wave_of: Dict[STask, int] = {}
+        for g, parts in enumerate(self.parts):
+            for r, p in enumerate(parts):
+                for t in p:
+                    self.owner[t], self.wave_of[t] = r, g
+        prev = {st: (self.stages[k - 1] if k > 0 else None) for k, st in enumerate(self.stages)}
+        sets = [set(p) for p in patch_pos]
+        self.needs: Dict[STask, List[Item]] = {}
+        self.bundles: List[Dict[Tuple[int, int], List[Item]]] = [dict() for _ in self.waves]
+        for g, parts in enumerate(self.parts):
+            for r, p in enumerate(parts):
+                for t in p:
+                    st, c, i, j = t
+                    need: List[Item] = []
+                    for kind, q in G.neighbour_positions((i, j), orientations[c]).items():
+                        if q in sets[c]:
+                            need.append((kind, (st, c) + q))
+                    if prev[st] is not None:
+                        need.append(("low", (prev[st], c, i, j)))
+                    self.needs[t] = need
+        # bundles in a canonical order: by producing wave, then the consumer's place in its own wave
+        for g, parts in enumerate(self.parts):
+            for r, p in enumerate(parts):
+                for t in p:
+                    for item in self.needs[t]:
+                        src = self.owner[item[1]]
+                        assert self.wave_of[item[1]] < g, "a task depends on a task of its own or a later wave"
+                        if src != r:
+                            self.bundles[self.wave_of[item[1]]].setdefault((src, r), []).append(item)
+
+    def item_numel(self, item: Item, overlap: float) -> int:
+        kind, (st, _, _, _) = item
+        S = G.PATCH_SIZES[st]
+        if kind == "low":
+            return 3 * S * S
+        sh = G.strip_shape(kind, S, int(overlap * S))
+        return sh[0] * sh[1] * sh[2]
+
+    def p2p_bytes(self, overlap: float) -> int:
+        """fp32 bytes that cross between ranks before the final gather (all bundles of all waves)."""
+        return 4 * sum(self.item_numel(it, overlap) for b in self.bundles for items in b.values() for it in items)
+
+    def p2p_messages(self) -> int:
+        return sum(len(b) for b in self.bundles)
+
+    def makespan(self, stage_cost: Dict[int, float]) -> float:
+        """Length of the schedule when nothing but the dependencies holds a rank back (no barrier between waves, free
+        exchange): a rank starts its share of wave g when it has finished wave g - 1 and every producer of that
+        share is done; the tasks of the share run one after the other."""
+        finish: Dict[STask, float] = {}
+        free = [0.0] * self.world
+        for g, parts in enumerate(self.parts):
+            for r, p in enumerate(parts):
+                if not p:
+                    continue
+                t0 = max([free[r]] + [finish[it[1]] for t in p for it in self.needs[t]])
+                for t in p:
+                    t0 += stage_cost.get(t[0], 1.0)
+                    finish[t] = t0
+                free[r] = t0
+        return max(free)
+
+
+def _cut_item(item: Item, patch: torch.Tensor, overlap: float, orientation: int) -> torch.Tensor:
+    kind = item[0]
+    if kind == "low":
+        return patch
+    return G.cut_strip(kind, patch, int(overlap * patch.shape[-1]), orientation)
+
+
+def _item_shape(item: Item, overlap: float) -> Tuple[int, int, int]:
+    kind, (st, _, _, _) = item
+    S = G.PATCH_SIZES[st]
+    return (3, S, S) if kind == "low" else G.strip_shape(kind, S, int(overlap * S))
 
 
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
@@ -187,9 +265,12 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
                  patch_width: Optional[int] = None, group=None,
                  device: Optional[torch.device] = None, pipeline: bool = True,
                  stage_cost: Optional[Dict[int, float]] = None,
-                 overlap_stages: Optional[torch.device] = None) -> List[List[torch.Tensor]]:
-    """Runs `stages` (e.g. (1,2,3)) over one or more canvases and returns, on every rank,
-    `out[c][idx]` = (3,S,S) final-stage patch `idx` of canvas c (index order of patch_pos[c]).
+                 overlap_stages: Optional[torch.device] = None,
+                 gather: str = "all", stats: Optional[dict] = None) -> List[List[Optional[torch.Tensor]]]:
+    """Runs `stages` (e.g. (1,2,3)) over one or more canvases and returns `out[c][idx]` = (3,S,S) final-stage
+    patch `idx` of canvas c (index order of patch_pos[c]) - on every rank with gather="all" (one all-gather of
+    equal-sized slabs after the last wave), on rank 0 alone with gather="root" (one gather; the other ranks keep
+    their own patches, None elsewhere), only this rank's own patches with gather="none".
 
     cond_images[c]: (N_c, Cc, 1024, 1024) or None; lowres[c]: optional (N_c,3,s,s) start images for
     the first stage in `stages` (the reference's --ignore_unet_1 path, sample_ultra_res.py:417-420).
@@ -198,7 +279,10 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
     on this rank are independent, so the heaviest (stage 3: kernels that fill the chip) runs on the caller's stream
     while the lighter ones (batch-1 stage-1/2 passes: weight-bandwidth and launch-latency bound, most of the chip
     idle) run from a second host thread on a side stream; same results, the wave ends when both are done.  The
-    sample_fn must have been warmed (plans built, graphs captured) and keep per-stage state apart."""
+    sample_fn must have been warmed (plans built, graphs captured) and keep per-stage state apart.
+    `device`: where finished patches and strips are kept and exchanged (HBM under RCCL, host memory under gloo).
+    `stats` (a dict) receives what the exchange moved: p2p bytes / messages of the whole job and of this rank,
+    the bytes of the final gather and the number of blocking collectives."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     ncanvas = len(patch_pos)
@@ -206,49 +290,138 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
     orientations = list(orientations) if orientations is not None else [G.choose_orientation(p) for p in patch_pos]
     index = [{p: n for n, p in enumerate(pos)} for pos in patch_pos]
     start_low = [None] * ncanvas if lowres is None else [None if l is None else list(l) for l in lowres]
-    # done[stage][canvas][(i, j)] = finished (3,S,S) patch, identical on every rank after the wave's exchange
-    done: Dict[int, List[Dict[G.Pos, torch.Tensor]]] = {st: [dict() for _ in range(ncanvas)] for st in stages}
-    prev_stage = {st: (stages[k - 1] if k > 0 else None) for k, st in enumerate(stages)}
+    plan = ExchangePlan(patch_pos, orientations, stages, world, pipeline, stage_cost)
+    local: Dict[STask, torch.Tensor] = {}     # finished patches sampled on this rank
+    have: Dict[Item, torch.Tensor] = {}       # strips / previous-stage patches received from other ranks
+    pending: Dict[Tuple[int, int], tuple] = {}   # (src, wave) -> (works, buffer, items) of a bundle in flight
+    send_keep = []                             # (works, buffer) of posted sends
+    sent_bytes = 0
 
-    for wave in stage_waves(patch_pos, orientations, stages, pipeline):
-        parts = assign_tasks(wave, world, stage_cost)
-        mine = parts[rank]
-        wave_stages = sorted({t[0] for t in wave})
+    def receive(src: int, g: int):
+        rec = pending.pop((src, g), None)
+        if rec is None:
+            return
+        works, buf, items = rec
+        for w in works:
+            w.wait()
+        off = 0
+        for it in items:
+            sh = _item_shape(it, overlap)
+            n = sh[0] * sh[1] * sh[2]
+            have[it] = buf[off:off + n].view(sh)
+            off += n
+
+    def fetch(item: Item) -> torch.Tensor:
+        prod = item[1]
+        if plan.owner[prod] == rank:
+            return _cut_item(item, local[prod], overlap, orientations[prod[1]])
+        receive(plan.owner[prod], plan.wave_of[prod])
+        return have.pop(item)
+
+    for g, wave in enumerate(plan.waves):
+        mine = plan.parts[g][rank]
         results: Dict[int, List[torch.Tensor]] = {}
         groups = []
         for st in sorted({t[0] for t in mine}, reverse=True):   # heaviest stage first
             S = G.PATCH_SIZES[st]
+            ov = int(overlap * S)
             tasks = [t for t in mine if t[0] == st]
             lows, conds, ips, ims = [], [], [], []
-            for (_, c, i, j) in tasks:
+            for t in tasks:
+                _, c, i, j = t
                 idx = index[c][(i, j)]
                 cond = None if cond_images[c] is None else cond_images[c][idx]
-                ip, im = G.assemble_inpaint((i, j), patch_pos[c], done[st][c], S, overlap, orientations[c],
-                                            num_patches_width[c], cond_image=cond, patch_width=patch_width)
-                ps = prev_stage[st]
-                low = done[ps][c][(i, j)] if ps is not None else (None if start_low[c] is None else start_low[c][idx])
+                strips = G.fallback_strips((i, j), patch_pos[c], S, overlap, orientations[c], num_patches_width[c],
+                                           cond, patch_width)
+                low = None if start_low[c] is None else start_low[c][idx]
+                for item in plan.needs[t]:
+                    if item[0] == "low":
+                        low = fetch(item)
+                    else:
+                        strips[item[0]] = fetch(item)
+                ip, im = G.inpaint_from_strips(strips, S, ov, orientations[c])
                 lows.append(low)
                 conds.append(cond)
                 ips.append(ip)
                 ims.append(im)
             groups.append((st, [(c, i, j) for (_, c, i, j) in tasks], lows, conds, ips, ims))
         _run_stage_groups(sample_fn, groups, results, overlap_stages)
-        # one all-gather per stage present in the wave, all in flight together
-        pending = []
-        for st in wave_stages:
-            S = G.PATCH_SIZES[st]
-            outs = results.get(st, [])
-            dev = device if device is not None else (outs[0].device if outs else torch.device("cpu"))
-            slab = torch.stack(outs).to(dev) if outs else torch.zeros((0, 3, S, S), device=dev)
-            per_rank = [[t for t in p if t[0] == st] for p in parts]
-            pending.append((st, per_rank, _all_gather_start(slab.float().contiguous(), [len(p) for p in per_rank], group)))
-        for st, per_rank, finish in pending:
-            gathered = finish()
-            for r, tasks in enumerate(per_rank):
-                for n, (_, c, i, j) in enumerate(tasks):
-                    done[st][c][(i, j)] = gathered[r][n]
+        for grp in groups:
+            st = grp[0]
+            for (c, i, j), o in zip(grp[1], results[st]):
+                dev = device if device is not None else o.device
+                local[(st, c, i, j)] = o.to(dev).float()
+        if world == 1:
+            continue
+        # this wave's exchange, posted in one batch and not waited for here: my strips to their consumers, and
+        # the strips other ranks produced in this wave that tasks of mine will consume later
+        ops, recvs, sends = [], [], []
+        for (src, dst), items in sorted(plan.bundles[g].items()):
+            if src == rank:
+                flat = torch.cat([_cut_item(it, local[it[1]], overlap, orientations[it[1][1]]).reshape(-1)
+                                  for it in items])
+                sent_bytes += flat.numel() * 4
+                ops.append(dist.P2POp(dist.isend, flat, dst if group is None else dist.get_global_rank(group, dst), group))
+                sends.append(flat)
+            elif dst == rank:
+                n = sum(plan.item_numel(it, overlap) for it in items)
+                ref = next(iter(local.values())) if local else None
+                dev = device if device is not None else (ref.device if ref is not None else torch.device("cpu"))
+                buf = torch.empty(n, device=dev, dtype=torch.float32)
+                ops.append(dist.P2POp(dist.irecv, buf, src if group is None else dist.get_global_rank(group, src), group))
+                recvs.append((src, buf, items))
+        if ops:
+            works = dist.batch_isend_irecv(ops)
+            if len(works) == len(ops):   # one handle per operation (gloo): a consumer waits for its receive alone
+                k = 0
+                for op, w in zip(ops, works):
+                    if op.op is dist.irecv:
+                        src, buf, items = recvs[k]
+                        k += 1
+                        pending[(src, g)] = ([w], buf, items)
+                    else:
+                        send_keep.append(([w], op.tensor))
+            else:                        # one handle for the coalesced batch (RCCL): stream-ordered, not host-blocking
+                for src, buf, items in recvs:
+                    pending[(src, g)] = (works, buf, items)
+                send_keep.append((works, sends))
+    for works, _ in send_keep:
+        for w in works:
+            w.wait()
+    assert not pending, "a posted bundle was never consumed"
     last = stages[-1]
-    return [[done[last][c][p] for p in patch_pos[c]] for c in range(ncanvas)]
+    S = G.PATCH_SIZES[last]
+    own = [[local.get((last, c) + p) for p in patch_pos[c]] for c in range(ncanvas)]
+    gather_bytes = 0
+    if world > 1 and gather in ("all", "root"):
+        # ONE collective per job: equal-sized slabs of final-stage patches, canvas-major in index order per rank
+        per_rank = [[(c, p) for c in range(ncanvas) for p in patch_pos[c] if plan.owner[(last, c) + p] == r]
+                    for r in range(world)]
+        mx = max(len(p) for p in per_rank)
+        ref = next((t for row in own for t in row if t is not None), None)
+        dev = device if device is not None else (ref.device if ref is not None else torch.device("cpu"))
+        slab = torch.zeros((mx, 3, S, S), device=dev, dtype=torch.float32)
+        for n, (c, p) in enumerate(per_rank[rank]):
+            slab[n] = local[(last, c) + p]
+        if gather == "all":
+            allp = torch.empty((world * mx, 3, S, S), device=dev, dtype=torch.float32)
+            dist.all_gather_into_tensor(allp, slab, group=group)
+            parts_ = [allp[r * mx:(r + 1) * mx] for r in range(world)]
+        else:   # only rank 0 of the group stitches: a gather moves 1 / world of the all-gather's bytes
+            parts_ = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
+            dist.gather(slab, parts_, dst=0 if group is None else dist.get_global_rank(group, 0), group=group)
+        if parts_ is not None:
+            gather_bytes = world * slab.numel() * 4
+            for r, lst in enumerate(per_rank):
+                for n, (c, p) in enumerate(lst):
+                    own[c][index[c][p]] = parts_[r][n]
+    if stats is not None:
+        stats.update(p2p_bytes_total=plan.p2p_bytes(overlap), p2p_messages_total=plan.p2p_messages(),
+                     p2p_bytes_sent_by_this_rank=sent_bytes, final_gather_bytes_per_rank=gather_bytes,
+                     blocking_collectives=int(world > 1 and gather in ("all", "root")), waves=len(plan.waves),
+                     whole_patch_allgather_bytes_per_rank=sum(
+                         4 * 3 * G.PATCH_SIZES[t[0]] ** 2 * (world - 1) for w in plan.waves for t in w) if world > 1 else 0)
+    return own
 
 
 def outpaint_canvas(sample_fn: Callable, num_patches_width: int, overlap: float = 0.25, canvases: int = 1,

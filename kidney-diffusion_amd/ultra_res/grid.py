@@ -92,6 +92,84 @@ def wavefronts(patch_pos: Sequence[Pos], orientation: int) -> List[List[Pos]]:
     return waves
 
 
+STRIP_KINDS = ("above", "next", "corner")   # what a patch takes from (i-1, j), (i, j+o) and (i-1, j+o)
+
+
+def neighbour_positions(pos: Pos, orientation: int) -> Dict[str, Pos]:
+    i, j = pos
+    return {"above": (i - 1, j), "next": (i, j + orientation), "corner": (i - 1, j + orientation)}
+
+
+def cut_strip(kind: str, patch: torch.Tensor, ov: int, orientation: int) -> torch.Tensor:
+    """The part of a finished (3,S,S) neighbour that its consumer pastes (sample_ultra_res.py:156-170): the bottom
+    `ov` rows of the patch above, the facing `ov` columns of the patch beside it, the facing corner of the diagonal
+    one.  These three strips are the whole data dependency between patches."""
+    if kind == "above":
+        return patch[:, -ov:, :]
+    if kind == "next":
+        return patch[:, :, -ov:] if orientation == -1 else patch[:, :, :ov]
+    if kind == "corner":
+        return patch[:, -ov:, -ov:] if orientation == -1 else patch[:, -ov:, :ov]
+    raise ValueError(kind)
+
+
+def strip_shape(kind: str, size: int, ov: int) -> Tuple[int, int, int]:
+    return {"above": (3, ov, size), "next": (3, size, ov), "corner": (3, ov, ov)}[kind]
+
+
+def inpaint_from_strips(strips: Dict[str, Optional[torch.Tensor]], size: int, ov: int, orientation: int):
+    """inpaint_patch (3,S,S) and inpaint_mask (S,S) from the three strips (None = no such neighbour), written in the
+    reference's order: above, beside, corner (sample_ultra_res.py:156-170)."""
+    a, n, an = strips.get("above"), strips.get("next"), strips.get("corner")
+    ref = next((t for t in (a, n, an) if t is not None), None)
+    kw = dict(device=ref.device, dtype=ref.dtype) if ref is not None else {}
+    patch = torch.zeros(3, size, size, **kw)
+    mask = torch.zeros(size, size, **kw)
+    if a is not None:
+        patch[:, :ov, :] = a
+        mask[:ov, :] = 1
+    if n is not None:
+        if orientation == -1:
+            patch[:, :, :ov] = n
+            mask[:, :ov] = 1
+        else:
+            patch[:, :, -ov:] = n
+            mask[:, -ov:] = 1
+    if an is not None:
+        if orientation == -1:
+            patch[:, :ov, :ov] = an
+        else:
+            patch[:, :ov, -ov:] = an
+    return patch, mask
+
+
+def fallback_strips(pos: Pos, patch_pos: Sequence[Pos], size: int, overlap: float, orientation: int,
+                    num_patches_width: int, cond_image: Optional[torch.Tensor], patch_width: Optional[int]
+                    ) -> Dict[str, torch.Tensor]:
+    """Strips for neighbours that were filtered out of `patch_pos` but lie inside the image: cut from bilinear-upscaled
+    crops of the conditioning image, exactly as sample_ultra_res.py:128-140."""
+    i, j = pos
+    s = set(patch_pos)
+    space_above = i != 0
+    space_next = (orientation == 1 and j < num_patches_width - 1) or (orientation == -1 and j > 0)
+    space = {"above": space_above, "next": space_next, "corner": space_above and space_next}
+    shift = {"above": (-1, 0), "next": (0, orientation), "corner": (-1, orientation)}
+    ov = int(overlap * size)
+    out = {}
+    for kind, p in neighbour_positions(pos, orientation).items():
+        if p in s or not space[kind] or cond_image is None:
+            continue
+        assert patch_width is not None
+        dy, dx = shift[kind]
+        dist = int(patch_width * (1 - overlap))
+        ty = cond_image.shape[1] // 2 - patch_width // 2 + dy * dist
+        tx = cond_image.shape[2] // 2 - patch_width // 2 + dx * dist
+        crop = cond_image[:3, ty:ty + patch_width, tx:tx + patch_width].unsqueeze(0)
+        full = F.interpolate(crop, size=(size, size), mode="bilinear", align_corners=False)[0]
+        out[kind] = cut_strip(kind, full, ov, orientation)
+    return out
+
+
 def assemble_inpaint(pos: Pos, patch_pos: Sequence[Pos], done: Dict[Pos, torch.Tensor], size: int, overlap: float,
                      orientation: int, num_patches_width: int, cond_image: Optional[torch.Tensor] = None,
                      patch_width: Optional[int] = None):
@@ -99,49 +177,13 @@ def assemble_inpaint(pos: Pos, patch_pos: Sequence[Pos], done: Dict[Pos, torch.T
     (`done[pos]` = (3,S,S) tensors of the SAME stage).  Neighbours that were filtered out of
     `patch_pos` but lie inside the image fall back to bilinear-upscaled crops of the conditioning
     image, exactly as sample_ultra_res.py:128-140."""
-    i, j = pos
     s = set(patch_pos)
-    above, next_to, above_next = (i - 1, j), (i, j + orientation), (i - 1, j + orientation)
-    space_above = i != 0
-    space_next = (orientation == 1 and j < num_patches_width - 1) or (orientation == -1 and j > 0)
-
-    def fallback(dy, dx):
-        assert cond_image is not None and patch_width is not None
-        dist = int(patch_width * (1 - overlap))
-        ty = cond_image.shape[1] // 2 - patch_width // 2 + dy * dist
-        tx = cond_image.shape[2] // 2 - patch_width // 2 + dx * dist
-        crop = cond_image[:3, ty:ty + patch_width, tx:tx + patch_width].unsqueeze(0)
-        return F.interpolate(crop, size=(size, size), mode="bilinear", align_corners=False)[0]
-
-    def get(p, has_space, dy, dx):
-        if p in s:
-            return done[p]
-        return fallback(dy, dx) if has_space and cond_image is not None else None
-
-    a = get(above, space_above, -1, 0)
-    n = get(next_to, space_next, 0, orientation)
-    an = get(above_next, space_above and space_next, -1, orientation)
-    ref = next((t for t in (a, n, an) if t is not None), None)
-    kw = dict(device=ref.device, dtype=ref.dtype) if ref is not None else {}
-    patch = torch.zeros(3, size, size, **kw)
-    mask = torch.zeros(size, size, **kw)
     ov = int(overlap * size)
-    if a is not None:
-        patch[:, :ov, :] = a[:, -ov:, :]
-        mask[:ov, :] = 1
-    if n is not None:
-        if orientation == -1:
-            patch[:, :, :ov] = n[:, :, -ov:]
-            mask[:, :ov] = 1
-        else:
-            patch[:, :, -ov:] = n[:, :, :ov]
-            mask[:, -ov:] = 1
-    if an is not None:
-        if orientation == -1:
-            patch[:, :ov, :ov] = an[:, -ov:, -ov:]
-        else:
-            patch[:, :ov, -ov:] = an[:, -ov:, :ov]
-    return patch, mask
+    strips = fallback_strips(pos, patch_pos, size, overlap, orientation, num_patches_width, cond_image, patch_width)
+    for kind, p in neighbour_positions(pos, orientation).items():
+        if p in s:
+            strips[kind] = cut_strip(kind, done[p], ov, orientation)
+    return inpaint_from_strips(strips, size, ov, orientation)
 
 
 def rgb_to_hsv(img: torch.Tensor) -> torch.Tensor:

@@ -198,6 +198,78 @@ def test_c2_segcond_base_unet_forward_matches_oracle(device):
     assert err < FWD_REL_L2, f"C2 forward: rel-L2 {err:.3e}"
 
 
+def _plan_labels(pu, B, S, device, with_text):
+    import ctypes as C
+    from imagen_pytorch import _engine as E
+
+    buf = C.create_string_buffer(1 << 20)
+    E.check(E.load().kd_unet_profile(pu.engine(B, S, device, with_text=with_text), 1, buf, len(buf), E.current_stream()))
+    return buf.value.decode()
+
+
+def test_c2_segcond_base_unet_at_batch_16_forward_and_guided_sampler_match_oracle(device):
+    """BASELINE configs[1] on the plan it actually runs (train.py:30-39, sample_cond.py:40-48: batch 16): at batch 16
+    the 16x16 level (dim 768) and the 8x8 middle (dim 1024) go to Winograd F(4x4,3x3) with K = 768 / 1536 / 1024 - shapes
+    the batch-2 test above never builds.  One forward (4.2 TFLOP on the host) and two text-conditioned sampler steps
+    per guidance scale (cond_scale 1 and 2.5: sample.py:51-60) at the reference's dims against the oracle."""
+    import imagen_pytorch as ip
+
+    ou = _oracle("seg1", False, seed=53, text=True)
+    B, S = 16, 64
+    g = torch.Generator().manual_seed(28)
+    x = torch.randn(B, 3, S, S, generator=g)
+    t = torch.randn(B, generator=g) * 2
+    text, mask = _text_inputs(B)
+    text[3, 0] = torch.tensor([0.3, -0.2, 1.0])   # one sample with another text row
+    labels = torch.nn.functional.one_hot(torch.randint(0, 4, (B, S, S), generator=g), 4).permute(0, 3, 1, 2).float()
+    with torch.no_grad():
+        ref = ou(x, t, text_embeds=text, text_mask=mask, cond_images=labels)
+    dv = _dv(device)
+    pu = H.product_unet_like(ou).to(device)
+    got = pu(dv(x), dv(t), text_embeds=dv(text), text_mask=dv(mask), cond_images=dv(labels))
+    err = H.rel_l2(got, ref)
+    plan = _plan_labels(pu, B, S, device, True)
+    n4 = plan.count("wino4 gemm")
+    print(f"C2 forward at batch 16: rel-L2 {err:.3e}; {n4} F(4x4,3x3) layers, {plan.count('wino fused')} fused F(2x2,3x3)")
+    assert n4 >= 8, n4     # the 16x16 level's ResnetBlocks at the least
+    assert err < FWD_REL_L2, f"C2 forward at batch 16: rel-L2 {err:.3e}"
+    del pu
+    # guided sampler at full dims: T = 2 (first and last-step branches), the loop replayed from the captured graph
+    kw = dict(image_sizes=(S,), timesteps=(2,), pred_objectives=("noise",), text_embed_dim=3)
+    oim = RS.Imagen([ou], **kw)
+    pim = ip.Imagen([ip.Unet(**ou._locals)], **kw)
+    pim.load_state_dict(oim.state_dict(), strict=True)
+    pim = pim.to(device)
+    nf = RS.generator_noise_fn(29)
+    for cs in (1.0, 2.5):
+        sref = oim.sample(noise_fn=nf, text_embeds=text, cond_images=labels, cond_scale=cs)
+        sgot = pim.sample(noise_fn=nf, text_embeds=dv(text), cond_images=dv(labels), cond_scale=cs, device=device)
+        d = float((sgot.cpu() - sref).abs().max())
+        print(f"C2 guided sampler, cond_scale {cs}: max|diff| {d:.3e}")
+        assert d < SAMPLE_ABS, (cs, d)
+
+
+def test_ultra_unet1_at_batch_16_matches_oracle(device):
+    """train_ultra_res.py:29-36 (configs[3] stage 1) at batch 16: its 32x32 (dim 512) and 16x16 (dim 1024) levels and the
+    8x8 middle (dim 2048) switch to F(4x4,3x3) from batch 8 on; one forward against the oracle (5.5 TFLOP on the host)."""
+    u1 = dict(dim=256, dim_mults=(1, 2, 4, 8), num_resnet_blocks=3, layer_attns=(F_, T_, T_, T_),
+              layer_cross_attns=(F_, T_, T_, T_), cond_images_channels=3)
+    ou = H.randomize_(R.Unet(**u1, cond_on_text=False, text_embed_dim=None), 84).eval()
+    B, S = 16, 64
+    x, _, cond, t, _ = _fwd_inputs(B, S, False, 3, seed=19)
+    with torch.no_grad():
+        ref = ou(x, t, cond_images=cond)
+    dv = _dv(device)
+    pu = H.product_unet_like(ou).to(device)
+    got = pu(dv(x), dv(t), cond_images=dv(cond))
+    err = H.rel_l2(got, ref)
+    plan = _plan_labels(pu, B, S, device, False)
+    n4 = plan.count("wino4 gemm")
+    print(f"ultra unet1 forward at batch 16: rel-L2 {err:.3e}; {n4} F(4x4,3x3) layers, {plan.count('wino fused')} fused")
+    assert n4 >= 16, n4
+    assert err < FWD_REL_L2, err
+
+
 def test_text_lowres_sr_unet_cond_dim_512_forward_matches_oracle(device):
     """train.py:42-53: the SR UNet of the seg-cond cascade - text + low-res conditioning + cond_dim 512 (the
     cross-attention context is 4 time tokens + 36 pooled text tokens of width 512)."""

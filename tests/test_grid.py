@@ -189,6 +189,95 @@ def test_four_rank_gloo_three_canvases_pipelined_equals_single_process_with_stag
     assert single.shape == (3, 16, 3, 32, 32)
 
 
+def _run_grid8(world, rank=0, port=None, out=None, gather="all"):
+    """One 8x8 canvas (the shape of BASELINE configs[4]) through three pipelined stages, plus a filtered 5x5 canvas of
+    the other orientation whose missing neighbours fall back to crops of the conditioning image."""
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    old = dict(G.PATCH_SIZES)
+    G.PATCH_SIZES.update({1: 8, 2: 16, 3: 32})
+    try:
+        pos8 = [(i, j) for i in range(8) for j in range(8)]
+        pos5 = [(i, j) for i in range(5) for j in range(5) if (i, j) not in ((0, 0), (1, 3), (2, 2), (4, 0))]
+        g = torch.Generator().manual_seed(2)
+        conds = [torch.rand(len(pos8), 3, 40, 40, generator=g), torch.rand(len(pos5), 3, 40, 40, generator=g)]
+        stats = {}
+        res = D.sample_grids(_stub_sample_fn, (1, 2, 3), [pos8, pos5], conds, 0.25, [8, 5], orientations=[-1, 1],
+                             patch_width=6, gather=gather, stats=stats)
+        if out is not None:
+            out[rank] = (res, stats)
+        return res, stats
+    finally:
+        G.PATCH_SIZES.clear()
+        G.PATCH_SIZES.update(old)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+
+
+def _worker8(rank, world, port, out, gather):
+    _run_grid8(world, rank, port, out, gather)
+
+
+@pytest.mark.parametrize("world,gather", [(8, "all"), (3, "none"), (2, "root")])
+def test_strip_exchange_on_many_ranks_equals_single_process(world, gather):
+    """The neighbour exchange moves only the overlap strips (sample_ultra_res.py:156-170), point to point, and the
+    canvas is gathered once: 8 ranks (and 3, a world that does not divide the grid) give bit for bit the patches of
+    one process; with gather="none" a rank ends with exactly the patches it sampled."""
+    single, s1 = _run_grid8(1)
+    assert s1["p2p_bytes_total"] == 0 and s1["blocking_collectives"] == 0
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = mp.Manager().dict()
+    mp.spawn(_worker8, args=(world, port, out, gather), nprocs=world, join=True)
+    held = [[0] * len(c) for c in single]
+    for r in range(world):
+        res, st = out[r]
+        assert st["blocking_collectives"] == (0 if gather == "none" else 1)
+        assert 0 < st["p2p_bytes_total"] < st["whole_patch_allgather_bytes_per_rank"]
+        for c, canvas in enumerate(res):
+            for k, p in enumerate(canvas):
+                if gather == "all" or (gather == "root" and r == 0):
+                    assert p is not None
+                if p is not None:
+                    assert torch.equal(p, single[c][k]), (r, c, k)
+                    held[c][k] += 1
+    want = {"all": (world, world), "none": (1, 1), "root": (1, 2)}[gather]   # root: rank 0 holds all, an owner its own
+    assert all(want[0] <= h <= want[1] for row in held for h in row)
+    assert sum(out[r][1]["p2p_bytes_sent_by_this_rank"] for r in range(world)) == out[0][1]["p2p_bytes_total"]
+
+
+def test_exchange_plan_of_the_8x8_grid_moves_strips_not_patches():
+    """BASELINE configs[4] on 8 ranks: what crosses xGMI before the final gather, from the plan alone."""
+    pos = [(i, j) for i in range(8) for j in range(8)]
+    cost = {1: 6.9, 2: 5.7, 3: 46.4}
+    plan = D.ExchangePlan([pos], [-1], (1, 2, 3), 8, True, cost)
+    # every task is dealt exactly once and depends only on earlier waves
+    assert sorted(plan.owner) == sorted((s, 0, i, j) for s in (1, 2, 3) for i, j in pos)
+    for t, need in plan.needs.items():
+        assert all(plan.wave_of[p] < plan.wave_of[t] for _, p in need)
+        assert len(need) <= 4 and [k for k, _ in need].count("low") == (0 if t[0] == 1 else 1)
+    # bundle contents = exactly the needs whose producer sits on another rank
+    remote = {(it, t) for t, need in plan.needs.items() for it in need if plan.owner[it[1]] != plan.owner[t]}
+    bundled = [it for b in plan.bundles for items in b.values() for it in items]
+    assert len(bundled) == len(remote) and set(bundled) == {it for it, _ in remote}
+    for g, b in enumerate(plan.bundles):
+        for (src, dst), items in b.items():
+            assert src != dst and all(plan.owner[it[1]] == src and plan.wave_of[it[1]] == g for it in items)
+    p2p = plan.p2p_bytes(0.25)
+    whole = sum(4 * 3 * G.PATCH_SIZES[t[0]] ** 2 * 7 for w in plan.waves for t in w)   # every patch to 7 other ranks
+    one_patch = 4 * 3 * 1024 * 1024
+    print(f"8x8 grid on 8 ranks: p2p {p2p / 1e6:.0f} MB in {plan.p2p_messages()} messages; whole-patch all-gathers moved "
+          f"{whole / 1e6:.0f} MB; final gather {64 * one_patch * 7 / 1e6:.0f} MB")
+    assert p2p < 64 * 7.2e6 and p2p * 10 < whole
+    # without a barrier between the waves the schedule is never longer than the per-wave maximum
+    per_wave = sum(max(sum(cost[t[0]] for t in part) for part in parts) for parts in plan.parts)
+    assert plan.makespan(cost) <= per_wave + 1e-9
+    one = D.ExchangePlan([pos], [-1], (1, 2, 3), 1, True, cost)
+    assert abs(one.makespan(cost) - 64 * sum(cost.values())) < 1e-6 and one.p2p_bytes(0.25) == 0
+
+
 def test_stage_pipelining_and_the_deal_of_a_wave():
     n = 8
     pos = [(i, j) for i in range(n) for j in range(n)]

@@ -180,6 +180,9 @@ WINO4_REL = 8e-6
     (1, 64, 64, 32, 64, False, True),        # one image, Mt = 256, short K
     (16, 16, 16, 2048, 128, False, True),    # the concat convs' K
     (8, 16, 16, 512, 256, True, True),       # Mt = 128: one 128-row tile per weight slab (batch 8 at the 16x16 level)
+    (16, 16, 16, 768, 768, True, True),      # configs[1] (train.py:30-39, dim_mults 1,2,3,4) at batch 16: the 16x16 up level,
+    (16, 16, 16, 1280, 768, False, True),    # ... its concat conv (768 + 512 skip channels), twelve 64-channel blocks
+    (16, 16, 16, 1536, 768, False, False),   # K = 1536 (48 chunks of 32)
 ])
 def test_conv3x3_winograd4_matches_direct(lib, device, B, H, W, Cin, Cout, res, stats):
     E = _E()
