@@ -660,6 +660,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # what the conditioning table costs a cold 250-step sample(): all T rows rebuilt, device time by HIP events
+    cond_build = None
+    if not args.no_cond_table:
+        built, rows = C.c_int(0), C.c_int(0)
+        E.check(lib.kd_sample_build_cond_table(handle, C.byref(sc), C.byref(sa), 0, T_SCHED, 1, C.byref(built), E.current_stream()))
+        ms = float(lib.kd_unet_cond_table_build_ms(handle, C.byref(rows)))
+        cond_build = {"ms": ms, "rows": int(built.value), "schedule_steps": T_SCHED,
+                      "runs_of_the_conditioning_ops": -(-T_SCHED // BATCH) if built.value else 0}
+
     # the >= 6x target of BASELINE.json is patch throughput of the 8x8 grid: measured by the same command, after the
     # timed region of the headline metric, on every rank (collective inside); 1 canvas (dependency bound 4.27x at 8
     # ranks) and 3 canvases in flight (bound 6.2x)
@@ -725,6 +734,7 @@ def main():
                        "cond_table": ("off" if args.no_cond_table else
                                       f"{cond_launches} conditioning launches (time MLPs, FiLM scale / shift GEMM, tokens, cross-attention K / V) "
                                       "replaced by one gather per step; the per-launch profile in roofline.kernels runs all of them"),
+                       "cond_table_build_ms": cond_build,
                        "parallelism": f"{world} independent batch replicas (no data-path collective)"},
             "roofline": roof,
             "rccl_ranks": nranks, "collective_backend": coll,

@@ -131,6 +131,10 @@ int kd_unet_num_launches(const kd_unet_t* u);
 /* ... of which conditioning launches (functions of log_snr / lowres_log_snr / text only): the sampler replaces them by ONE
  * gather per iteration when it runs from the conditioning table (kd_sample_args_t::cond_table). */
 int kd_unet_num_cond_launches(const kd_unet_t* u);
+/* device time (ms) and row count (*rows, may be NULL) of the plan's last conditioning-table build, < 0 if none was built
+ * yet.  Rows are built on demand for the schedule steps a call walks, B steps per run of the conditioning ops (their rows
+ * are independent over the batch): T / B runs for a whole schedule. */
+float kd_unet_cond_table_build_ms(const kd_unet_t* u, int* rows);
 
 /* Step-invariant text conditioning (the text branch of Unet.forward; reached by the
  * reference through sample_cond.py:36-48 / sample.py:51-60): text_to_cond, null-embedding select,
@@ -221,10 +225,13 @@ typedef struct kd_sample_args {
    * all B entries of d_lowres_log_snr hold ONE value (what Imagen.sample passes), the time conditioning of a step - time
    * embeddings, FiLM scale / shift of every ResnetBlock, time tokens and their cross-attention K / V - is a function of
    * the schedule index alone: it is computed once per (schedule, value) into a table and restored per iteration by one
-   * gather.  Bit-identical results either way.  cond_table: 0 = use it when possible, < 0 = never. */
+   * gather.  Bit-identical results either way.  cond_table: 0 = use it when possible, < 0 = never.  The table is
+   * allocated only if T * cond_bytes fits cond_table_max_mb (0 = 4096) and 1/8 of the free HBM (a failed allocation
+   * falls back to computing the conditioning in the step); its rows are built for the steps a call walks. */
   int lowres_log_snr_uniform;   /* 1: all entries of d_lowres_log_snr equal lowres_log_snr_value */
   float lowres_log_snr_value;
   int cond_table;
+  int cond_table_max_mb;
 } kd_sample_args_t;
 
 /* In: d_img = x_T [B,3,S,S].  Out: d_img = unnormalised sample in [0,1] (clamp, final inpaint
@@ -235,6 +242,11 @@ int kd_sample_loop(kd_unet_t* u, const kd_schedule_t* sched, const kd_sample_arg
  * to time exactly K steps, and by tests to compare intermediate states). */
 int kd_sample_steps(kd_unet_t* u, const kd_schedule_t* sched, const kd_sample_args_t* args,
                     float* d_img, int k_begin, int k_end, void* stream);
+/* Builds (force != 0: rebuilds) the conditioning-table rows of schedule steps [k_begin, k_end) without sampling, so
+ * that the first sampling call of a schedule does not pay for them; *built (may be NULL) = rows built, 0 when the plan
+ * runs without a table.  Device time of the build: kd_unet_cond_table_build_ms. */
+int kd_sample_build_cond_table(kd_unet_t* u, const kd_schedule_t* sched, const kd_sample_args_t* args, int k_begin,
+                               int k_end, int force, int* built, void* stream);
 /* The tail of p_sample_loop on its own: clamp(-1,1), paste of the known inpaint pixels,
  * (x+1)/2.  kd_sample_loop == kd_sample_steps(0,T) + kd_sample_finalize. */
 int kd_sample_finalize(kd_unet_t* u, const kd_sample_args_t* args, float* d_img, void* stream);

@@ -274,6 +274,11 @@ int launch_renoise(float* x, const float* noise, int64_t noise_stride, const uin
                    const int* d_iter, int R, int T, int B, int64_t per, hipStream_t s);
 int launch_iter_set(int* d_iter, int value, hipStream_t s);
 int launch_cond_gather(const void* tab, void* dst, size_t bytes, const int* d_iter, int R, hipStream_t s);
+// one tensor of the conditioning region, batch-major [B][row4 floats] at float offset off4; start = sum of row4 before it
+struct CondSeg { uint32_t off4, row4, start; };
+int launch_fill_time_rows(const float* table, int k0, int T, float* out, int B, hipStream_t s);
+int launch_cond_scatter(const float* ws, float* tab, const CondSeg* d_segs, int nseg, uint32_t row_total, int B, int k0, int T,
+                        int64_t cond_floats, hipStream_t s);
 int launch_finalize(float* x, const float* inp, const float* mask, int B, int C, int64_t hw, hipStream_t s);
 int launch_iter_inc(int* d_iter, hipStream_t s);
 int launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, hipStream_t s);

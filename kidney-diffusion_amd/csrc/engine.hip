@@ -191,12 +191,21 @@ struct kd_unet {
   int cond_tab_T = 0;
   float cond_tab_lowres = 0.f;
   bool cond_tab_valid = false;
+  // the tensors of the cond region (every one batch-major: the table is then built B schedule steps per run)
+  std::vector<kd::CondSeg> cond_segs;
+  bool cond_rows_ok = true;
+  kd::CondSeg* d_cond_segs = nullptr;
+  uint32_t cond_row_total = 0;
+  std::vector<char> cond_tab_row_ok;   // [T]: rows are built on demand, for the steps a call walks
+  float cond_tab_build_ms = -1.f;    // device time and row count of the last build (kd_unet_cond_table_build_ms)
+  int cond_tab_build_rows = 0;
 
   float* P(size_t off) const { return (float*)((off & COND_FLAG) ? cond_ws + (off & ~COND_FLAG) : ws + off); }
   ~kd_unet() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
-    void* frees[] = {ws, s_pred, s_x0, s_thresh, s_time, s_tables, s_iter, s_seed, s_qws, s_pred_null, cond_ws, cond_tab};
+    void* frees[] = {ws, s_pred, s_x0, s_thresh, s_time, s_tables, s_iter, s_seed, s_qws, s_pred_null, cond_ws, cond_tab,
+                     d_cond_segs};
     for (void* p : frees)
       if (p) (void)hipFree(p);
     if (s_tables_pinned) (void)hipHostFree(s_tables_pinned);
@@ -301,6 +310,11 @@ struct Builder {
     const size_t bytes = (size_t)b * h * w * c * sizeof(float);
     if (to_cond) {
       t.off = cond_alloc(bytes);
+      const size_t row = (size_t)h * w * c;
+      if (b == B && row > 0 && row < (size_t(1) << 31))
+        u->cond_segs.push_back(CondSeg{(uint32_t)((t.off & ~kd_unet::COND_FLAG) / 4), (uint32_t)row, 0});
+      else
+        u->cond_rows_ok = false;
       return t;
     }
     t.off = arena.alloc(bytes);
@@ -312,6 +326,7 @@ struct Builder {
     t.B = 1; t.H = 1; t.W = 1; t.C = (int)((bytes + 3) / 4);
     if (to_cond) {
       t.off = cond_alloc(bytes);
+      u->cond_rows_ok = false;   // a cond tensor without batch rows: the table is built step by step
       return t;
     }
     t.off = arena.alloc(bytes);
@@ -531,7 +546,8 @@ struct Builder {
       seg_c0 = o.seg_c0 >= 0 ? o.seg_c0 : o.yoff;   // in channels of the tensor y (a slice counts from its own first)
       const int span = o.seg_c0 >= 0 ? o.seg_cn : cw;
       ConvParams probe = p;
-      probe.res = has_res ? (const float*)16 : nullptr;
+      // (the residual's channel offset decides the alignment of its rows: checked here, at plan time)
+      probe.res = has_res ? (const float*)(uintptr_t)(4096 + (o.res->at() % 4096) + (size_t)res_coff * sizeof(float)) : nullptr;
       probe.gate_src = has_gs ? (const float*)16 : nullptr;
       probe.seg_c0 = y.coff + seg_c0;
       probe.partial = ks > 1 ? (float*)16 : nullptr;   // split-K: statistics from the reduction kernel, one chunk per pixel

@@ -851,7 +851,7 @@ int conv_seg_chunks(const ConvParams& p) {
   const int64_t hw = (int64_t)p.Ho * p.Wo, M = (int64_t)p.B * hw;
   if (p.partial && conv_ksplit(p) > 1)   // split-K: the reduction kernel leaves one chunk per output pixel (16-byte path)
     return (p.out_mode == OUT_NHWC && !(p.Cout & 15) && !((p.yoff - p.seg_c0) & 15) && !(p.ldy & 3) && !(p.yoff & 3) &&
-            (!p.res || !(p.ldres & 3)) && (!p.gate_src || !(p.ldgs & 3)) && hw < 0x7fffffff)
+            (!p.res || (!(p.ldres & 3) && !((uintptr_t)p.res & 15))) && (!p.gate_src || !(p.ldgs & 3)) && hw < 0x7fffffff)
                ? (int)hw
                : 0;
   if ((hw & 31) || (p.Cout & 15) || ((p.yoff - p.seg_c0) & 15)) return 0;

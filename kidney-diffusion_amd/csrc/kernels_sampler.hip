@@ -98,10 +98,56 @@ __global__ __launch_bounds__(256) void cond_gather_kernel(const float4* __restri
   if (i < n16) dst[i] = tab[(int64_t)(*d_iter / R) * n16 + i];
 }
 int launch_cond_gather(const void* tab, void* dst, size_t bytes, const int* d_iter, int R, hipStream_t s) {
+  KD_REQUIRE(tab != nullptr && dst != nullptr, "cond gather: no table");
   KD_REQUIRE(bytes % 16 == 0 && (((uintptr_t)tab | (uintptr_t)dst) & 15) == 0, "cond gather: 16-byte granules");
   const int64_t n16 = (int64_t)(bytes / 16);
   hipLaunchKernelGGL(cond_gather_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (const float4*)tab, (float4*)dst, n16,
                      d_iter, R);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- building the per-schedule conditioning table B schedule steps at a time.  The conditioning ops are row-wise
+// over the batch (time MLPs, token LayerNorm, K / V projections: sample b's rows depend on sample b's log-SNR alone), so a
+// run whose B samples carry B DIFFERENT schedule steps yields in row b what a run at step k0 + b yields in every row;
+// the scatter writes row b of every tensor into all B rows of table entry k0 + b.  Same kernels, same tile shapes, same
+// per-row arithmetic as the in-step path: the table is bit-identical to one built step by step.
+__global__ void fill_time_rows_kernel(const float* __restrict__ table, int k0, int T, float* __restrict__ out, int B) {
+  const int i = threadIdx.x;
+  if (i < B) out[i] = table[min(k0 + i, T - 1)];
+}
+int launch_fill_time_rows(const float* table, int k0, int T, float* out, int B, hipStream_t s) {
+  KD_REQUIRE(B <= 1024 && T > 0, "batch too large for fill_time_rows");
+  hipLaunchKernelGGL(fill_time_rows_kernel, dim3(1), dim3(((B + 63) / 64) * 64), 0, s, table, k0, T, out, B);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void cond_scatter_kernel(const float* __restrict__ ws, float* __restrict__ tab,
+                                                           const CondSeg* __restrict__ segs, int nseg, uint32_t row_total, int B,
+                                                           int k0, int T, int64_t cond_floats) {
+  const int b = blockIdx.y, k = k0 + b;
+  if (k >= T) return;
+  float* row = tab + (int64_t)k * cond_floats;
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < row_total; e += gridDim.x * 256) {
+    int lo = 0, hi = nseg - 1;   // last segment whose start <= e
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (segs[mid].start <= e) lo = mid; else hi = mid - 1;
+    }
+    const CondSeg sg = segs[lo];
+    const uint32_t j = e - sg.start;
+    const float v = ws[(size_t)sg.off4 + (size_t)b * sg.row4 + j];
+    float* dst = row + sg.off4 + j;
+    for (int b2 = 0; b2 < B; ++b2) dst[(size_t)b2 * sg.row4] = v;
+  }
+}
+int launch_cond_scatter(const float* ws, float* tab, const CondSeg* d_segs, int nseg, uint32_t row_total, int B, int k0, int T,
+                        int64_t cond_floats, hipStream_t s) {
+  KD_REQUIRE(ws && tab && d_segs && nseg > 0 && row_total > 0, "cond scatter: empty conditioning region");
+  const unsigned gx = (unsigned)std::min<uint32_t>((row_total + 255) / 256, 1024);
+  hipLaunchKernelGGL(cond_scatter_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, ws, tab, d_segs, nseg, row_total, B, k0, T,
+                     cond_floats);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

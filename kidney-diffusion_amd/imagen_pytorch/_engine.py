@@ -92,6 +92,7 @@ class kd_sample_args_t(C.Structure):
         ("lowres_log_snr_uniform", C.c_int),
         ("lowres_log_snr_value", C.c_float),
         ("cond_table", C.c_int),
+        ("cond_table_max_mb", C.c_int),
     ]
 
 
@@ -111,6 +112,7 @@ SIGNATURES = {
     "kd_unet_mfma_macs": (C.c_int64, [C.c_void_p]),
     "kd_unet_num_launches": (C.c_int, [C.c_void_p]),
     "kd_unet_num_cond_launches": (C.c_int, [C.c_void_p]),
+    "kd_unet_cond_table_build_ms": (C.c_float, [C.c_void_p, C.POINTER(C.c_int)]),
     "kd_unet_text_cond": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "kd_unet_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_void_p]),
@@ -119,6 +121,8 @@ SIGNATURES = {
                                  C.c_void_p]),
     "kd_sample_steps": (C.c_int, [C.c_void_p, C.POINTER(kd_schedule_t), C.POINTER(kd_sample_args_t), C.c_void_p,
                                   C.c_int, C.c_int, C.c_void_p]),
+    "kd_sample_build_cond_table": (C.c_int, [C.c_void_p, C.POINTER(kd_schedule_t), C.POINTER(kd_sample_args_t), C.c_int,
+                                             C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "kd_sample_finalize": (C.c_int, [C.c_void_p, C.POINTER(kd_sample_args_t), C.c_void_p, C.c_void_p]),
     "kd_sample_last": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "kd_conv2d_nhwc": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]),
@@ -186,7 +190,11 @@ def _check_build_id(lib, path):
     if want is None:
         return
     have = lib.kd_build_id().decode()
-    if have.split("+")[0] != want:
+    if "+" in have:
+        raise EngineUnavailable(
+            f"{path} is an experiment build ({have}: its kernels and plans follow KD_* environment variables); the product "
+            "path loads it only when KD_ENGINE_LIB names it explicitly. Rebuild with `make -C kidney-diffusion_amd/csrc`.")
+    if have != want:
         raise EngineUnavailable(
             f"{path} was built from other sources (library build id {have}, sources {want}): "
             "rebuild with `make -C kidney-diffusion_amd/csrc`.")

@@ -400,15 +400,16 @@ class Unet(nn.Module):
         assert mode in (0, 1, 2), "attn_qk_norm: 0 scaled dot product, 1 cosine-sim, 2 learned q/k scales"
         if getattr(self, "_engines", None):
             self.invalidate_engine()
-        self.attn_qk_norm = mode
-        self._locals["attn_qk_norm"] = mode
+        self.attn_qk_norm = mode   # the LIVE mode; _locals keeps what the constructor was asked for (clones: cast_model_parameters)
         for m in self.modules():
             if isinstance(m, _QKNorm):
                 m.set_qk_norm(mode)
 
     def set_version_forks(self, downsample_form=None, mid_attn_form=None):
         """Rebuilds the parameter containers of the two structural version forks in place (fresh parameters, same
-        device / dtype) and drops the execution plans."""
+        device / dtype) and drops the execution plans.  The replaced modules get NEW Parameter objects: an optimizer
+        or EMA copy built before the switch (e.g. before a load_state_dict that triggers it) keeps the old ones -
+        build those after loading, as ImagenTrainer.load does."""
         ref = self.final_conv.weight
         changed = False
         if downsample_form is not None and downsample_form != self.downsample_form:
@@ -464,9 +465,14 @@ class Unet(nn.Module):
         if (lowres_cond == self.lowres_cond and channels == self.channels and cond_on_text == self.cond_on_text
                 and text_embed_dim == self._locals["text_embed_dim"] and channels_out == self.channels_out):
             return self
-        return self.__class__(**{**self._locals, **dict(
+        clone = self.__class__(**{**self._locals, **dict(
             lowres_cond=lowres_cond, text_embed_dim=text_embed_dim, channels=channels, channels_out=channels_out,
             cond_on_text=cond_on_text)})
+        # a mode a checkpoint switched on travels to the clone as a live mode, not as a constructor request: the clone
+        # still follows the next checkpoint's keys (with or without q_scale / k_scale) the way the original would
+        if clone.attn_qk_norm != self.attn_qk_norm:
+            clone.set_attn_qk_norm(self.attn_qk_norm)
+        return clone
 
     # ---- engine plumbing
     def invalidate_engine(self):

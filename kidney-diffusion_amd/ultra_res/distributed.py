@@ -213,22 +213,23 @@ def _run_stage_groups(sample_fn: Callable, groups, results: Dict[int, List[torch
     stream (torch's current stream is per thread), both drained before the results are used."""
     # A (stage, batch) the sampler has not run yet would build its plan and capture its graph on the side thread
     # while this thread launches: such a wave runs its groups one after the other
-    is_warm = getattr(sample_fn, "is_warm", None)
-    cold = is_warm is not None and not all(is_warm(g[0], len(g[1])) for g in groups)
-    if device is None or len(groups) < 2 or torch.device(device).type != "cuda" or cold:
-        for g in groups:
-            results[g[0]] = list(sample_fn(*g))
-        return
-    import threading
-
     # An unseeded sampler draws its Philox keys from torch's global CPU generator; two threads drawing from it would
-    # make the patch -> seed mapping depend on their interleaving.  The draws happen HERE, on the calling thread, in
-    # group order, and are handed in (torch.manual_seed then reproduces an overlapped run)
+    # make the patch -> seed mapping depend on their interleaving, and a sequential wave must not consume the generator
+    # differently from an overlapped one.  So the draws ALWAYS happen here, on the calling thread, one per group in
+    # group order, and are handed in: torch.manual_seed reproduces a run whether or not its waves overlapped
     seeded = getattr(sample_fn, "takes_base_seed", False)
     base = [int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if seeded else None for _ in groups]
 
     def call(n):
         return list(sample_fn(*groups[n], base_seed=base[n]) if seeded else sample_fn(*groups[n]))
+
+    is_warm = getattr(sample_fn, "is_warm", None)
+    cold = is_warm is not None and not all(is_warm(g[0], len(g[1])) for g in groups)
+    if device is None or len(groups) < 2 or torch.device(device).type != "cuda" or cold:
+        for n, g in enumerate(groups):
+            results[g[0]] = call(n)
+        return
+    import threading
 
     dev = torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -479,9 +480,11 @@ def imagen_sample_fn(load_imagen: Callable, inpaint_resample: int, device: torch
                 kw["seed"] = seed + 7919 * stage + 104729 * hash(tasks[n0]) % (2 ** 31)
             elif base_seed is not None:   # drawn by the scheduler on its own thread (overlapped stage groups)
                 kw["seed"] = (base_seed + n0) % (2 ** 31 - 1)
-            # the reference passes the (possibly all-zero) inpaint tensors for every grid patch (:149-174)
-            kw.update(inpaint_images=stack(ips[sl]), inpaint_masks=stack(ims[sl]),
-                      inpaint_resample_times=inpaint_resample)
+            # the reference passes the (possibly all-zero) inpaint tensors for every grid patch (:149-174) and none
+            # for the single mag-0 image, which has no position (:88-91)
+            if ips[n0] is not None:
+                kw.update(inpaint_images=stack(ips[sl]), inpaint_masks=stack(ims[sl]),
+                          inpaint_resample_times=inpaint_resample)
             out = imagen.sample(**kw)
             warmed.add((stage, b))
             outs.extend(out[i] for i in range(b))

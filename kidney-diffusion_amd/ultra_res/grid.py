@@ -212,8 +212,12 @@ def tissue_mask(zoomed_image: torch.Tensor, version: str = "ultra", erode: int =
     hsv = rgb_to_hsv(zoomed_image[0].float())
     m = (hsv[2] > 0.1) if version == "airs" else ((hsv[0] > 0.5) & (hsv[1] > 0.02))
     m = m.float()[None, None]
-    m = -F.max_pool2d(-m, erode, stride=1, padding=erode // 2)
-    m = F.max_pool2d(m, dilate, stride=1, padding=dilate // 2)
+    def pool(t, k):   # a k x k max is a k x 1 max of a 1 x k max (2k instead of k^2 reads per pixel: 51 x 51 on 6400^2)
+        t = F.max_pool2d(t, (1, k), stride=1, padding=(0, k // 2))
+        return F.max_pool2d(t, (k, 1), stride=1, padding=(k // 2, 0))
+
+    m = -pool(-m, erode)
+    m = pool(m, dilate)
     return m[0, 0] > 0.5
 
 
@@ -259,29 +263,78 @@ def cond_images_for_grid(zoomed_image: torch.Tensor, geom: GridGeometry, patch_p
                          fill_color: float = 0.95, centre_crop_channels: bool = False) -> torch.Tensor:
     """(N,3|6,1024,1024) conditioning images: the zoomed image shifted so that each patch sits in the
     centre, gaps filled, centre-cropped to 1024 (sample_ultra_res.py:356-400; `v2` adds the
-    nearest-upsampled centre patch as 3 extra channels)."""
+    nearest-upsampled centre patch as 3 extra channels).
+
+    The reference rolls the WHOLE zoomed image per patch (np.roll of 6400 x 6400 x 3 at mag 2) and crops 1024 px
+    out of it; only the cropped window is computed here - row / column y of the rolled image is row (y - shift) mod W
+    of the source, filled where the reference's slices fill (a shift of 0 fills everything, as its `[shift:]` slice
+    does) - which gives the same pixels for 1/39 of the traffic at mag 2."""
     W = zoomed_image.shape[3]
+    assert zoomed_image.shape[2] == W, "square zoomed image expected (sample_ultra_res.py:307)"
+    src = zoomed_image[0]
+    dev = src.device
     out = []
     for i, j in patch_pos:
         cy = i * geom.patch_dist + geom.patch_width // 2
         cx = j * geom.patch_dist + geom.patch_width // 2
         sy, sx = W // 2 - cy, W // 2 - cx
-        img = torch.roll(zoomed_image[0], shifts=(sy, sx), dims=(1, 2))
-        if sy > 0:
-            img[:, :sy, :] = fill_color
-        else:
-            img[:, sy:, :] = fill_color   # sy == 0 fills everything, as the reference's slice does
-        if sx > 0:
-            img[:, :, :sx] = fill_color
-        else:
-            img[:, :, sx:] = fill_color
-        c = center_crop(img, PATCH_SIZE)                       # sample_ultra_res.py:391
+        if W >= PATCH_SIZE:
+            top = center_crop_offset(W, PATCH_SIZE)                # sample_ultra_res.py:391
+            win = torch.arange(top, top + PATCH_SIZE, device=dev)
+
+            def axis(shift):
+                idx = torch.remainder(win - shift, W)
+                filled = (win < shift) if shift > 0 else (win >= (W + shift) % W)   # `[shift:]`; shift == 0: every row / column
+                return idx, filled
+
+            (ry, fy), (rx, fx) = axis(sy), axis(sx)
+            c = src.index_select(1, ry).index_select(2, rx)
+            c = torch.where((fy[:, None] | fx[None, :])[None], torch.full_like(c, fill_color), c)
+        else:   # narrower than the crop: roll, fill, then torchvision's zero padding
+            img = torch.roll(src, shifts=(sy, sx), dims=(1, 2))
+            if sy > 0:
+                img[:, :sy, :] = fill_color
+            else:
+                img[:, sy:, :] = fill_color   # sy == 0 fills everything, as the reference's slice does
+            if sx > 0:
+                img[:, :, :sx] = fill_color
+            else:
+                img[:, :, sx:] = fill_color
+            c = center_crop(img, PATCH_SIZE)
         if centre_crop_channels:
             centre = center_crop(c, geom.patch_width)          # :393
             centre = F.interpolate(centre.unsqueeze(0), PATCH_SIZE, mode="nearest").squeeze(0)
             c = torch.cat((c, centre), 0)
         out.append(c)
     return torch.stack(out)
+
+
+def bilinear_resize_large(img: torch.Tensor, size: int, band_rows: int = 2048) -> torch.Tensor:
+    """`F.interpolate(img, (size, size), mode='bilinear', align_corners=False)` for outputs beyond 2^31 elements (the
+    mag-2 canvas: 3 x 40960 x 40960), which torch's device kernel refuses: the same formula (source coordinate
+    max(scale (d + 0.5) - 0.5, 0), neighbours i0 and min(i0 + 1, n - 1)) evaluated separably in bands of output rows."""
+    _, C, Hs, Ws = img.shape
+    dev, dt = img.device, img.dtype
+
+    def taps(n_in, n_out):   # torch's own arithmetic: fp32 scale and source coordinate
+        scale = torch.tensor(float(n_in), dtype=torch.float32) / torch.tensor(float(n_out), dtype=torch.float32)
+        srcp = ((torch.arange(n_out, dtype=torch.float32) + 0.5) * scale - 0.5).clamp_(min=0).to(dev)
+        i0 = srcp.long().clamp_(max=n_in - 1)
+        i1 = (i0 + 1).clamp_(max=n_in - 1)
+        l1 = (srcp - i0.to(torch.float32)).to(dt)
+        return i0, i1, 1 - l1, l1
+
+    y0, y1, ly0, ly1 = taps(Hs, size)
+    x0, x1, lx0, lx1 = taps(Ws, size)
+    out = torch.empty((1, C, size, size), device=dev, dtype=dt)
+    src = img[0]
+    for r in range(0, size, band_rows):
+        sl = slice(r, min(size, r + band_rows))
+        top, bot = src.index_select(1, y0[sl]), src.index_select(1, y1[sl])      # (C, band, Ws)
+        tx = lx0 * top.index_select(2, x0) + lx1 * top.index_select(2, x1)
+        bx = lx0 * bot.index_select(2, x0) + lx1 * bot.index_select(2, x1)
+        out[0, :, sl, :] = ly0[sl][None, :, None] * tx + ly1[sl][None, :, None] * bx
+    return out
 
 
 def stitch_canvas(patches: Sequence[torch.Tensor], patch_pos: Sequence[Pos], geom: GridGeometry,
@@ -292,7 +345,9 @@ def stitch_canvas(patches: Sequence[torch.Tensor], patch_pos: Sequence[Pos], geo
     stride = geom.out_patch_dist  # in output pixels of `patch_size`-wide patches
     width = patch_size + (geom.num_patches_width - 1) * stride
     ref = patches[0]
-    if background is not None:
+    if background is not None and 3 * width * width >= 2 ** 31 - 1:
+        full = bilinear_resize_large(background.to(ref), width)
+    elif background is not None:
         full = F.interpolate(background.to(ref), size=(width, width), mode="bilinear", align_corners=False)
     else:
         full = torch.zeros(1, 3, width, width, device=ref.device, dtype=ref.dtype)

@@ -10,9 +10,10 @@ stage and level (:264-270, :451-494); here the caller supplies one `sample_fn` p
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
+import torch.distributed as dist
 
 from . import distributed as D
 from . import grid as G
@@ -54,3 +55,46 @@ def generate_high_res_image(sample_fn: Callable, zoomed_image: torch.Tensor, mag
                          orientations=[G.choose_orientation(pos)], lowres=lowres, patch_width=geom.patch_width,
                          group=group, device=device)[0]
     return G.stitch_canvas(out, pos, geom, background=zoomed_image.to(out[0].device), patch_size=out[0].shape[-1])
+
+
+def generate_mag0_image(sample_fn: Callable, stages: Sequence[int] = (1, 2, 3), group=None) -> torch.Tensor:
+    """`generate_image(0, args)` (sample_ultra_res.py:264-270, :463): ONE unconditional sample through the stages -
+    no conditioning image, no patch position and therefore no inpainting tensors (:88-91, :149).  Under
+    torch.distributed rank 0 samples and broadcasts, so every rank starts the grid levels from the same image."""
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    img = None
+    if not multi or dist.get_rank(group) == 0:
+        for st in stages:
+            img = sample_fn(st, [(0, 0, 0)], [img], [None], [None], [None])[0]
+    if multi:
+        shape = (3, G.PATCH_SIZES[stages[-1]], G.PATCH_SIZES[stages[-1]])
+        if img is None:
+            img = torch.empty(shape, dtype=torch.float32)
+        buf = img.float().contiguous()
+        if dist.get_backend(group) == "gloo":
+            buf = buf.cpu()
+        dist.broadcast(buf, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+        img = buf
+    return img[None]
+
+
+def generate_all_levels(sample_fns: Dict[int, Callable], overlap: float = 0.25, version: str = "ultra",
+                        ignore_unet_1: bool = False, group=None, device: Optional[torch.device] = None,
+                        patch_filter: Optional[Callable[[int, List[G.Pos]], List[G.Pos]]] = None
+                        ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The reference's `main()` chain (sample_ultra_res.py:463-469): mag 0 (one unconditional 1024-px sample) ->
+    mag 1 (grid over it; kidney: 8x8, canvas 6400^2) -> mag 2 (grid over the mag-1 canvas filtered by the tissue
+    mask; kidney: 53x53 candidates, canvas 40960^2).  `sample_fns[level]` samples with that level's models (the
+    reference loads `--unet{n}_mag{level}` checkpoints, :36-63).  `patch_filter(level, positions)` may thin a level's
+    positions (tests, partial regeneration).  Returns the three images, each (1,3,W,W)."""
+    mag0 = generate_mag0_image(sample_fns[0], group=group)
+    if device is not None:
+        mag0 = mag0.to(device)
+    out = [mag0]
+    for level in (1, 2):
+        pos = None
+        if patch_filter is not None:
+            pos = patch_filter(level, level_patches(out[-1], level, overlap, version)[1])
+        out.append(generate_high_res_image(sample_fns[level], out[-1], level, overlap=overlap, version=version,
+                                           ignore_unet_1=ignore_unet_1, group=group, device=device, patch_pos=pos))
+    return tuple(out)

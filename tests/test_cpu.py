@@ -269,6 +269,25 @@ def test_qk_norm_fallback_follows_the_constructor():
     assert u2.attn_qk_norm == 2 and missing and all(k.endswith(("q_scale", "k_scale")) for k in missing) and not unexpected
 
 
+def test_clone_of_a_switched_unet_still_follows_checkpoint_keys():
+    """cast_model_parameters clones through the CONSTRUCTOR's kwargs: a mode a checkpoint switched on is carried over as
+    the live mode, not as an explicit request, so the clone loads a checkpoint without q_scale / k_scale strictly and
+    falls back to what the user built (cosine-sim here)."""
+    from imagen_pytorch import Unet
+
+    kw = dict(H.UNET_KW["small1"], cond_on_text=False, text_embed_dim=None)
+    with_scales = R.Unet(**kw, attn_qk_norm=2).state_dict()
+    u = Unet(**kw, cosine_sim_attn=True)
+    u.load_state_dict(with_scales, strict=True)
+    assert u.attn_qk_norm == 2 and u._locals["attn_qk_norm"] is None
+    clone = u.cast_model_parameters(lowres_cond=True, text_embed_dim=None, channels=3, channels_out=3, cond_on_text=False)
+    assert clone is not u and clone.attn_qk_norm == 2 and not clone._ctor_qk_explicit and clone._ctor_qk_norm == 1
+    assert any(k.endswith("q_scale") for k in clone.state_dict())
+    without = R.Unet(**kw, lowres_cond=True).state_dict()
+    clone.load_state_dict(without, strict=True)
+    assert clone.attn_qk_norm == 1
+
+
 def test_restore_parts_reports_what_it_could_not_load_and_unets_deepcopy():
     """A checkpoint from another library version must not be half-loaded silently (sample_ultra_res.py:59-63
     falls back to restore_parts on any RuntimeError of the strict load)."""

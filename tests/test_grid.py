@@ -94,6 +94,39 @@ def test_cond_images_and_stitch_semantics(monkeypatch):
     assert G.stitch_canvas(patches[:1], pos[:1], small, background=bg, patch_size=16)[0, :, 20:, 20:].eq(0.5).all()
 
 
+def test_windowed_cond_images_equal_the_reference_roll_and_large_resize_equals_interpolate(monkeypatch):
+    """cond_images_for_grid computes only the cropped window; the reference rolls the whole image, fills and crops
+    (sample_ultra_res.py:356-391).  Restated naively here, including the shift == 0 quirk and odd crop margins."""
+    monkeypatch.setattr(G, "PATCH_SIZE", 14)
+    for W, pw, dist, n in ((51, 9, 6, 8), (40, 8, 4, 9), (14, 2, 3, 4)):
+        z = torch.rand(1, 3, W, W, generator=torch.Generator().manual_seed(W))
+        geom = G.GridGeometry(pw, dist, n, 10, 0)
+        pos = geom.positions
+        got = G.cond_images_for_grid(z, geom, pos, fill_color=0.95)
+        for k, (i, j) in enumerate(pos):
+            cy, cx = i * dist + pw // 2, j * dist + pw // 2
+            sy, sx = W // 2 - cy, W // 2 - cx
+            img = torch.roll(z[0], shifts=(sy, sx), dims=(1, 2))
+            if sy > 0:
+                img[:, :sy, :] = 0.95
+            else:
+                img[:, sy:, :] = 0.95
+            if sx > 0:
+                img[:, :, :sx] = 0.95
+            else:
+                img[:, :, sx:] = 0.95
+            off = int(round((W - 14) / 2.0))
+            assert torch.equal(got[k], img[:, off:off + 14, off:off + 14]), (W, i, j)
+        assert any(W // 2 == i * dist + pw // 2 for i in range(n)) or W == 51   # the shift == 0 row is exercised
+    # banded bilinear resize (the mag-2 canvas exceeds torch's 2^31-element device kernel) = F.interpolate
+    g = torch.Generator().manual_seed(9)
+    for hs, size in ((13, 83), (64, 64), (50, 37), (7, 400)):
+        x = torch.rand(1, 3, hs, hs, generator=g)
+        want = torch.nn.functional.interpolate(x, size=(size, size), mode="bilinear", align_corners=False)
+        got = G.bilinear_resize_large(x, size, band_rows=29)
+        assert torch.allclose(got, want, atol=1e-6, rtol=0), (hs, size, float((got - want).abs().max()))
+
+
 def _stub_sample_fn(stage, tasks, lows, conds, ips, ims):
     """Deterministic stand-in for the sampler: a function of every input the real one consumes."""
     S = G.PATCH_SIZES[stage]

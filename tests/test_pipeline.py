@@ -147,3 +147,36 @@ def test_mag2_level_filters_by_tissue_and_handles_an_empty_canvas(small_patches)
     assert 0 < len(pos) < geom.num_patches_width ** 2
     out = P.generate_high_res_image(_sample_fn, img, 2, overlap=0.25)
     assert out.shape == (1, 3, geom.canvas_width, geom.canvas_width) and torch.isfinite(out).all()
+
+
+def test_three_level_chain_is_mag0_then_two_grid_levels(small_patches):
+    """sample_ultra_res.py:463-469: mag 0 is ONE unconditional sample without position or inpainting tensors
+    (:88-91), each further level is generate_high_res_image over the previous level's image."""
+    calls = []
+
+    def fn0(stage, tasks, lows, conds, ips, ims):
+        calls.append((stage, tasks, conds, ips, ims))
+        S = G.PATCH_SIZES[stage]
+        base = torch.linspace(0, 1, S * S).reshape(1, S, S).repeat(3, 1, 1) * (0.5 + 0.1 * stage)
+        if lows[0] is not None:
+            base = base + 0.3 * F.interpolate(lows[0][None], S, mode="nearest")[0]
+        return [base]
+
+    def fn1(stage, tasks, lows, conds, ips, ims):
+        outs = _sample_fn(stage, tasks, lows, conds, ips, ims)
+        for t, o in zip(tasks, outs):   # a few purple patches, so that the mag-2 tissue filter finds something
+            if (t[1] + t[2]) % 6 == 0:
+                o[:] = torch.tensor([0.75, 0.35, 0.8])[:, None, None]
+        return outs
+
+    keep = lambda level, pos: pos if level == 1 else pos[:7]
+    mag0, mag1, mag2 = P.generate_all_levels({0: fn0, 1: fn1, 2: _sample_fn}, overlap=0.25, patch_filter=keep)
+    assert [c[0] for c in calls] == [1, 2, 3] and all(c[1] == [(0, 0, 0)] and c[2] == [None] and c[3] == [None] and c[4] == [None]
+                                                       for c in calls)
+    assert mag0.shape == (1, 3, 32, 32)
+    want1 = P.generate_high_res_image(fn1, mag0.clone(), 1, overlap=0.25)
+    assert torch.equal(mag1, want1) and mag1.shape[-1] == 32 + 9 * 24
+    geom2, pos2 = P.level_patches(mag1, 2, 0.25)
+    assert len(pos2) > 7
+    want2 = P.generate_high_res_image(_sample_fn, mag1.clone(), 2, overlap=0.25, patch_pos=pos2[:7])
+    assert torch.equal(mag2, want2) and mag2.shape[-1] == geom2.canvas_width

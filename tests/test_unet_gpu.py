@@ -156,6 +156,17 @@ def test_conditioning_table_gives_bit_identical_samples(device):
         a, b = run(True, **kw), run(False, **kw)
         assert torch.isfinite(a).all() and torch.equal(a, b), (n, float((a - b).abs().max()))
     assert not torch.equal(run(True, **cases[5]), run(True, **cases[6])), "the low-res level must matter"
+    # a traced run walks the schedule one step per call: the table's rows are built on demand, two schedule steps (= the
+    # batch) per run of the conditioning ops, the last chunk of the odd-length schedule half filled
+    ta, tb = [], []
+    a = run(True, trace=ta, start_at_unet_number=2, start_image_or_video=low, lowres_sample_noise_level=0.3)
+    b = run(False, trace=tb, start_at_unet_number=2, start_image_or_video=low, lowres_sample_noise_level=0.3)
+    assert torch.equal(a, b) and len(ta) == len(tb) == 4 and all(torch.equal(x, y) for x, y in zip(ta, tb))
+    a3 = pim.sample(batch_size=3, cond_images=cond[:1].expand(3, -1, -1, -1).contiguous(), device=device, seed=5, stop_at_unet_number=1)
+    pim.cond_table = -1
+    b3 = pim.sample(batch_size=3, cond_images=cond[:1].expand(3, -1, -1, -1).contiguous(), device=device, seed=5, stop_at_unet_number=1)
+    pim.cond_table = 0
+    assert torch.equal(a3, b3)   # batch 3, T = 5: chunks of three schedule steps
     # another schedule length on the same plan
     pim2 = ip.Imagen([pim.unets[0], pim.unets[1]], image_sizes=(16, 32), timesteps=(3, 6), pred_objectives=("noise", "v"),
                      condition_on_text=False).to(device)
