@@ -149,6 +149,17 @@ int launch_wino_fused128_items(void* items, int B, int H, int W, int N, hipStrea
 int launch_wino_fused_gn128(const float* x, int ldx, const float* ab, const float* U, const float* bias, const float* res,
                             int ldres, float* y, int B, int H, int W, int C, int N, double* out_partial, int out_groups,
                             const void* items, hipStream_t s);
+// Fused Winograd F(4x4,3x3) + GroupNorm / FiLM / SiLU (kernels_wino4_fused.hip): items of 16 x 32 pixels x 64 output
+// channels, Cin <= 512.  U from launch_wino4_fused_pack (36 N C floats), ab as for launch_wino_fused_gn, out_partial
+// [B][N / 16][wino4_fused_out_stats_chunks][2] doubles (SegSrc with 16-channel groups)
+bool wino4_fused_ok(int B, int H, int W, int C, int N);
+int launch_wino4_fused_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s, float scale);
+size_t wino4_fused_items_count(int B, int H, int W, int N);
+size_t wino4_fused_out_stats_chunks(int H, int W);
+int launch_wino4_fused_items(void* items, int B, int H, int W, int N, hipStream_t s);
+int launch_wino4_fused_gn(const float* x, int ldx, const float* ab, const float* U, const float* bias, const float* res,
+                          int ldres, float* y, int B, int H, int W, int C, int N, double* out_partial, const void* items,
+                          hipStream_t s);
 int wino_fused_gn_max_cin();   // largest Cin launch_wino_fused_gn takes (its affine table lives in LDS)
 // stats[b][g] = (mean, rstd) from `chunks` (sum, sum of squares) partials per (b, g), summed in index order
 int launch_gn_finalize(const double* partial, float* stats, int chunks, int B, int G, double count, float eps,
