@@ -127,14 +127,20 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_gn_kernel(const float* __r
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ res, int ldres,
                                                                float* __restrict__ y, int B, int H, int W, int C, int N,
-                                                               double* __restrict__ opart, const int4* __restrict__ items) {
+                                                               double* __restrict__ opart, const int4* __restrict__ items,
+                                                               int xflags) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifdef KD_EXPERIMENT   // ablations (timing only, wrong results): 1 no stores, 2 no MFMAs, 4 no vector work, 8 no DMA, 16 no operand reads
+  const int flags = xflags;
+#else
+  constexpr int flags = 0;
+#endif
   __shared__ __attribute__((aligned(1024))) float lds[L_END];
   using LP = __attribute__((address_space(3))) float*;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mb = wave & 1, cb = wave >> 1;
+  const int mb = wave >> 2, cb = wave & 3;   // (the four waves of a tile half sit on the four SIMDs)
   const int pw = W / 32, ph_ = H / 16;
   const int nitems = B * pw * ph_ * (N / F4_N);
   const int nchunks = C / F4_K;
@@ -167,6 +173,10 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_gn_kernel(const float* __r
   const int p4a = (6 * ti) >> 2;   // group of the row's first position (slots 0-3 if i is even, 2-3 if odd)
   const int vwo = ((p4a * 4 + 2 * tchp) * F4_TILES + ttile) * 4;
 
+  // ---- activation role: float2 element aoff0 (+ 128 r for waves 6-7) of the raw stage
+  const int aoff0 = wave < 6 ? wave * 64 + lane : 384 + (wave - 6) * 64 + lane;
+  const int nact = wave < 6 ? 1 : 7;
+
   // ---- per-item state
   int b, y0, x0, slab, prem;
   __amdgpu_buffer_rsrc_t rsX;
@@ -196,13 +206,9 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_gn_kernel(const float* __r
     if (rawp0 >= 0 && slot_pixel(rawp0 * 64 + lane, iy, ix)) voffA = (uint32_t)(((iy * W + ix) * ldx) * 4);
     if (rawp1 >= 0 && slot_pixel(rawp1 * 64 + lane, iy, ix)) voffB = (uint32_t)(((iy * W + ix) * ldx) * 4);
     amask = 0;
-    if (wave >= 6) {
 #pragma unroll
-      for (int r = 0; r < 10; ++r) {
-        const int e = (wave - 6) * 64 + lane + 128 * r;   // float2 element of the stage: pixel slot e >> 1
-        if (slot_pixel(e >> 1, iy, ix)) amask |= 1u << r;
-      }
-    }
+    for (int r = 0; r < 7; ++r)
+      if (r < nact && slot_pixel((aoff0 + 128 * r) >> 1, iy, ix)) amask |= 1u << r;
   };
   auto issue_raw = [&](int chunk, int stage_off) {
     const uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t)(chunk * F4_K * 4));
@@ -211,33 +217,53 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_gn_kernel(const float* __r
     if (rawp1 >= 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (LP)(lds + stage_off + rawp1 * 256), 16, voffB, sx, 0, 0);
   };
-  auto issue_u = [&](int chunk, int stage_off) {   // 36 pieces of 1 KB: wave w carries 4 w .. 4 w + 3 and (w < 4) 32 + w
+  // 36 pieces of 1 KB: wave w carries 4 w .. 4 w + 3 and (w < 4) 32 + w; part 0 = the first two, part 1 = the rest
+  auto issue_u_part = [&](int chunk, int stage_off, int part) {
     const uint32_t su = __builtin_amdgcn_readfirstlane((uint32_t)(((slab * nchunks + chunk) * F4_U) * 4));
     const uint32_t vo = (uint32_t)(lane * 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (LP)(lds + stage_off + (wave * 4 + q) * 256), 16, vo,
-                                               su + (uint32_t)((wave * 4 + q) * 1024), 0, 0);
-    if (wave < 4)
+      if ((q >> 1) == part)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (LP)(lds + stage_off + (wave * 4 + q) * 256), 16, vo,
+                                                 su + (uint32_t)((wave * 4 + q) * 1024), 0, 0);
+    if (wave < 4 && part == 1)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (LP)(lds + stage_off + (32 + wave) * 256), 16, vo,
                                                su + (uint32_t)((32 + wave) * 1024), 0, 0);
   };
-  // GroupNorm / FiLM / SiLU of one raw stage in place (waves 6-7).  ab holds -log2(e) (A, B): u = -log2(e) v,
-  // e^-v = 2^u, u / (1 + 2^u) = -log2(e) SiLU(v); -ln 2 sits in U (WF_U_SCALE)
-  auto activate = [&](int chunk, int stage_off, bool masked) {
+  auto issue_u = [&](int chunk, int stage_off) {
+    issue_u_part(chunk, stage_off, 0);
+    issue_u_part(chunk, stage_off, 1);
+  };
+  // GroupNorm / FiLM / SiLU of one raw stage in place: 1224 float2 elements (612 pixel slots x 2 channel pairs) per chunk.
+  // Waves 0-5 take one round of 64 elements each behind their transform, waves 6-7 seven rounds each (the transform is
+  // worth five rounds: the two waves of a SIMD, w and w + 4, carry about the same vector work).  ab holds -log2(e) (A, B):
+  // u = -log2(e) v, e^-v = 2^u, u / (1 + 2^u) = -log2(e) SiLU(v); -ln 2 sits in U (WF_U_SCALE).
+  // All reads first, then the arithmetic, then the writes: one LDS round trip per chunk, not one per round
+  auto activate = [&](int chunk, int stage_off, auto MASK) {
+    const f32x4 a4 = *(const f32x4*)(lds + L_AB + 2 * (chunk * F4_K + (lane & 1) * 2));
+    f32x2* ap = (f32x2*)(lds + stage_off + aoff0 * 2);
+    if (wave < 6) {
+      f32x2 v = ap[0];
+      const float u0 = fmaf(v[0], a4[0], a4[1]), u1 = fmaf(v[1], a4[2], a4[3]);
+      v[0] = u0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u0));
+      v[1] = u1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u1));
+      if (decltype(MASK)::value && !(amask & 1)) v[0] = v[1] = 0.f;
+      ap[0] = v;
+    } else {
+      f32x2 v[7];
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
-      const int e = (wave - 6) * 64 + lane + 128 * r;
-      if (r < 9 || e < F4_SLOTS * 2) {   // (only wave 7's last round is partly past the 612 pixel slots)
-        const f32x4 a4 = *(const f32x4*)(lds + L_AB + 2 * (chunk * F4_K + (e & 1) * 2));
-        f32x2* ap = (f32x2*)(lds + stage_off + e * 2);
-        f32x2 v = *ap;
-        const float u0 = fmaf(v[0], a4[0], a4[1]), u1 = fmaf(v[1], a4[2], a4[3]);
-        v[0] = u0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u0));
-        v[1] = u1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u1));
-        if (masked && !((amask >> r) & 1)) v[0] = v[1] = 0.f;
-        *ap = v;
+      for (int r = 0; r < 7; ++r)
+        if (r < 6 || aoff0 + 128 * 6 < F4_SLOTS * 2) v[r] = ap[128 * r];   // (wave 7's last round is partly past the 612 slots)
+#pragma unroll
+      for (int r = 0; r < 7; ++r) {
+        const float u0 = fmaf(v[r][0], a4[0], a4[1]), u1 = fmaf(v[r][1], a4[2], a4[3]);
+        v[r][0] = u0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u0));
+        v[r][1] = u1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u1));
+        if (decltype(MASK)::value && !((amask >> r) & 1)) v[r][0] = v[r][1] = 0.f;
       }
+#pragma unroll
+      for (int r = 0; r < 7; ++r)
+        if (r < 6 || aoff0 + 128 * 6 < F4_SLOTS * 2) ap[128 * r] = v[r];
     }
   };
   // row i of B^T d B for (tile, 2 channels) from the activated raw stage into the V stage (waves 0-5)
@@ -273,18 +299,46 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_gn_kernel(const float* __r
   };
 
   f32x4 acc[36];
-  auto mfmas = [&](int u_off, int v_off) {
+  auto mfmas = [&](int u_off, int v_off, auto between) {
     const float* va = lds + v_off + aoff;
     const float* ub = lds + u_off + boff;
+    // three batches of three position groups; the reads of batch k + 1 are in flight under the MFMAs of batch k
+    f32x4 a0[3], b0[3], a1[3], b1[3];
+    auto rd = [&](int g0, f32x4 (&a)[3], f32x4 (&bq)[3]) {
+      if (flags & 16) {   // (ablation: operands without LDS reads)
 #pragma unroll
-    for (int g = 0; g < 9; ++g) {
-      const f32x4 a = *(const f32x4*)(va + g * (4 * F4_TILES * 4));
-      const f32x4 bq = *(const f32x4*)(ub + g * (4 * F4_N * 4));
-      acc[4 * g + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bq[0], acc[4 * g + 0], 0, 0, 0);
-      acc[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], bq[1], acc[4 * g + 1], 0, 0, 0);
-      acc[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bq[2], acc[4 * g + 2], 0, 0, 0);
-      acc[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], bq[3], acc[4 * g + 3], 0, 0, 0);
-    }
+        for (int g = 0; g < 3; ++g) {
+          const float z = (float)(g0 + g + lane);
+          a[g] = f32x4{z, z + 1.f, z + 2.f, z + 3.f};
+          bq[g] = f32x4{z, z - 1.f, z - 2.f, z - 3.f};
+          asm volatile("" : "+v"(a[g]), "+v"(bq[g]));
+        }
+        return;
+      }
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        a[g] = *(const f32x4*)(va + (g0 + g) * (4 * F4_TILES * 4));
+        bq[g] = *(const f32x4*)(ub + (g0 + g) * (4 * F4_N * 4));
+      }
+    };
+    auto mm = [&](int g0, const f32x4 (&a)[3], const f32x4 (&bq)[3]) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const int p = 4 * (g0 + g);
+        acc[p + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][0], bq[g][0], acc[p + 0], 0, 0, 0);
+        acc[p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][1], bq[g][1], acc[p + 1], 0, 0, 0);
+        acc[p + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][2], bq[g][2], acc[p + 2], 0, 0, 0);
+        acc[p + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][3], bq[g][3], acc[p + 3], 0, 0, 0);
+      }
+    };
+    rd(0, a0, b0);
+    rd(3, a1, b1);
+    mm(0, a0, b0);
+    rd(6, a0, b0);
+    between(0);
+    mm(3, a1, b1);
+    between(1);
+    mm(6, a0, b0);
   };
 
   constexpr int RS[3] = {L_R0, L_R1, L_R2};
@@ -293,27 +347,45 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_gn_kernel(const float* __r
   (void)US[1];
   (void)VS[1];
 
-  for (int item = blockIdx.x; item < nitems; item += (int)gridDim.x) {
-    setup(item);
-    const bool border = y0 == 0 || x0 == 0 || y0 + 16 >= H || x0 + 32 >= W;
-    // everybody is past the previous item's loop (its LDS stages are free) before the first DMA of this one
-    __builtin_amdgcn_s_barrier();
+  using MaskT = std::integral_constant<bool, true>;
+  using MaskF = std::integral_constant<bool, false>;
+  bool border = false;
+  // the vector work of one interval: transform of chunk ct (waves 0-5), activation of chunk ca (all waves)
+  auto vector_work = [&](int ct, int raw_t, int v_t, int ca, int raw_a) {
+    if (wave < 6 && ct < nchunks && !(flags & 64)) transform(raw_t, v_t);
+    if (ca < nchunks && !(flags & 32)) {
+      if (border) activate(ca, raw_a, MaskT{});
+      else activate(ca, raw_a, MaskF{});
+    }
+  };
+  // first raw chunks of the item that setup() just described (the three raw stages are free)
+  auto issue_first_raws = [&]() {
     issue_raw(0, RS[0]);
-    if (tid < C) *(f32x2*)(lds + L_AB + 2 * tid) = ((const f32x2*)ab)[(int64_t)b * C + tid];
+    if (1 < nchunks) issue_raw(1, RS[1]);
+    if (2 < nchunks) issue_raw(2, RS[2]);
+  };
+
+  int item = blockIdx.x;
+  setup(item);
+  issue_first_raws();
+  f32x2 abv = f32x2{0.f, 0.f};
+  if (tid < C) abv = ((const f32x2*)ab)[(int64_t)b * C + tid];
+  bool first = true;
+  while (true) {
+    // ---- top of an item: its raw chunks 0-2 are in flight (issued under the previous item's epilogue), abv holds its
+    // affine table row.  (Later items: the only younger operations of a wave are its last 8 output stores.)
+    if (tid < C) *(f32x2*)(lds + L_AB + 2 * tid) = abv;
+    border = y0 == 0 || x0 == 0 || y0 + 16 >= H || x0 + 32 >= W;
 #pragma unroll
     for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // iteration -2: raw(0) landed -> activate it; fetch raw(1)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (first) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (1 < nchunks) issue_raw(1, RS[1]);
-    if (wave >= 6) activate(0, RS[0], border);
-    // iteration -1: transform chunk 0, activate chunk 1; fetch raw(2), U(0)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (2 < nchunks) issue_raw(2, RS[2]);
     issue_u(0, US[0]);
-    if (wave < 6) transform(RS[0], VS[0]);
-    else if (1 < nchunks) activate(1, RS[1], border);
+    vector_work(nchunks, 0, 0, 0, RS[0]);           // activate chunk 0
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    vector_work(0, RS[0], VS[0], 1, RS[1]);         // transform chunk 0, activate chunk 1
 
     // stage offsets of chunk c: raw c % 3, U / V c % 2 (scalars, rotated by hand)
     int r_c = L_R0, r_c1 = L_R1, r_c2 = L_R2;   // raw stages of chunks c, c + 1, c + 2
@@ -321,14 +393,30 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_gn_kernel(const float* __r
     for (int c = 0; c < nchunks; ++c) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (c + 3 < nchunks) issue_raw(c + 3, r_c);     // (chunk c's raw stage was consumed by the transform of iteration c - 1)
-      if (c + 1 < nchunks) issue_u(c + 1, u_c1);
-      mfmas(u_c, v_c);
-      if (wave < 6) {
-        if (c + 1 < nchunks) transform(r_c1, v_c1);
-      } else {
-        if (c + 2 < nchunks) activate(c + 2, r_c2, border);
+      // The two waves of a SIMD (w and w + 4) run the interval in opposite order - matrix work first on waves 0-3, vector
+      // work first on waves 4-7 - so that one's transform / activation issues under the other's MFMAs
+      // (ONE copy of the MFMA block: two copies behind a branch make hipcc spill the 144 accumulators).
+      // The DMA of the next chunks (6 one-KB pieces per wave: raw(c+3) into the stage the transform of iteration c - 1
+      // consumed, U(c+1)) costs the issuing wave ~100 cycles a piece: waves 4-7 issue theirs in front of their vector
+      // work, waves 0-3 between the batches of their MFMAs, where the partner's MFMAs cover it
+      const bool dma = !(flags & 8);
+      if (wave >= 4) {
+        if (c + 3 < nchunks && dma) issue_raw(c + 3, r_c);
+        if (c + 1 < nchunks && dma) issue_u(c + 1, u_c1);
+        if (!(flags & 4)) vector_work(c + 1, r_c1, v_c1, c + 2, r_c2);
       }
+      if (!(flags & 2))
+        mfmas(u_c, v_c, [&](int k) {
+          if (wave < 4 && dma) {
+            if (k == 0) {
+              if (c + 3 < nchunks) issue_raw(c + 3, r_c);
+              if (c + 1 < nchunks) issue_u_part(c + 1, u_c1, 0);
+            } else if (c + 1 < nchunks) {
+              issue_u_part(c + 1, u_c1, 1);
+            }
+          }
+        });
+      if (wave < 4 && !(flags & 4)) vector_work(c + 1, r_c1, v_c1, c + 2, r_c2);
       const int t3 = r_c;
       r_c = r_c1;
       r_c1 = r_c2;
@@ -340,58 +428,94 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_gn_kernel(const float* __r
       v_c = v_c1;
       v_c1 = tv;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every stage is free from here on
 
-    // ---- output transform Y = A^T m A, in registers: the lane holds positions 0..35 of tiles 16 mb + 4 (lane >> 4) + r
-    // (r = 0..3) at output channel 64 slab + 16 cb + (lane & 15)
-    const int n = slab * F4_N + cb * 16 + (lane & 15);
-    const float bv = bias ? bias[n] : 0.f;
-    float* const yb = y + (int64_t)b * H * W * N;
-    const float* const rb = res ? res + (int64_t)b * H * W * ldres : nullptr;
+    // ---- this item's coordinates for the epilogue; the loader state moves on to the next item, whose first three raw
+    // chunks start now (the raw stages take no part in the output exchange) and whose affine row is fetched
+    const int eb = b, ey0 = y0, ex0 = x0, eslab = slab, eprem = prem;
+    const int next = item + (int)gridDim.x;
+    const bool has_next = next < nitems;
+    if (has_next) {
+      setup(next);
+      issue_first_raws();
+      if (tid < C) abv = ((const f32x2*)ab)[(int64_t)b * C + tid];
+    }
+
+    // ---- output transform Y = A^T m A in registers (the lane holds positions 0..35 of tiles 16 mb + 4 (lane >> 4) + r at
+    // output channel 16 cb + (lane & 15)), then a turn through LDS so that every pixel's 64 channels (256 bytes) leave
+    // in 16-byte pieces: X[tile 0..15][pixel 0..15][64 channels] = 64 KB over the U stages, one half of the tiles (mb)
+    // per round; all eight waves read a round back (32 pixels each), add bias / residual and store
+    float* const X = lds + L_U0;
+    const int n4 = eslab * F4_N + (lane & 15) * 4;
+    const f32x4 b4 = bias ? *(const f32x4*)(bias + n4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float* const yb = y + (int64_t)eb * H * W * N;
+    const float* const rb = res ? res + (int64_t)eb * H * W * ldres : nullptr;
     float fs1 = 0.f, fs2 = 0.f;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      if (mb == h) {
+        float* xw = X + ((lane >> 4) * 4 * 16) * F4_N + cb * 16 + (lane & 15);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int t = mb * 16 + (lane >> 4) * 4 + r;
-      const int ty = t >> 3, tx = t & 7;
-      float s[4][6];   // A^T m: columns first
+        for (int r = 0; r < 4; ++r) {
+          float sc[4][6];   // A^T m: columns first
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const float m[6] = {acc[j][r], acc[6 + j][r], acc[12 + j][r], acc[18 + j][r], acc[24 + j][r], acc[30 + j][r]};
-        float o[4];
-        f4_at(m, o);
+          for (int j = 0; j < 6; ++j) {
+            const float m[6] = {acc[j][r], acc[6 + j][r], acc[12 + j][r], acc[18 + j][r], acc[24 + j][r], acc[30 + j][r]};
+            float o[4];
+            f4_at(m, o);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) s[a][j] = o[a];
-      }
+            for (int a = 0; a < 4; ++a) sc[a][j] = o[a];
+          }
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        float o[4];
-        f4_at(s[a], o);
-        const uint32_t pix = (uint32_t)((y0 + 4 * ty + a) * W + x0 + 4 * tx);
+          for (int a = 0; a < 4; ++a) {
+            float o[4];
+            f4_at(sc[a], o);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v = o[q] + bv;
-          if (rb) v += rb[(pix + q) * (uint32_t)ldres + (uint32_t)n];
-          yb[(pix + q) * (uint32_t)N + (uint32_t)n] = v;
-          fs1 += v;
-          fs2 = fmaf(v, v, fs2);
+            for (int q = 0; q < 4; ++q) xw[((r * 16) + a * 4 + q) * F4_N] = o[q];
+          }
         }
       }
-    }
-    if (opart) {   // the wave's 16 channels are one 16-channel segment: one entry per (patch, mb)
-      double gs1 = (double)fs1, gs2 = (double)fs2;
-      // lanes with the same (lane & 15) >> 4 ... all 64 lanes belong to the segment
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
 #pragma unroll
-      for (int off = 1; off <= 32; off <<= 1) {
+      for (int j = 0; j < 8; ++j) {
+        const int P = wave * 32 + j * 4 + (lane >> 4);   // pixel of the round: tile P >> 4, row (P >> 2) & 3, column P & 3
+        const int t = h * 16 + (P >> 4);
+        const uint32_t pix = (uint32_t)((ey0 + 4 * (t >> 3) + ((P >> 2) & 3)) * W + ex0 + 4 * (t & 7) + (P & 3));
+        f32x4 v = *(const f32x4*)(X + P * F4_N + (lane & 15) * 4);
+        v += b4;
+        if (rb && !(flags & 1)) v += *(const f32x4*)(rb + (pix * (uint32_t)ldres + (uint32_t)n4));
+        if (!(flags & 1) || v[0] == 123.456f) *(f32x4*)(yb + (pix * (uint32_t)N + (uint32_t)n4)) = v;
+        fs1 += (v[0] + v[1]) + (v[2] + v[3]);
+        fs2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], fs2))));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // the round has been read: the next round (or the next item's U) may overwrite it
+    }
+    if (opart) {   // the lane's 4 channels lie in 16-channel segment (lane & 15) >> 2: one entry per (patch, wave, segment)
+      double gs1 = (double)fs1, gs2 = (double)fs2;
+#pragma unroll
+      for (int off = 1; off <= 2; off <<= 1) {
         gs1 += __shfl_xor(gs1, off, 64);
         gs2 += __shfl_xor(gs2, off, 64);
       }
-      if (lane == 0) {
-        const int seg = slab * (F4_N / 16) + cb;
-        const int64_t nchunk = (int64_t)pw * ph_ * 2;
-        double* op = opart + ((((int64_t)b * (N / 16) + seg) * nchunk) + (int64_t)prem * 2 + mb) * 2;
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {
+        gs1 += __shfl_xor(gs1, off, 64);
+        gs2 += __shfl_xor(gs2, off, 64);
+      }
+      if ((lane & 0x33) == 0) {
+        const int seg = eslab * (F4_N / 16) + (lane >> 2);
+        const int64_t nchunk = (int64_t)pw * ph_ * 8;
+        double* op = opart + ((((int64_t)eb * (N / 16) + seg) * nchunk) + (int64_t)eprem * 8 + wave) * 2;
         op[0] = gs1;
         op[1] = gs2;
       }
     }
+    if (!has_next) break;
+    item = next;
+    first = false;
   }
 #endif
 }
@@ -411,8 +535,8 @@ int launch_wino4_fused_pack(const float* w_oihw, float* U, int O, int I, hipStre
 }
 
 size_t wino4_fused_items_count(int B, int H, int W, int N) { return (size_t)B * (H / 16) * (W / 32) * (N / F4_N); }
-// chunks per image and 16-channel segment of the statistics the epilogue leaves: one per (patch, tile half)
-size_t wino4_fused_out_stats_chunks(int H, int W) { return (size_t)(H / 16) * (W / 32) * 2; }
+// chunks per image and 16-channel segment of the statistics the epilogue leaves: one per (patch, wave)
+size_t wino4_fused_out_stats_chunks(int H, int W) { return (size_t)(H / 16) * (W / 32) * 8; }
 
 int launch_wino4_fused_items(void* items, int B, int H, int W, int N, hipStream_t s) {
   const size_t n = wino4_fused_items_count(B, H, W, N);
@@ -430,6 +554,8 @@ int launch_wino4_fused_gn(const float* x, int ldx, const float* ab, const float*
              "GroupNorm-fused F(4x4,3x3) conv needs H % 16 == 0, W % 32 == 0, Cin % 4 == 0, Cin <= 512, Cout % 64 == 0");
   KD_REQUIRE(items != nullptr, "GroupNorm-fused F(4x4,3x3) conv: item table missing (launch_wino4_fused_items)");
   KD_REQUIRE(!res || ((int64_t)H * W * ldres * 4 < 0x7fffffff && ldres >= N), "GroupNorm-fused F(4x4,3x3) conv: bad residual");
+  KD_REQUIRE(((uintptr_t)y & 15) == 0 && ((uintptr_t)bias & 15) == 0 && ((uintptr_t)res & 15) == 0 && ldres % 4 == 0,
+             "GroupNorm-fused F(4x4,3x3) conv: output, bias and residual rows must be 16-byte aligned");
   const unsigned grid = (unsigned)wino4_fused_items_count(B, H, W, N);
   static int cus = 0;
   if (!cus) {
@@ -440,8 +566,9 @@ int launch_wino4_fused_gn(const float* x, int ldx, const float* ab, const float*
     cus = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 8;   // a multiple of the 8 XCDs
   }
   const unsigned pgrid = grid < (unsigned)cus ? grid : (unsigned)cus;   // persistent: one workgroup per CU
+  const int xflags = kd_switch("KD_W4F_FLAGS", 0);   // (experiment builds only)
   hipLaunchKernelGGL(wino4_fused_gn_kernel, dim3(pgrid), dim3(512), 0, s, x, ldx, ab, U, bias, res, ldres, y, B, H, W, C, N,
-                     out_partial, (const int4*)items);
+                     out_partial, (const int4*)items, xflags);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
