@@ -46,6 +46,28 @@ constexpr int L_U0 = 0, L_U1 = F4_U, L_V0 = 2 * F4_U, L_V1 = L_V0 + F4_V, L_R0 =
               L_R2 = L_R1 + F4_RAW, L_AB = L_R2 + F4_RAW, L_END = L_AB + 2 * F4_MAXC;
 static_assert(L_END * 4 <= 160 * 1024, "LDS");
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// One LDS-DMA piece (64 lanes x 16 bytes -> 1 KB of LDS at byte address lds_addr) as inline assembly.  Through the
+// builtin, hipcc orders later LDS accesses of the kernel behind the DMA with s_waitcnt vmcnt(0) wherever it cannot prove
+// them apart, i.e. it exposes the whole latency right behind the issue; the kernel orders its DMAs itself (one
+// s_waitcnt vmcnt(0) + barrier per chunk).  m0 is not live across this statement: nothing else in the kernel uses it.
+// NOTE: any VGPR spill inside the chunk loop brings the same stall back (a scratch reload waits vmcnt(0)).
+__device__ __forceinline__ void f4_dma16(const i32x4& rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+__device__ __forceinline__ i32x4 f4_rsrc(const void* base, uint32_t bytes) {
+  const uint64_t a = (uint64_t)(uintptr_t)base;
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffffu));
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+
 // B^T applied to six values (one row of the 6 x 6 tile): the formulas of kernels_wino4.hip
 __device__ __forceinline__ void f4_bt(const float (&d)[6], float (&t)[6]) {
   t[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
@@ -130,13 +152,20 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_gn_kernel(const float* __r
                                                                double* __restrict__ opart, const int4* __restrict__ items,
                                                                int xflags) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#ifdef KD_EXPERIMENT   // ablations (timing only, wrong results): 1 no stores, 2 no MFMAs, 4 no vector work, 8 no DMA, 16 no operand reads
-  const int flags = xflags;
+#ifdef KD_EXPERIMENT   // ablations (timing only, wrong results): 1 no stores, 2 no MFMAs, 4 no vector work, 8 no DMA,
+  const int flags = xflags;   // 16 no operand reads, 32 no activation, 64 no transform
 #else
   constexpr int flags = 0;
 #endif
-  __shared__ __attribute__((aligned(1024))) float lds[L_END];
+  // Separate LDS objects and compile-time stage indices (the chunk loop is unrolled six times): one array with run-time
+  // stage offsets costs address arithmetic per access
+  __shared__ __attribute__((aligned(1024))) float raw_0[F4_RAW], raw_1[F4_RAW], raw_2[F4_RAW];
+  __shared__ __attribute__((aligned(1024))) float us_0[F4_U], us_1[F4_U];
+  __shared__ __attribute__((aligned(1024))) float vs[2 * F4_V];   // both V stages; the epilogue's exchange tile
+  __shared__ __attribute__((aligned(16))) float abl[2 * F4_MAXC];
   using LP = __attribute__((address_space(3))) float*;
+  auto rawp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return raw_0; else if constexpr (decltype(S)::value == 1) return raw_1; else return raw_2; };
+  auto usp = [&](auto S) -> float* { if constexpr (decltype(S)::value == 0) return us_0; else return us_1; };
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,42 +173,35 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_gn_kernel(const float* __r
   const int pw = W / 32, ph_ = H / 16;
   const int nitems = B * pw * ph_ * (N / F4_N);
   const int nchunks = C / F4_K;
-  const __amdgpu_buffer_rsrc_t rsU =
-      __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, (int)((int64_t)36 * N * C * 4), 0x00020000);
+  const i32x4 rsU = f4_rsrc(U, (uint32_t)((int64_t)36 * N * C * 4));
 
   // ---- MFMA role: A = V[p][16 mb + (lane & 15)][lane >> 4], B = U[p][16 cb + (lane & 15)][lane >> 4]
   const int aoff = ((lane >> 4) * F4_TILES + mb * 16 + (lane & 15)) * 4;
   const int boff = ((lane >> 4) * F4_N + cb * 16 + (lane & 15)) * 4;
 
-  // ---- transform role (waves 0-5): row i = wave of B^T d B for tile (ty, tx) and channels 2 chp, 2 chp + 1
+  // ---- transform role (waves 0-2): TWO rows of B^T d B for tile (ty, tx) and channels 2 chp, 2 chp + 1.  The rows
+  // of B^T pair up with shared terms - (1, 2): a = d4 - 4 d2, b = d3 - 4 d1, a + b | a - b;  (3, 4): a = d4 - d2,
+  // b = d3 - d1, a + 2 b | a - 2 b;  (0, 5): 4 d0 - 5 d2 + d4 | 4 d1 - 5 d3 + d5 - so the three pair tasks do the
+  // 144 operations per tile and channel of the separable transform, and read each patch value 2.3 times instead of 4
   const int ttx = lane & 7, tchp = (lane >> 3) & 1, tty = lane >> 4;
   const int ttile = tty * 8 + ttx;
-  // row i of B^T d = c0 d[r0] + c1 d[r1] + c2 d[r2] + c3 d[r3] (wave-uniform rows and coefficients)
-  int r0, r1, r2, r3;
-  float k0, k1, k2, k3;
-  switch (wave) {
-    case 0: r0 = 0; r1 = 2; r2 = 4; r3 = 0; k0 = 4.f; k1 = -5.f; k2 = 1.f; k3 = 0.f; break;
-    case 1: r0 = 1; r1 = 2; r2 = 3; r3 = 4; k0 = -4.f; k1 = -4.f; k2 = 1.f; k3 = 1.f; break;
-    case 2: r0 = 1; r1 = 2; r2 = 3; r3 = 4; k0 = 4.f; k1 = -4.f; k2 = -1.f; k3 = 1.f; break;
-    case 3: r0 = 1; r1 = 2; r2 = 3; r3 = 4; k0 = -2.f; k1 = -1.f; k2 = 2.f; k3 = 1.f; break;
-    case 4: r0 = 1; r1 = 2; r2 = 3; r3 = 4; k0 = 2.f; k1 = -1.f; k2 = -2.f; k3 = 1.f; break;
-    default: r0 = 1; r1 = 3; r2 = 5; r3 = 1; k0 = 4.f; k1 = -5.f; k2 = 1.f; k3 = 0.f; break;
-  }
   const int rbase = ((4 * tty) * F4_ROW + ttx) * 4 + tchp * 2;   // patch pixel (4 ty, 4 tx), channel pair
-  const int ro0 = rbase + r0 * F4_ROW * 4, ro1 = rbase + r1 * F4_ROW * 4, ro2 = rbase + r2 * F4_ROW * 4,
-            ro3 = rbase + r3 * F4_ROW * 4;
-  // V store: positions 6 i .. 6 i + 5 of channel ch: [p/4][ch][tile][p%4]
-  const int ti = wave < 6 ? wave : 0;
-  const int p4a = (6 * ti) >> 2;   // group of the row's first position (slots 0-3 if i is even, 2-3 if odd)
-  const int vwo = ((p4a * 4 + 2 * tchp) * F4_TILES + ttile) * 4;
+  const float talpha = wave == 0 ? -4.f : -1.f, tbeta = wave == 0 ? 1.f : 2.f;
+  const int i_odd = wave == 0 ? 1 : wave == 1 ? 3 : 5, i_even = wave == 0 ? 2 : wave == 1 ? 4 : 0;
+  // V store of row i: positions 6 i .. 6 i + 5 of channel ch at [p/4][ch][tile][p%4]
+  const int vw_odd = ((((6 * i_odd) >> 2) * 4 + 2 * tchp) * F4_TILES + ttile) * 4;
+  const int vw_even = ((((6 * i_even) >> 2) * 4 + 2 * tchp) * F4_TILES + ttile) * 4;
 
-  // ---- activation role: float2 element aoff0 (+ 128 r for waves 6-7) of the raw stage
-  const int aoff0 = wave < 6 ? wave * 64 + lane : 384 + (wave - 6) * 64 + lane;
-  const int nact = wave < 6 ? 1 : 7;
+  // ---- activation role (waves 3-7): float2 elements (first + r) * 64 + lane, r < nact, of the 1224 of a raw stage
+  // (612 pixel slots x 2 channel pairs): 20 rounds of 64 over five waves - 5 on waves 3 and 7 (whose SIMD carries no
+  // transform wave), 4 / 3 / 3 on waves 4 / 5 / 6 (SIMD partners of the transform waves 0 / 1 / 2)
+  const int nact = wave < 3 ? 0 : (wave == 3 || wave == 7) ? 5 : wave == 4 ? 4 : 3;
+  const int afirst = wave == 3 ? 0 : wave == 4 ? 5 : wave == 5 ? 9 : wave == 6 ? 12 : 15;
+  const int aoff0 = afirst * 64 + lane;
 
   // ---- per-item state
   int b, y0, x0, slab, prem;
-  __amdgpu_buffer_rsrc_t rsX;
+  i32x4 rsX;
   uint32_t voffA = F4_OOB, voffB = F4_OOB;   // the thread's (up to two) raw pieces
   uint32_t amask = 0;                        // activation rounds whose pixel lies inside the image
   // raw pieces: waves 4-7 carry pieces 2 (w - 4), 2 (w - 4) + 1; waves 0-1 pieces 8, 9
@@ -199,110 +221,117 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_gn_kernel(const float* __r
     x0 = it.z;
     slab = it.w;
     prem = (y0 >> 4) * pw + (x0 >> 5);
-    rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (int64_t)b * H * W * ldx), 0, (int)((int64_t)H * W * ldx * 4),
-                                            0x00020000);
+    rsX = f4_rsrc(x + (int64_t)b * H * W * ldx, (uint32_t)((int64_t)H * W * ldx * 4));
     int iy, ix;
     voffA = voffB = F4_OOB;
     if (rawp0 >= 0 && slot_pixel(rawp0 * 64 + lane, iy, ix)) voffA = (uint32_t)(((iy * W + ix) * ldx) * 4);
     if (rawp1 >= 0 && slot_pixel(rawp1 * 64 + lane, iy, ix)) voffB = (uint32_t)(((iy * W + ix) * ldx) * 4);
     amask = 0;
 #pragma unroll
-    for (int r = 0; r < 7; ++r)
-      if (r < nact && slot_pixel((aoff0 + 128 * r) >> 1, iy, ix)) amask |= 1u << r;
+    for (int r = 0; r < 5; ++r)
+      if (r < nact && slot_pixel((aoff0 + 64 * r) >> 1, iy, ix)) amask |= 1u << r;
   };
-  auto issue_raw = [&](int chunk, int stage_off) {
+  auto lds_addr = [&](const float* p) { return (uint32_t)(uintptr_t)(LP)p; };
+  auto issue_raw = [&](int chunk, float* stage) {
     const uint32_t sx = __builtin_amdgcn_readfirstlane((uint32_t)(chunk * F4_K * 4));
-    if (rawp0 >= 0)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (LP)(lds + stage_off + rawp0 * 256), 16, voffA, sx, 0, 0);
-    if (rawp1 >= 0)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (LP)(lds + stage_off + rawp1 * 256), 16, voffB, sx, 0, 0);
+    const uint32_t la = __builtin_amdgcn_readfirstlane(lds_addr(stage));
+    if (rawp0 >= 0) f4_dma16(rsX, la + (uint32_t)(rawp0 * 1024), voffA, sx);
+    if (rawp1 >= 0) f4_dma16(rsX, la + (uint32_t)(rawp1 * 1024), voffB, sx);
   };
-  // 36 pieces of 1 KB: wave w carries 4 w .. 4 w + 3 and (w < 4) 32 + w; part 0 = the first two, part 1 = the rest
-  auto issue_u_part = [&](int chunk, int stage_off, int part) {
+  auto issue_u = [&](int chunk, float* stage) {   // 36 pieces of 1 KB: wave w carries 4 w .. 4 w + 3 and (w < 4) 32 + w
     const uint32_t su = __builtin_amdgcn_readfirstlane((uint32_t)(((slab * nchunks + chunk) * F4_U) * 4));
+    const uint32_t la = __builtin_amdgcn_readfirstlane(lds_addr(stage));
     const uint32_t vo = (uint32_t)(lane * 16);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if ((q >> 1) == part)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (LP)(lds + stage_off + (wave * 4 + q) * 256), 16, vo,
-                                                 su + (uint32_t)((wave * 4 + q) * 1024), 0, 0);
-    if (wave < 4 && part == 1)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (LP)(lds + stage_off + (32 + wave) * 256), 16, vo,
-                                               su + (uint32_t)((32 + wave) * 1024), 0, 0);
+    for (int q = 0; q < 4; ++q) f4_dma16(rsU, la + (uint32_t)((wave * 4 + q) * 1024), vo, su + (uint32_t)((wave * 4 + q) * 1024));
+    if (wave < 4) f4_dma16(rsU, la + (uint32_t)((32 + wave) * 1024), vo, su + (uint32_t)((32 + wave) * 1024));
   };
-  auto issue_u = [&](int chunk, int stage_off) {
-    issue_u_part(chunk, stage_off, 0);
-    issue_u_part(chunk, stage_off, 1);
-  };
-  // GroupNorm / FiLM / SiLU of one raw stage in place: 1224 float2 elements (612 pixel slots x 2 channel pairs) per chunk.
-  // Waves 0-5 take one round of 64 elements each behind their transform, waves 6-7 seven rounds each (the transform is
-  // worth five rounds: the two waves of a SIMD, w and w + 4, carry about the same vector work).  ab holds -log2(e) (A, B):
-  // u = -log2(e) v, e^-v = 2^u, u / (1 + 2^u) = -log2(e) SiLU(v); -ln 2 sits in U (WF_U_SCALE).
-  // All reads first, then the arithmetic, then the writes: one LDS round trip per chunk, not one per round
-  auto activate = [&](int chunk, int stage_off, auto MASK) {
-    const f32x4 a4 = *(const f32x4*)(lds + L_AB + 2 * (chunk * F4_K + (lane & 1) * 2));
-    f32x2* ap = (f32x2*)(lds + stage_off + aoff0 * 2);
-    if (wave < 6) {
-      f32x2 v = ap[0];
-      const float u0 = fmaf(v[0], a4[0], a4[1]), u1 = fmaf(v[1], a4[2], a4[3]);
-      v[0] = u0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u0));
-      v[1] = u1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u1));
-      if (decltype(MASK)::value && !(amask & 1)) v[0] = v[1] = 0.f;
-      ap[0] = v;
-    } else {
-      f32x2 v[7];
+  // GroupNorm / FiLM / SiLU of one raw stage in place.  ab holds -log2(e) (A, B): u = -log2(e) v, e^-v = 2^u,
+  // u / (1 + 2^u) = -log2(e) SiLU(v); -ln 2 sits in U (WF_U_SCALE).  All reads first, then the arithmetic, then the
+  // writes: one LDS round trip per chunk, not one per round
+  auto activate = [&](int chunk, float* stage, auto MASK) {
+    const f32x4 a4 = *(const f32x4*)(abl + 2 * (chunk * F4_K + (lane & 1) * 2));
+    f32x2* ap = (f32x2*)(stage + aoff0 * 2);
+    f32x2 v[5];
+    // (wave 7's last round is partly past the 1224 elements)
+    auto live = [&](int r) { return r < nact && (r < 4 || wave != 7 || aoff0 + 64 * 4 < F4_SLOTS * 2); };
 #pragma unroll
-      for (int r = 0; r < 7; ++r)
-        if (r < 6 || aoff0 + 128 * 6 < F4_SLOTS * 2) v[r] = ap[128 * r];   // (wave 7's last round is partly past the 612 slots)
+    for (int r = 0; r < 5; ++r)
+      if (live(r)) v[r] = ap[64 * r];
 #pragma unroll
-      for (int r = 0; r < 7; ++r) {
-        const float u0 = fmaf(v[r][0], a4[0], a4[1]), u1 = fmaf(v[r][1], a4[2], a4[3]);
-        v[r][0] = u0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u0));
-        v[r][1] = u1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u1));
-        if (decltype(MASK)::value && !((amask >> r) & 1)) v[r][0] = v[r][1] = 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 7; ++r)
-        if (r < 6 || aoff0 + 128 * 6 < F4_SLOTS * 2) ap[128 * r] = v[r];
+    for (int r = 0; r < 5; ++r) {
+      const float u0 = fmaf(v[r][0], a4[0], a4[1]), u1 = fmaf(v[r][1], a4[2], a4[3]);
+      v[r][0] = u0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u0));
+      v[r][1] = u1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u1));
+      if (decltype(MASK)::value && !((amask >> r) & 1)) v[r][0] = v[r][1] = 0.f;
     }
-  };
-  // row i of B^T d B for (tile, 2 channels) from the activated raw stage into the V stage (waves 0-5)
-  auto transform = [&](int raw_off, int v_off) {
-    const float* R = lds + raw_off;
-    // column c of the tile: pixel 4 tx + c -> slot offset {0, 9, 18, 26, 1, 10} (residue block, then index)
-    constexpr int CO[6] = {0, 9 * 4, 18 * 4, 26 * 4, 1 * 4, 10 * 4};
-    float wa[6], wb[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const f32x2 d0 = *(const f32x2*)(R + ro0 + CO[c]), d1 = *(const f32x2*)(R + ro1 + CO[c]),
-                  d2 = *(const f32x2*)(R + ro2 + CO[c]), d3 = *(const f32x2*)(R + ro3 + CO[c]);
-      wa[c] = fmaf(k3, d3[0], fmaf(k2, d2[0], fmaf(k1, d1[0], k0 * d0[0])));
-      wb[c] = fmaf(k3, d3[1], fmaf(k2, d2[1], fmaf(k1, d1[1], k0 * d0[1])));
-    }
+    for (int r = 0; r < 5; ++r)
+      if (live(r)) ap[64 * r] = v[r];
+  };
+  // column c of the tile: pixel 4 tx + c -> slot offset {0, 9, 18, 26, 1, 10} (residue block, then index), in floats
+  constexpr int CO[6] = {0, 9 * 4, 18 * 4, 26 * 4, 1 * 4, 10 * 4};
+  constexpr int CH = F4_TILES * 4;       // channel stride of V
+  constexpr int PG = 4 * F4_TILES * 4;   // position-group stride of V
+  // one row of B^T d (both channels) -> B^T along the row -> positions 6 i .. 6 i + 5 of V
+  auto store_even = [&](float* Vd, const float (&wa)[6], const float (&wb)[6]) {   // 6 i % 4 == 0: a full group, then two
     float ta[6], tb[6];
     f4_bt(wa, ta);
     f4_bt(wb, tb);
-    float* Vd = lds + v_off + vwo;
-    constexpr int CH = F4_TILES * 4;   // channel stride
-    constexpr int PG = 4 * F4_TILES * 4;   // position-group stride
-    if ((wave & 1) == 0) {   // positions 6 i .. 6 i + 3 fill one group, 6 i + 4, 6 i + 5 open the next
-      *(f32x4*)(Vd) = f32x4{ta[0], ta[1], ta[2], ta[3]};
-      *(f32x4*)(Vd + CH) = f32x4{tb[0], tb[1], tb[2], tb[3]};
-      *(f32x2*)(Vd + PG) = f32x2{ta[4], ta[5]};
-      *(f32x2*)(Vd + PG + CH) = f32x2{tb[4], tb[5]};
-    } else {                 // positions 6 i, 6 i + 1 close a group (slots 2, 3), 6 i + 2 .. 6 i + 5 fill the next
-      *(f32x2*)(Vd + 2) = f32x2{ta[0], ta[1]};
-      *(f32x2*)(Vd + CH + 2) = f32x2{tb[0], tb[1]};
-      *(f32x4*)(Vd + PG) = f32x4{ta[2], ta[3], ta[4], ta[5]};
-      *(f32x4*)(Vd + PG + CH) = f32x4{tb[2], tb[3], tb[4], tb[5]};
+    *(f32x4*)(Vd) = f32x4{ta[0], ta[1], ta[2], ta[3]};
+    *(f32x4*)(Vd + CH) = f32x4{tb[0], tb[1], tb[2], tb[3]};
+    *(f32x2*)(Vd + PG) = f32x2{ta[4], ta[5]};
+    *(f32x2*)(Vd + PG + CH) = f32x2{tb[4], tb[5]};
+  };
+  auto store_odd = [&](float* Vd, const float (&wa)[6], const float (&wb)[6]) {    // 6 i % 4 == 2: two, then a full group
+    float ta[6], tb[6];
+    f4_bt(wa, ta);
+    f4_bt(wb, tb);
+    *(f32x2*)(Vd + 2) = f32x2{ta[0], ta[1]};
+    *(f32x2*)(Vd + CH + 2) = f32x2{tb[0], tb[1]};
+    *(f32x4*)(Vd + PG) = f32x4{ta[2], ta[3], ta[4], ta[5]};
+    *(f32x4*)(Vd + PG + CH) = f32x4{tb[2], tb[3], tb[4], tb[5]};
+  };
+  auto transform = [&](const float* raw_stage, int v_off) {
+    const float* R = raw_stage + rbase;
+    float oa[6], ob[6], ea[6], eb[6];   // the odd and the even row of the pair, channels a / b
+    if (wave < 2) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        if (c == 3) __builtin_amdgcn_sched_barrier(0);   // (12 reads in flight at a time: registers)
+        const f32x2 d1 = *(const f32x2*)(R + 1 * F4_ROW * 4 + CO[c]), d2 = *(const f32x2*)(R + 2 * F4_ROW * 4 + CO[c]),
+                    d3 = *(const f32x2*)(R + 3 * F4_ROW * 4 + CO[c]), d4 = *(const f32x2*)(R + 4 * F4_ROW * 4 + CO[c]);
+        const float a0 = fmaf(talpha, d2[0], d4[0]), b0 = fmaf(talpha, d1[0], d3[0]);
+        const float a1 = fmaf(talpha, d2[1], d4[1]), b1 = fmaf(talpha, d1[1], d3[1]);
+        oa[c] = fmaf(tbeta, b0, a0);
+        ea[c] = fmaf(-tbeta, b0, a0);
+        ob[c] = fmaf(tbeta, b1, a1);
+        eb[c] = fmaf(-tbeta, b1, a1);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        if (c == 2 || c == 4) __builtin_amdgcn_sched_barrier(0);   // (12 reads in flight at a time, not 36: registers)
+        const f32x2 d0 = *(const f32x2*)(R + CO[c]), d2 = *(const f32x2*)(R + 2 * F4_ROW * 4 + CO[c]),
+                    d4 = *(const f32x2*)(R + 4 * F4_ROW * 4 + CO[c]);
+        const f32x2 d1 = *(const f32x2*)(R + 1 * F4_ROW * 4 + CO[c]), d3 = *(const f32x2*)(R + 3 * F4_ROW * 4 + CO[c]),
+                    d5 = *(const f32x2*)(R + 5 * F4_ROW * 4 + CO[c]);
+        ea[c] = fmaf(4.0f, d0[0], fmaf(-5.0f, d2[0], d4[0]));
+        eb[c] = fmaf(4.0f, d0[1], fmaf(-5.0f, d2[1], d4[1]));
+        oa[c] = fmaf(4.0f, d1[0], fmaf(-5.0f, d3[0], d5[0]));
+        ob[c] = fmaf(4.0f, d1[1], fmaf(-5.0f, d3[1], d5[1]));
+      }
     }
+    store_odd(vs + v_off + vw_odd, oa, ob);
+    store_even(vs + v_off + vw_even, ea, eb);
   };
 
   f32x4 acc[36];
-  auto mfmas = [&](int u_off, int v_off, auto between) {
-    const float* va = lds + v_off + aoff;
-    const float* ub = lds + u_off + boff;
+  auto mfmas = [&](const float* u_stage, int v_off) {
+    const float* va = vs + v_off + aoff;
+    const float* ub = u_stage + boff;
     // three batches of three position groups; the reads of batch k + 1 are in flight under the MFMAs of batch k
+    // (batches of two: +1.5 %)
     f32x4 a0[3], b0[3], a1[3], b1[3];
     auto rd = [&](int g0, f32x4 (&a)[3], f32x4 (&bq)[3]) {
       if (flags & 16) {   // (ablation: operands without LDS reads)
@@ -335,163 +364,161 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_gn_kernel(const float* __r
     rd(3, a1, b1);
     mm(0, a0, b0);
     rd(6, a0, b0);
-    between(0);
     mm(3, a1, b1);
-    between(1);
     mm(6, a0, b0);
   };
-
-  constexpr int RS[3] = {L_R0, L_R1, L_R2};
-  constexpr int US[2] = {L_U0, L_U1};
-  constexpr int VS[2] = {L_V0, L_V1};
-  (void)US[1];
-  (void)VS[1];
 
   using MaskT = std::integral_constant<bool, true>;
   using MaskF = std::integral_constant<bool, false>;
   bool border = false;
-  // the vector work of one interval: transform of chunk ct (waves 0-5), activation of chunk ca (all waves)
-  auto vector_work = [&](int ct, int raw_t, int v_t, int ca, int raw_a) {
-    if (wave < 6 && ct < nchunks && !(flags & 64)) transform(raw_t, v_t);
-    if (ca < nchunks && !(flags & 32)) {
+  // the vector work of one interval: transform of chunk ct (waves 0-2) into V stage v_t, activation of chunk ca (waves 3-7)
+  auto vector_work = [&](int ct, const float* raw_t, int v_t, int ca, float* raw_a) {
+    if (wave < 3) {
+      if (ct < nchunks && !(flags & 64)) transform(raw_t, v_t);
+    } else if (ca < nchunks && !(flags & 32)) {
       if (border) activate(ca, raw_a, MaskT{});
       else activate(ca, raw_a, MaskF{});
     }
   };
-  // first raw chunks of the item that setup() just described (the three raw stages are free)
-  auto issue_first_raws = [&]() {
-    issue_raw(0, RS[0]);
-    if (1 < nchunks) issue_raw(1, RS[1]);
-    if (2 < nchunks) issue_raw(2, RS[2]);
+  // first raw chunks and U chunk 0 of the item that setup() just described (raw and U stages are free)
+  auto issue_first = [&]() {
+    issue_raw(0, raw_0);
+    if (1 < nchunks) issue_raw(1, raw_1);
+    if (2 < nchunks) issue_raw(2, raw_2);
+    issue_u(0, us_0);
   };
 
   int item = blockIdx.x;
   setup(item);
-  issue_first_raws();
+  issue_first();
   f32x2 abv = f32x2{0.f, 0.f};
   if (tid < C) abv = ((const f32x2*)ab)[(int64_t)b * C + tid];
   bool first = true;
   while (true) {
-    // ---- top of an item: its raw chunks 0-2 are in flight (issued under the previous item's epilogue), abv holds its
-    // affine table row.  (Later items: the only younger operations of a wave are its last 8 output stores.)
-    if (tid < C) *(f32x2*)(lds + L_AB + 2 * tid) = abv;
+    // ---- top of an item: its raw chunks 0-2 and U chunk 0 are in flight (issued in front of the previous item's epilogue),
+    // abv holds its affine table row.  Later items: a wave's younger operations are its 16 output stores (and the two
+    // stores of the statistics): all but those 18 done means the prefetch has landed, while the stores drain under the
+    // two prologue intervals and the first iteration
+    if (tid < C) *(f32x2*)(abl + 2 * tid) = abv;
     border = y0 == 0 || x0 == 0 || y0 + 16 >= H || x0 + 32 >= W;
 #pragma unroll
     for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (first) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue_u(0, US[0]);
-    vector_work(nchunks, 0, 0, 0, RS[0]);           // activate chunk 0
+    vector_work(nchunks, raw_0, 0, 0, raw_0);       // activate chunk 0
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    vector_work(0, RS[0], VS[0], 1, RS[1]);         // transform chunk 0, activate chunk 1
+    vector_work(0, raw_0, 0, 1, raw_1);             // transform chunk 0, activate chunk 1
 
-    // stage offsets of chunk c: raw c % 3, U / V c % 2 (scalars, rotated by hand)
-    int r_c = L_R0, r_c1 = L_R1, r_c2 = L_R2;   // raw stages of chunks c, c + 1, c + 2
-    int u_c = L_U0, u_c1 = L_U1, v_c = L_V0, v_c1 = L_V1;
-    for (int c = 0; c < nchunks; ++c) {
+    // iteration c = c0 + J (c0 % 6 == 0; stages of chunk j: raw j % 3, U / V j % 2): raw(c+2) and U(c) have landed,
+    // barrier; DMA of raw(c+3) into the stage the transform of iteration c - 1 consumed and of U(c+1); MFMAs of chunk c,
+    // transform of chunk c+1, activation of chunk c+2.  The two waves of a SIMD (w and w + 4) run the interval in
+    // opposite order - vector work first on waves 0-3 (the transform waves and one activation wave), matrix work first
+    // on waves 4-7.  (ONE copy of the MFMA block per body: two behind a branch make hipcc spill the accumulators.
+    // Issuing the matrix-first waves' DMA pieces behind their MFMAs was measured: the second call site costs registers,
+    // the loop spills, and a scratch reload is a vmcnt(0) wait behind the DMA: +12 %)
+    auto body = [&](int c, auto JJ) {
+      constexpr int J = decltype(JJ)::value;
+      using Rc = std::integral_constant<int, J % 3>;
+      using Rc1 = std::integral_constant<int, (J + 1) % 3>;
+      using Rc2 = std::integral_constant<int, (J + 2) % 3>;
+      using Uc = std::integral_constant<int, J % 2>;
+      using Uc1 = std::integral_constant<int, (J + 1) % 2>;
+      constexpr int Vc = (J % 2) * F4_V, Vc1 = ((J + 1) % 2) * F4_V;
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      // The two waves of a SIMD (w and w + 4) run the interval in opposite order - matrix work first on waves 0-3, vector
-      // work first on waves 4-7 - so that one's transform / activation issues under the other's MFMAs
-      // (ONE copy of the MFMA block: two copies behind a branch make hipcc spill the 144 accumulators).
-      // The DMA of the next chunks (6 one-KB pieces per wave: raw(c+3) into the stage the transform of iteration c - 1
-      // consumed, U(c+1)) costs the issuing wave ~100 cycles a piece: waves 4-7 issue theirs in front of their vector
-      // work, waves 0-3 between the batches of their MFMAs, where the partner's MFMAs cover it
-      const bool dma = !(flags & 8);
-      if (wave >= 4) {
-        if (c + 3 < nchunks && dma) issue_raw(c + 3, r_c);
-        if (c + 1 < nchunks && dma) issue_u(c + 1, u_c1);
-        if (!(flags & 4)) vector_work(c + 1, r_c1, v_c1, c + 2, r_c2);
-      }
-      if (!(flags & 2))
-        mfmas(u_c, v_c, [&](int k) {
-          if (wave < 4 && dma) {
-            if (k == 0) {
-              if (c + 3 < nchunks) issue_raw(c + 3, r_c);
-              if (c + 1 < nchunks) issue_u_part(c + 1, u_c1, 0);
-            } else if (c + 1 < nchunks) {
-              issue_u_part(c + 1, u_c1, 1);
-            }
-          }
-        });
-      if (wave < 4 && !(flags & 4)) vector_work(c + 1, r_c1, v_c1, c + 2, r_c2);
-      const int t3 = r_c;
-      r_c = r_c1;
-      r_c1 = r_c2;
-      r_c2 = t3;
-      const int tu = u_c;
-      u_c = u_c1;
-      u_c1 = tu;
-      const int tv = v_c;
-      v_c = v_c1;
-      v_c1 = tv;
+      if (c + 3 < nchunks && !(flags & 8)) issue_raw(c + 3, rawp(Rc{}));
+      if (c + 1 < nchunks && !(flags & 8)) issue_u(c + 1, usp(Uc1{}));
+      const bool vfirst = wave < 4;
+      if (vfirst && !(flags & 4)) vector_work(c + 1, rawp(Rc1{}), Vc1, c + 2, rawp(Rc2{}));
+      if (!(flags & 2)) mfmas(usp(Uc{}), Vc);
+      if (!vfirst && !(flags & 4)) vector_work(c + 1, rawp(Rc1{}), Vc1, c + 2, rawp(Rc2{}));
+    };
+    for (int c = 0; c < nchunks; c += 6) {
+#define KD_G(J) \
+  if (c + J < nchunks) body(c + J, std::integral_constant<int, J>{});
+      KD_G(0) KD_G(1) KD_G(2) KD_G(3) KD_G(4) KD_G(5)
+#undef KD_G
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // every stage is free from here on
 
     // ---- this item's coordinates for the epilogue; the loader state moves on to the next item, whose first three raw
-    // chunks start now (the raw stages take no part in the output exchange) and whose affine row is fetched
+    // chunks and first U chunk start now (the output exchange below lives in the V stages) and whose affine row is fetched
     const int eb = b, ey0 = y0, ex0 = x0, eslab = slab, eprem = prem;
     const int next = item + (int)gridDim.x;
     const bool has_next = next < nitems;
     if (has_next) {
       setup(next);
-      issue_first_raws();
+      issue_first();
       if (tid < C) abv = ((const f32x2*)ab)[(int64_t)b * C + tid];
     }
 
     // ---- output transform Y = A^T m A in registers (the lane holds positions 0..35 of tiles 16 mb + 4 (lane >> 4) + r at
     // output channel 16 cb + (lane & 15)), then a turn through LDS so that every pixel's 64 channels (256 bytes) leave
-    // in 16-byte pieces: X[tile 0..15][pixel 0..15][64 channels] = 64 KB over the U stages, one half of the tiles (mb)
-    // per round; all eight waves read a round back (32 pixels each), add bias / residual and store
-    float* const X = lds + L_U0;
+    // in 16-byte pieces: X[8 tiles][16 pixels][64 channels] = 32 KB over the V stages, four rounds: in round h every
+    // wave transforms its accumulator row h (tiles 16 mb + 4 (lane >> 4) + h); all eight waves read the round back (16
+    // pixels each), add bias / residual and store
+    float* const X = vs;
     const int n4 = eslab * F4_N + (lane & 15) * 4;
     const f32x4 b4 = bias ? *(const f32x4*)(bias + n4) : f32x4{0.f, 0.f, 0.f, 0.f};
     float* const yb = y + (int64_t)eb * H * W * N;
-    const float* const rb = res ? res + (int64_t)eb * H * W * ldres : nullptr;
+    const float* const rb = (res && !(flags & 1)) ? res + (int64_t)eb * H * W * ldres : nullptr;
     float fs1 = 0.f, fs2 = 0.f;
-#pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
-      if (mb == h) {
-        float* xw = X + ((lane >> 4) * 4 * 16) * F4_N + cb * 16 + (lane & 15);
+    // round h: accumulator row r = h of EVERY wave: X tile (mb * 4 + (lane >> 4)) = tile 16 mb + 4 (lane >> 4) + h
+    auto out_row = [&](auto RR) {
+      constexpr int r = decltype(RR)::value;
+      float* xw = X + ((mb * 4 + (lane >> 4)) * 16) * F4_N + cb * 16 + (lane & 15);
+      float sc[4][6];   // A^T m: columns first
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float sc[4][6];   // A^T m: columns first
+      for (int j = 0; j < 6; ++j) {
+        const float m[6] = {acc[j][r], acc[6 + j][r], acc[12 + j][r], acc[18 + j][r], acc[24 + j][r], acc[30 + j][r]};
+        float o[4];
+        f4_at(m, o);
 #pragma unroll
-          for (int j = 0; j < 6; ++j) {
-            const float m[6] = {acc[j][r], acc[6 + j][r], acc[12 + j][r], acc[18 + j][r], acc[24 + j][r], acc[30 + j][r]};
-            float o[4];
-            f4_at(m, o);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) sc[a][j] = o[a];
-          }
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            float o[4];
-            f4_at(sc[a], o);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xw[((r * 16) + a * 4 + q) * F4_N] = o[q];
-          }
-        }
+        for (int a = 0; a < 4; ++a) sc[a][j] = o[a];
       }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        float o[4];
+        f4_at(sc[a], o);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xw[(a * 4 + q) * F4_N] = o[q];
+      }
+    };
+#pragma unroll 1
+    for (int h = 0; h < 4; ++h) {
+      // pixel of the round this lane reads back: P = wave * 16 + j * 4 + (lane >> 4): X tile xt = P >> 4 is tile
+      // 16 (xt >> 2) + 4 (xt & 3) + h
+      f32x4 rv[4];
+      uint32_t pixv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int P = wave * 16 + j * 4 + (lane >> 4);
+        const int xt = P >> 4;
+        const int t = (xt >> 2) * 16 + (xt & 3) * 4 + h;
+        pixv[j] = (uint32_t)((ey0 + 4 * (t >> 3) + ((P >> 2) & 3)) * W + ex0 + 4 * (t & 7) + (P & 3));
+        if (rb) rv[j] = *(const f32x4*)(rb + (pixv[j] * (uint32_t)ldres + (uint32_t)n4));   // in flight under the transform
+      }
+      if (h == 0) out_row(std::integral_constant<int, 0>{});
+      else if (h == 1) out_row(std::integral_constant<int, 1>{});
+      else if (h == 2) out_row(std::integral_constant<int, 2>{});
+      else out_row(std::integral_constant<int, 3>{});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int P = wave * 32 + j * 4 + (lane >> 4);   // pixel of the round: tile P >> 4, row (P >> 2) & 3, column P & 3
-        const int t = h * 16 + (P >> 4);
-        const uint32_t pix = (uint32_t)((ey0 + 4 * (t >> 3) + ((P >> 2) & 3)) * W + ex0 + 4 * (t & 7) + (P & 3));
+      for (int j = 0; j < 4; ++j) {
+        const int P = wave * 16 + j * 4 + (lane >> 4);
         f32x4 v = *(const f32x4*)(X + P * F4_N + (lane & 15) * 4);
         v += b4;
-        if (rb && !(flags & 1)) v += *(const f32x4*)(rb + (pix * (uint32_t)ldres + (uint32_t)n4));
-        if (!(flags & 1) || v[0] == 123.456f) *(f32x4*)(yb + (pix * (uint32_t)N + (uint32_t)n4)) = v;
+        if (rb) v += rv[j];
+        if (!(flags & 1) || v[0] == 123.456f) *(f32x4*)(yb + (pixv[j] * (uint32_t)N + (uint32_t)n4)) = v;
         fs1 += (v[0] + v[1]) + (v[2] + v[3]);
         fs2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], fs2))));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // the round has been read: the next round (or the next item's U) may overwrite it
+      __builtin_amdgcn_s_barrier();   // the round has been read: the next round (or the next item's V) may overwrite it
     }
     if (opart) {   // the lane's 4 channels lie in 16-channel segment (lane & 15) >> 2: one entry per (patch, wave, segment)
       double gs1 = (double)fs1, gs2 = (double)fs2;
