@@ -293,14 +293,7 @@ int kd_gn_conv3x3_winograd_fused_nhwc(const float* d_x, const float* d_gamma, co
                                       const float* d_bias, const float* d_res, float* d_y, int B, int H,
                                       int W, int Cin, int Cout, int G, float eps, float* d_out_stats,
                                       int ldx, void* stream);
-/* The same `Block` through the fused Winograd F(4x4,3x3) kernel (1.78x fewer MFMA issues than F(2x2,3x3); V and the 36
- * positions of a tile never leave LDS / registers): needs H % 16 == 0, W % 32 == 0, Cin % 4 == 0, Cin <= 512,
- * Cout % 64 == 0.  Arguments as above. */
-int kd_gn_conv3x3_winograd4_fused_nhwc(const float* d_x, const float* d_gamma, const float* d_beta,
-                                      const float* d_scale_shift, const float* d_w_oihw,
-                                      const float* d_bias, const float* d_res, float* d_y, int B, int H,
-                                      int W, int Cin, int Cout, int G, float eps, float* d_out_stats,
-                                      int ldx, void* stream);
+
 /* (ldx: row stride of d_x in floats, >= Cin and a multiple of 4, 0 = dense: the plan hands this kernel channel-slice
  * views of wider buffers - a skip tensor living in the concat it will join.) */
 /* (d_out_stats, may be NULL: [B, G, 2] = (mean, rstd) of y per image and group of Cout / G channels, reduced

@@ -119,48 +119,27 @@ int launch_wino4_in(const float* x, int ldx, const float* stats, const float* ga
 int launch_wino4_out(const float* D, const float* bias, const float* res, int ldres, float* y, int ldy, double* seg_partial,
                      int B, int H, int W, int C, hipStream_t s);
 
-// ---- fused Winograd F(2x2,3x3) conv + GroupNorm / FiLM / SiLU, items of 64 output channels (kernels_wino_fused.hip)
-// U from launch_wino_fused_pack (16*N*C floats).  wino_fused_ok states the shapes it takes.
-bool wino_fused_ok(int B, int H, int W, int C, int N);
-int launch_wino_fused_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s, float scale = 1.0f);
-// wino_fused_gn_kernel evaluates SiLU as u / (1 + 2^u) on u = -log2(e) (A x + B): the affine of launch_gn_fold /
-// launch_gn_fold_seg carries WF_AB_SCALE and the weights packed for that kernel WF_U_SCALE = -ln 2 (the conv is
+// ---- fused Winograd F(2x2,3x3) conv + GroupNorm / FiLM / SiLU (kernels_wino_fused128.hip): items of 16 x 8 pixels x 128
+// output channels, Cin <= 2048.  The kernel evaluates SiLU as u / (1 + 2^u) on u = -log2(e) (A x + B): the affine of
+// launch_gn_fold / launch_gn_fold_seg carries WF_AB_SCALE and the weights packed for it WF_U_SCALE = -ln 2 (the conv is
 // linear, so the factor left on the activated values moves into U)
 constexpr float WF_AB_SCALE = -1.4426950408889634f;
 constexpr float WF_U_SCALE = -0.6931471805599453f;
-// y = conv3x3(SiLU(A x + B)) + bias (+ res): ab = launch_gn_fold's per-(image, channel) affine [B][C][2]; Cin <= 2048.
+// ab = per-(image, channel) affine [B][C][2] of GroupNorm (+ FiLM): y = conv3x3(SiLU(A x + B)) + bias (+ res)
 int launch_gn_fold(const float* stats, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
                    float* ab, int B, int C, int G, hipStream_t s);
-// out_partial != nullptr: the kernel also leaves (sum, sum of squares) partials of y per (image, group of
-// out_groups) in launch_gn_finalize's layout, wino_fused_out_stats_chunks(H, W, N, G) entries per (image, group)
-// items: the table launch_wino_fused_items fills for this (B, H, W, N): wino_fused_items_count entries of 16 bytes
-int launch_wino_fused_gn(const float* x, int ldx, const float* ab, const float* U, const float* bias, const float* res,
-                         int ldres, float* y, int B, int H, int W, int C, int N, double* out_partial, int out_groups,
-                         const void* items, hipStream_t s);
-size_t wino_fused_items_count(int B, int H, int W, int N);
-int launch_wino_fused_items(void* items, int B, int H, int W, int N, hipStream_t s);
-size_t wino_fused_out_stats_chunks(int H, int W, int N, int G);
-// The same layer with items of 16 x 8 pixels x 128 output channels (kernels_wino_fused128.hip): half the activation /
-// transform work per MFMA.  Own weight packing and item table; statistics in the same layout and count.
-bool wino_fused128_use(int B, int H, int W, int C, int N);   // shape fits and not switched off (KD_FWINO_N128=0)
-int launch_wino_fused128_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s, float scale);
+bool wino_fused128_ok(int B, int H, int W, int C, int N);   // H % 8 == 0, W % 16 == 0, Cin % 4 == 0, Cin <= 2048, Cout % 128 == 0
+int launch_wino_fused128_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s, float scale);   // U: 16 N C floats
+// items: id -> (image, y0, x0, slab), wino_fused128_items_count entries of 16 bytes for this (B, H, W, N)
 size_t wino_fused128_items_count(int B, int H, int W, int N);
 int launch_wino_fused128_items(void* items, int B, int H, int W, int N, hipStream_t s);
+// out_partial != nullptr: the kernel also leaves (sum, sum of squares) partials of y per (image, group of out_groups)
+// in launch_gn_finalize's layout, wino_fused_out_stats_chunks(H, W, N, G) entries per (image, group)
+size_t wino_fused_out_stats_chunks(int H, int W, int N, int G);
 int launch_wino_fused_gn128(const float* x, int ldx, const float* ab, const float* U, const float* bias, const float* res,
                             int ldres, float* y, int B, int H, int W, int C, int N, double* out_partial, int out_groups,
                             const void* items, hipStream_t s);
-// Fused Winograd F(4x4,3x3) + GroupNorm / FiLM / SiLU (kernels_wino4_fused.hip): items of 16 x 32 pixels x 64 output
-// channels, Cin <= 512.  U from launch_wino4_fused_pack (36 N C floats), ab as for launch_wino_fused_gn, out_partial
-// [B][N / 16][wino4_fused_out_stats_chunks][2] doubles (SegSrc with 16-channel groups)
-bool wino4_fused_ok(int B, int H, int W, int C, int N);
-int launch_wino4_fused_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s, float scale);
-size_t wino4_fused_items_count(int B, int H, int W, int N);
-size_t wino4_fused_out_stats_chunks(int H, int W);
-int launch_wino4_fused_items(void* items, int B, int H, int W, int N, hipStream_t s);
-int launch_wino4_fused_gn(const float* x, int ldx, const float* ab, const float* U, const float* bias, const float* res,
-                          int ldres, float* y, int B, int H, int W, int C, int N, double* out_partial, const void* items,
-                          hipStream_t s);
-int wino_fused_gn_max_cin();   // largest Cin launch_wino_fused_gn takes (its affine table lives in LDS)
+int wino_fused_gn_max_cin();   // largest Cin launch_wino_fused_gn128 takes (its affine table lives in LDS)
 // stats[b][g] = (mean, rstd) from `chunks` (sum, sum of squares) partials per (b, g), summed in index order
 int launch_gn_finalize(const double* partial, float* stats, int chunks, int B, int G, double count, float eps,
                        hipStream_t s);
@@ -189,7 +168,7 @@ int gate_add_chunks(int B, int HW);
 
 // GroupNorm statistics handed from the kernel that WRITES a map to the layer that normalises it: (sum, sum of
 // squares) in fp64 per image, 16-channel segment and producer-defined chunk, [B][nseg][nchunk][2].  Producers:
-// launch_gate_add, the conv epilogues (ConvParams::seg_partial), launch_wino_fused_gn (out_partial).
+// launch_gate_add, the conv epilogues (ConvParams::seg_partial), launch_wino_fused_gn128 (out_partial).
 struct SegSrc {
   const double* partial;  // nullptr: unused
   int nseg, nchunk;

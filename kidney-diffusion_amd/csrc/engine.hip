@@ -964,13 +964,13 @@ struct Builder {
     return y;
   }
 
-  // ---- fused Winograd F(2x2,3x3) + GroupNorm / FiLM / SiLU (kernels_wino_fused128.hip; kernels_wino_fused.hip where
-  // Cout % 128 != 0): every ResnetBlock 3x3 conv whose map the kernels can tile.  cfg.conv_algo 0: wherever the shape
-  // fits and the launch fills the chip; 1 and 2: never (2 = the batched-GEMM Winograd path only); 3: wherever the
-  // shape fits (tests).
+  // ---- fused Winograd F(2x2,3x3) + GroupNorm / FiLM / SiLU (kernels_wino_fused128.hip): every ResnetBlock 3x3 conv
+  // whose map the kernel can tile (H % 8, W % 16, Cout % 128: all reference configs; a reduced-width model's narrow
+  // levels take the batched-GEMM or the direct path).  cfg.conv_algo 0: wherever the shape fits and the launch fills
+  // the chip; 1 and 2: never (2 = the batched-GEMM Winograd path only); 3: wherever the shape fits (tests).
   bool fwino_ok(const T& x, int cout) const {
     if (cfg.conv_algo == 1 || cfg.conv_algo == 2) return false;
-    if (x.C < 32 || !wino_fused_ok(x.B, x.H, x.W, x.C, cout)) return false;
+    if (x.C < 32 || !wino_fused128_ok(x.B, x.H, x.W, x.C, cout)) return false;
     if (cfg.conv_algo == 3) return true;
     return (int64_t)x.B * (x.H / 16) * (x.W / 16) * (cout / 64) >= 256;  // one workgroup per CU and round
   }
@@ -990,11 +990,8 @@ struct Builder {
     const float* beta = P(gn_prefix + ".bias", Cin);
     const float* bias = P(conv_prefix + ".bias", Cout);
     const float* wsrc = raw(conv_prefix + ".weight", (int64_t)Cout * Cin * 9);
-    const bool n128 = wino_fused128_use(Bx, H, W, Cin, Cout);   // items of 128 output channels where the shape allows
-    float* U = n128 ? cached("winof_gn128:" + conv_prefix, (size_t)16 * Cout * Cin,
-                             [&](float* dst) { KD_THROW_IF(launch_wino_fused128_pack(wsrc, dst, Cout, Cin, 0, WF_U_SCALE)); })
-                    : cached("winof_gn:" + conv_prefix, (size_t)16 * Cout * Cin,
-                             [&](float* dst) { KD_THROW_IF(launch_wino_fused_pack(wsrc, dst, Cout, Cin, 0, WF_U_SCALE)); });
+    float* U = cached("winof_gn128:" + conv_prefix, (size_t)16 * Cout * Cin,
+                      [&](float* dst) { KD_THROW_IF(launch_wino_fused128_pack(wsrc, dst, Cout, Cin, 0, WF_U_SCALE)); });
     T ab = alloc_bytes((size_t)Bx * Cin * 2 * sizeof(float));
     T y = alloc(Bx, H, W, Cout);
     kd_unet* uu = u;
@@ -1016,17 +1013,11 @@ struct Builder {
     const int64_t m = (int64_t)Bx * H * W * Cout * Cin * 9;
     // id -> (image, y0, x0, slab) of the kernel's work items: one table per map shape, shared by the layers
     const std::string shape_key = std::to_string(Bx) + "x" + std::to_string(H) + "x" + std::to_string(W) + "x" + std::to_string(Cout);
-    const float* items =
-        n128 ? cached("winof128_items:" + shape_key, wino_fused128_items_count(Bx, H, W, Cout) * 4,
-                      [&](float* dst) { KD_THROW_IF(launch_wino_fused128_items(dst, Bx, H, W, Cout, 0)); })
-             : cached("winof_items:" + shape_key, wino_fused_items_count(Bx, H, W, Cout) * 4,
-                      [&](float* dst) { KD_THROW_IF(launch_wino_fused_items(dst, Bx, H, W, Cout, 0)); });
+    const float* items = cached("winof128_items:" + shape_key, wino_fused128_items_count(Bx, H, W, Cout) * 4,
+                                [&](float* dst) { KD_THROW_IF(launch_wino_fused128_items(dst, Bx, H, W, Cout, 0)); });
     emit([=](hipStream_t s) {
-      if (n128)
-        return launch_wino_fused_gn128(uu->P(xo), ldx, uu->P(abo), U, bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H,
-                                       W, Cin, Cout, so_ ? (double*)uu->P(pout) : nullptr, so_ ? Cout / 16 : 0, items, s);
-      return launch_wino_fused_gn(uu->P(xo), ldx, uu->P(abo), U, bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H, W,
-                                  Cin, Cout, so_ ? (double*)uu->P(pout) : nullptr, so_ ? Cout / 16 : 0, items, s);
+      return launch_wino_fused_gn128(uu->P(xo), ldx, uu->P(abo), U, bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Bx, H,
+                                     W, Cin, Cout, so_ ? (double*)uu->P(pout) : nullptr, so_ ? Cout / 16 : 0, items, s);
     }, "wino fused M" + std::to_string((int64_t)Bx * H * W) + " Cin" + std::to_string(Cin) + " Cout" +
            std::to_string(Cout), m);
     free(ab);

@@ -597,4 +597,36 @@ int launch_bcast_row(const float* src, float* dst, int64_t dst_bstride, int C, i
   return launch_copy_rows(src, 0, C, dst, dst_bstride, C, 1, C, B, s);
 }
 
+// ab[b][c] = (A, B) with GroupNorm(+FiLM)(x)[b][c] = A x + B (same arithmetic as gn_apply_silu_kernel)
+__global__ __launch_bounds__(256) void gn_fold_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      const float* __restrict__ scale_shift, int ld_ss,
+                                                      float* __restrict__ ab, int B, int C, int G) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * C) return;
+  const int b = idx / C, c = idx - b * C;
+  const int g = c / (C / G);
+  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+  float a = rstd * gamma[c];
+  float bb = beta[c] - mean * a;
+  if (scale_shift) {
+    const float sc = scale_shift[(int64_t)b * ld_ss + c] + 1.0f;
+    const float sh = scale_shift[(int64_t)b * ld_ss + C + c];
+    a *= sc;
+    bb = bb * sc + sh;
+  }
+  ab[2 * idx] = a * WF_AB_SCALE;   // the fused kernel's activation works on -log2(e) (A x + B)
+  ab[2 * idx + 1] = bb * WF_AB_SCALE;
+}
+
+int launch_gn_fold(const float* stats, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
+                   float* ab, int B, int C, int G, hipStream_t s) {
+  KD_REQUIRE(C % G == 0, "gn_fold: C % G");
+  hipLaunchKernelGGL(gn_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, stats, gamma, beta, scale_shift, ld_ss, ab,
+                     B, C, G);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+
 }  // namespace kd

@@ -1,6 +1,7 @@
-// Fused Winograd F(2x2,3x3) + GroupNorm/FiLM/SiLU for layers with Cout % 128 == 0: the sixteen-wave persistent kernel
-// of kernels_wino_fused.hip with an item of 16 x 8 pixels (8 x 4 output tiles) x 128 output channels instead of
-// 16 x 16 pixels x 64 channels - the same 64 accumulator registers per wave, the same MFMAs per chunk.
+// Fused Winograd F(2x2,3x3) + GroupNorm/FiLM/SiLU for the ResnetBlock 3x3 convs with Cout % 128 == 0 (every reference
+// config): a sixteen-wave persistent kernel with items of 16 x 8 pixels (8 x 4 output tiles) x 128 output channels.
+// (Its predecessor with items of 16 x 16 pixels x 64 channels - the same 64 accumulator registers per wave, the same
+// MFMAs per chunk - served only reduced-width test models and lives in scratch/wino_fused_64ch/.)
 //
 // Why: on gfx950 every VALU instruction is taken from the fp32 MFMA pipe's time (profiles/README.md), and in the
 // 64-channel kernel the activation (5 VALU + LDS round trip per patch value) and the input transform (8 VALU + 8 LDS
@@ -16,7 +17,7 @@
 //     (the row / column signs are wave-uniform multipliers of an fma, not code variants), one ds_write2;
 //   * activation: 180 x 4 patch values per chunk, at most one per thread;
 //   * U in 3 stages of 32 KB (chunk c + 2 is issued when chunk c - 1 has been consumed), raw patches in 4 of 4 KB, V in 2
-//     of 8 KB: the loop is unrolled 12 times (static stage indices, see kernels_wino_fused.hip);
+//     of 8 KB: the loop is unrolled 12 times (static stage indices, see scratch/wino_fused_64ch/kernels_wino_fused.hip);
 //   * the output transform's exchange (96 KB) lives in the three U stages, the waves' turn-around tiles (2 KB each,
 //     two rounds) in U stage 2 while U chunks 0 / 1 of the next item land in stages 0 / 1; the next item's first
 //     four raw chunks are fetched under the whole epilogue.
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(1024) void wino_fused_gn128_kernel(const float* __r
       // The wave's 16 outputs per lane are tile row PR of the item: pixel rows 2 PR, 2 PR + 1 x 16 pixels x 32 channels,
       // one channel per lane.  Two rounds (tile columns i = 2 h, 2 h + 1 of each lane half) through a private 2 KB of
       // LDS - [dy][xl = (2 i' + dx) + 4 half][channel] - turn them into 4 consecutive channels of one pixel per lane:
-      // 16-byte stores (+ residual loads), 4 per wave instead of 16 (kernels_wino_fused.hip)
+      // 16-byte stores (+ residual loads), 4 per wave instead of 16 (as its 64-channel predecessor did)
       float* sc = us_2 + wave * 512;
       const int rq = l_ >> 3, c4 = (l_ & 7) * 4;
       const int nb = en0 + wq * 32 + c4;
@@ -536,11 +537,10 @@ bool wino_fused128_ok(int B, int H, int W, int C, int N) {
          (int64_t)H * W * N * 4 < 0x7fffffff && (int64_t)B * (H / 8) * (W / 16) * (N / 128) < 0x7fffffff;
 }
 
-// the plan / the C ABI take this form wherever it applies; KD_FWINO_N128=0 (read once) keeps the 64-channel items (A/B)
-bool wino_fused128_use(int B, int H, int W, int C, int N) {
-  static const bool on = kd_switch("KD_FWINO_N128", 1) != 0;
-  return on && wino_fused128_ok(B, H, W, C, N);
-}
+int wino_fused_gn_max_cin() { return W_MAXC; }
+
+// chunks per image and group of the output statistics: four (tile rows) per 16 x 8 patch and 16-channel segment
+size_t wino_fused_out_stats_chunks(int H, int W, int N, int G) { return (size_t)(N / G / 16) * (H / 8) * (W / 16) * 4; }
 
 int launch_wino_fused128_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s, float scale) {
   KD_REQUIRE(O % 128 == 0 && I % WK == 0, "fused Winograd (128-channel items) weights need Cout % 128 == 0 and Cin % 4 == 0");

@@ -57,7 +57,7 @@ def test_unet_forward_with_winograd_levels_matches_oracle(device):
     import ctypes as C
     from imagen_pytorch import _engine as E
 
-    B, S = 16, 64
+    B, S = 4, 128   # (levels 32 @ 64^2, 64 @ 32^2, 128 @ 16^2, 256 @ 8^2: the fused kernel takes Cout % 128 on maps of 8 x 16 multiples)
     ou = H.oracle_unet("ultra2", lowres_cond=True, seed=13).eval()
     x, lr, cond, t, tl = _inputs("ultra2", B, S, True, seed=8)
     with torch.no_grad():
@@ -67,8 +67,8 @@ def test_unet_forward_with_winograd_levels_matches_oracle(device):
 
     outs, n_gemm = {}, {}
     # (conv_algo, wino_slice_mb): the third variant walks every Winograd layer in 256-tile slices
-    # conv_algo=3: the FUSED Winograd kernel (kernels_wino_fused.hip) wherever its shape rules allow, even
-    # where the launch would not fill the chip (here the 16x16 maps with 64 output channels)
+    # conv_algo=3: the FUSED Winograd kernel (kernels_wino_fused128.hip) wherever its shape rules allow, even
+    # where the launch would not fill the chip (here the 16x16 maps with 128 output channels)
     for algo, slice_mb in ((32, None), (1, None), (32, "1"), (3, None)):
         pu = H.product_unet_like(ou).to(device)
         pu.conv_algo = algo
