@@ -663,11 +663,11 @@ def main():
     # what the conditioning table costs a cold 250-step sample(): all T rows rebuilt, device time by HIP events
     cond_build = None
     if not args.no_cond_table:
-        built, rows = C.c_int(0), C.c_int(0)
+        built, rows, runs = C.c_int(0), C.c_int(0), C.c_int(0)
         E.check(lib.kd_sample_build_cond_table(handle, C.byref(sc), C.byref(sa), 0, T_SCHED, 1, C.byref(built), E.current_stream()))
-        ms = float(lib.kd_unet_cond_table_build_ms(handle, C.byref(rows)))
+        ms = float(lib.kd_unet_cond_table_build_ms(handle, C.byref(rows), C.byref(runs)))
         cond_build = {"ms": ms, "rows": int(built.value), "schedule_steps": T_SCHED,
-                      "runs_of_the_conditioning_ops": -(-T_SCHED // BATCH) if built.value else 0}
+                      "runs_of_the_conditioning_ops": int(runs.value)}
 
     # the >= 6x target of BASELINE.json is patch throughput of the 8x8 grid: measured by the same command, after the
     # timed region of the headline metric, on every rank (collective inside); 1 canvas (dependency bound 4.27x at 8

@@ -131,10 +131,11 @@ int kd_unet_num_launches(const kd_unet_t* u);
 /* ... of which conditioning launches (functions of log_snr / lowres_log_snr / text only): the sampler replaces them by ONE
  * gather per iteration when it runs from the conditioning table (kd_sample_args_t::cond_table). */
 int kd_unet_num_cond_launches(const kd_unet_t* u);
-/* device time (ms) and row count (*rows, may be NULL) of the plan's last conditioning-table build, < 0 if none was built
+/* device time (ms), row count (*rows) and runs of the conditioning ops (*runs; both may be NULL) of the plan's last
+ * conditioning-table build, < 0 if none was built
  * yet.  Rows are built on demand for the schedule steps a call walks, B steps per run of the conditioning ops (their rows
  * are independent over the batch): T / B runs for a whole schedule. */
-float kd_unet_cond_table_build_ms(const kd_unet_t* u, int* rows);
+float kd_unet_cond_table_build_ms(const kd_unet_t* u, int* rows, int* runs);
 
 /* Step-invariant text conditioning (the text branch of Unet.forward; reached by the
  * reference through sample_cond.py:36-48 / sample.py:51-60): text_to_cond, null-embedding select,

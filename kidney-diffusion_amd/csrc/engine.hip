@@ -198,7 +198,7 @@ struct kd_unet {
   uint32_t cond_row_total = 0;
   std::vector<char> cond_tab_row_ok;   // [T]: rows are built on demand, for the steps a call walks
   float cond_tab_build_ms = -1.f;    // device time and row count of the last build (kd_unet_cond_table_build_ms)
-  int cond_tab_build_rows = 0;
+  int cond_tab_build_rows = 0, cond_tab_build_runs = 0;
 
   float* P(size_t off) const { return (float*)((off & COND_FLAG) ? cond_ws + (off & ~COND_FLAG) : ws + off); }
   ~kd_unet() {
@@ -310,8 +310,9 @@ struct Builder {
     const size_t bytes = (size_t)b * h * w * c * sizeof(float);
     if (to_cond) {
       t.off = cond_alloc(bytes);
-      const size_t row = (size_t)h * w * c;
-      if (b == B && row > 0 && row < (size_t(1) << 31))
+      // batch-major: [B][...] as allocated, or a linear()'s flattened [1][1][B x tokens][N] (the batch still outermost)
+      const size_t total = (size_t)b * h * w * c, row = total / (size_t)B;
+      if ((b == B || (b == 1 && h == 1 && w % B == 0)) && row > 0 && row * B == total && row < (size_t(1) << 31))
         u->cond_segs.push_back(CondSeg{(uint32_t)((t.off & ~kd_unet::COND_FLAG) / 4), (uint32_t)row, 0});
       else
         u->cond_rows_ok = false;
@@ -535,7 +536,12 @@ struct Builder {
     // (one in-order stream: the next op that reuses the block runs after the reduction)
     const int ks = conv_ksplit(p);
     T part;
-    if (ks > 1) part = alloc_bytes((size_t)ks * x.B * Ho * Wo * Cout * sizeof(float));
+    if (ks > 1) {   // (scratch of this launch pair, not conditioning state: never in the cond region / table)
+      const bool tc = to_cond;
+      to_cond = false;
+      part = alloc_bytes((size_t)ks * x.B * Ho * Wo * Cout * sizeof(float));
+      to_cond = tc;
+    }
     const size_t parto = part.off;
     // GroupNorm partials of the output, left by the epilogue (channels [yoff, yoff + Cout) of y, or the Cout / 4
     // shuffled channels): several launches filling slices of one tensor (init conv) share the chunk count
@@ -848,6 +854,8 @@ struct Builder {
     // default threshold Cin >= 512.  Below it the transform passes (6.5 x the map through HBM) eat the GEMM saving:
     // same-box A/B against the fused F(2x2,3x3) kernel at batch 16: 256 -> 256 at 64 x 64 299 -> 286 us (-4 %, not
     // worth six times the per-conv rounding error), 256 -> 128 at 128 x 128 626 -> 737 (+18 %), at 256 x 256 +17 %
+    // (round 4, with the input transform 13 % faster: Cin = 256 on the 64 x 64 level alone, 9 layers, gives 32.74 -> 32.59 ms
+    // per forward - 0.5 % for six times those layers' rounding error: the threshold stays at 512)
     return x.C >= (cfg.wino43_min_cin > 0 ? cfg.wino43_min_cin : 512);
   }
   T wino4_block(const T& x, const std::string& gn_prefix, int ss_col, const std::string& conv_prefix, int Cout,

@@ -112,7 +112,7 @@ SIGNATURES = {
     "kd_unet_mfma_macs": (C.c_int64, [C.c_void_p]),
     "kd_unet_num_launches": (C.c_int, [C.c_void_p]),
     "kd_unet_num_cond_launches": (C.c_int, [C.c_void_p]),
-    "kd_unet_cond_table_build_ms": (C.c_float, [C.c_void_p, C.POINTER(C.c_int)]),
+    "kd_unet_cond_table_build_ms": (C.c_float, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "kd_unet_text_cond": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "kd_unet_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_void_p]),
