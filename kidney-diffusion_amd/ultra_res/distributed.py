@@ -298,13 +298,21 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
     send_keep = []                             # (works, buffer) of posted sends
     sent_bytes = 0
 
+    waited = {}   # id -> handle (kept alive: ids are reused after collection): a work handle is waited for ONCE - a
+                  # coalesced RCCL batch shares one handle between its bundles, and a second wait on a gloo handle hangs
+
+    def wait_all(works):
+        for w in works:
+            if id(w) not in waited:
+                waited[id(w)] = w
+                w.wait()
+
     def receive(src: int, g: int):
         rec = pending.pop((src, g), None)
         if rec is None:
             return
         works, buf, items = rec
-        for w in works:
-            w.wait()
+        wait_all(works)
         off = 0
         for it in items:
             sh = _item_shape(it, overlap)
@@ -387,8 +395,7 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
                     pending[(src, g)] = (works, buf, items)
                 send_keep.append((works, sends))
     for works, _ in send_keep:
-        for w in works:
-            w.wait()
+        wait_all(works)
     assert not pending, "a posted bundle was never consumed"
     last = stages[-1]
     S = G.PATCH_SIZES[last]

@@ -281,6 +281,44 @@ def test_strip_exchange_on_many_ranks_equals_single_process(world, gather):
     assert sum(out[r][1]["p2p_bytes_sent_by_this_rank"] for r in range(world)) == out[0][1]["p2p_bytes_total"]
 
 
+def _worker_coalesced(rank, world, port, out):
+    """RCCL returns ONE work handle for a whole batch_isend_irecv call (a coalesced group), gloo one per operation:
+    run the 2-rank grid with a batch_isend_irecv that hands back a single combined handle, as the RCCL path does."""
+    import torch.distributed as dist
+
+    real = dist.batch_isend_irecv
+
+    class Combined:
+        def __init__(self, works):
+            self.works = works
+
+        def wait(self):
+            for w in self.works:
+                w.wait()
+
+    def coalesced(ops):
+        return [Combined(real(ops))]
+
+    D.dist.batch_isend_irecv = coalesced
+    try:
+        _run_grid8(world, rank, port, out, "all")
+    finally:
+        D.dist.batch_isend_irecv = real
+
+
+def test_strip_exchange_with_one_handle_per_batch_as_rccl_returns_it():
+    single, _ = _run_grid8(1)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = mp.Manager().dict()
+    mp.spawn(_worker_coalesced, args=(2, port, out), nprocs=2, join=True)
+    for r in range(2):
+        res, st = out[r]
+        assert st["blocking_collectives"] == 1 and st["p2p_bytes_total"] > 0
+        assert all(torch.equal(p, q) for a, b in zip(res, single) for p, q in zip(a, b)), r
+
+
 def test_exchange_plan_of_the_8x8_grid_moves_strips_not_patches():
     """BASELINE configs[4] on 8 ranks: what crosses xGMI before the final gather, from the plan alone."""
     pos = [(i, j) for i in range(8) for j in range(8)]
