@@ -66,26 +66,28 @@ int launch_final_static(const float* lowres, const float* w, const float* bias, 
 }
 
 // out[b][o][y][x] = (stat ? stat[b][o][y][x] : bias[o]) + sum_tap P[b][y+kh-1][x+kw-1][o*9+tap]
-// One block per 64-pixel row segment: the 3 x 66 pixel rows of P (32 floats each) are staged in LDS
-// with 16-B loads, then every lane sums its pixel's 27 values.
-__global__ __launch_bounds__(64) void final_gather_kernel(const float* __restrict__ P, const float* __restrict__ stat,
-                                                          const float* __restrict__ bias, float* __restrict__ out,
-                                                          int H, int W) {
-  __shared__ __attribute__((aligned(16))) float tile[3][66][36];  // padded rows: conflict-free 4-B reads
-  const int segs = (W + 63) / 64;
-  const int seg = blockIdx.x % segs, y = (blockIdx.x / segs) % H, b = blockIdx.x / (segs * H);
-  const int x0 = seg * 64, lane = threadIdx.x;
+// One block per 4 rows x 64 pixels (a wave per row): the 6 x 66 pixel rows of P (32 floats each) are staged in LDS
+// with 16-B loads - every row of P is read 1.5 times (3 times with the one-row blocks of rounds 1-3: 165 -> ~60 us at
+// the headline shape) -, then every lane sums its pixel's 27 values.
+constexpr int FG_ROWS = 4;
+__global__ __launch_bounds__(64 * FG_ROWS) void final_gather_kernel(const float* __restrict__ P, const float* __restrict__ stat,
+                                                                   const float* __restrict__ bias, float* __restrict__ out,
+                                                                   int H, int W) {
+  __shared__ __attribute__((aligned(16))) float tile[FG_ROWS + 2][66][36];  // padded rows: conflict-free 4-B reads
+  const int segs = (W + 63) / 64, rgs = (H + FG_ROWS - 1) / FG_ROWS;
+  const int seg = blockIdx.x % segs, rg = (blockIdx.x / segs) % rgs, b = blockIdx.x / (segs * rgs);
+  const int x0 = seg * 64, y0 = rg * FG_ROWS, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  for (int idx = lane; idx < 3 * 66 * 8; idx += 64) {
+  for (int idx = threadIdx.x; idx < (FG_ROWS + 2) * 66 * 8; idx += 64 * FG_ROWS) {
     int q = idx & 7, px = (idx >> 3) % 66, r = idx / (66 * 8);
-    int iy = y + r - 1, ix = x0 + px - 1;
+    int iy = y0 + r - 1, ix = x0 + px - 1;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *(const f32x4*)(P + (((int64_t)b * H + iy) * W + ix) * 32 + q * 4);
     *(f32x4*)&tile[r][px][q * 4] = v;
   }
   __syncthreads();
-  const int x = x0 + lane;
-  if (x >= W) return;
+  const int x = x0 + lane, y = y0 + wv;
+  if (x >= W || y >= H) return;
 #pragma unroll
   for (int o = 0; o < 3; ++o) {
     const int64_t oi = (((int64_t)b * 3 + o) * H + y) * W + x;
@@ -93,15 +95,15 @@ __global__ __launch_bounds__(64) void final_gather_kernel(const float* __restric
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) acc += tile[kh][lane + kw][o * 9 + kh * 3 + kw];
+      for (int kw = 0; kw < 3; ++kw) acc += tile[wv + kh][lane + kw][o * 9 + kh * 3 + kw];
     out[oi] = acc;
   }
 }
 int launch_final_gather(const float* P, const float* stat, const float* bias, float* out, int B, int H, int W,
                         hipStream_t s) {
-  int segs = (W + 63) / 64;
-  hipLaunchKernelGGL(final_gather_kernel, dim3((unsigned)((int64_t)B * H * segs)), dim3(64), 0, s, P, stat, bias, out,
-                     H, W);
+  const int segs = (W + 63) / 64, rgs = (H + FG_ROWS - 1) / FG_ROWS;
+  hipLaunchKernelGGL(final_gather_kernel, dim3((unsigned)((int64_t)B * rgs * segs)), dim3(64 * FG_ROWS), 0, s, P, stat, bias,
+                     out, H, W);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
