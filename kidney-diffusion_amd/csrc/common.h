@@ -213,6 +213,10 @@ int launch_linear_skinny_valu(const float* x, int ldx, const float* w, const flo
 int launch_gca_pool(const float* x, const float* wk, const float* bk, float* logits, float* pooled,
                     float* scratch, int B, int HW, int C, hipStream_t s);
 size_t gca_scratch_floats(int B, int HW, int C);
+// the whole gate of a GlobalContext block with C <= 512 in two launches (pooling partials; merge + FC + SiLU + FC + sigmoid)
+bool gca_gate_fused_ok(int C, int hid);
+int launch_gca_gate(const float* x, const float* wk, const float* bk, float* scratch, const float* w0, const float* b0, int hid,
+                    const float* w2, const float* b2, float* gate, int B, int HW, int C, hipStream_t s);
 // time embedding: out[b][0]=t, [1..h]=sin(t*w*2pi), [h+1..2h]=cos
 int launch_sinu_emb(const float* t, const float* w, float* out, int B, int half, hipStream_t s);
 

@@ -799,12 +799,23 @@ struct Builder {
     const float* b0 = P(pre + ".net.0.bias", hid);
     const float* w2 = P(pre + ".net.2.weight", (int64_t)C * hid);
     const float* b2 = P(pre + ".net.2.bias", C);
+    int Bx = h.B, HW = h.HW();
+    kd_unet* uu = u;
+    if (gca_gate_fused_ok(C, hid) && h.B > 1 && kd_switch("KD_GCA_FUSED", 1)) {   // (a batch-1 patch: one workgroup would stream the weights alone)
+      T scratch = alloc_bytes(gca_scratch_floats(h.B, h.HW(), C) * sizeof(float));
+      T gate = alloc(h.B, 1, 1, C);
+      size_t ho = h.off, so = scratch.off, go = gate.off;
+      emit([=](hipStream_t s) {
+        return launch_gca_gate(uu->P(ho), wk, bk, uu->P(so), w0, b0, hid, w2, b2, uu->P(go), Bx, HW, C, s);
+      }, "gca_gate HW" + std::to_string(HW) + " C" + std::to_string(C));
+      u->macs += (int64_t)Bx * HW * C * 2 + (int64_t)Bx * C * hid * 2;
+      free(scratch);
+      return gate;
+    }
     T logits = alloc(h.B, h.H, h.W, 1);
     T pooled = alloc(h.B, 1, 1, C);
     T scratch = alloc_bytes(gca_scratch_floats(h.B, h.HW(), C) * sizeof(float));
     size_t ho = h.off, lo = logits.off, po = pooled.off, so = scratch.off;
-    int Bx = h.B, HW = h.HW();
-    kd_unet* uu = u;
     emit([=](hipStream_t s) {
       return launch_gca_pool(uu->P(ho), wk, bk, uu->P(lo), uu->P(po), uu->P(so), Bx, HW, C, s);
     }, "gca_pool HW" + std::to_string(HW) + " C" + std::to_string(C));

@@ -281,6 +281,120 @@ __global__ __launch_bounds__(256) void gca_combine_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------- GlobalContext gate in one launch (round 4)
+// The merge of the pooling partials, FC (C -> hid) + SiLU and FC (hid -> C) + sigmoid for one image per workgroup: three
+// launches (gca_combine + two skinny linears: 5 + 13-20 + 13-20 us of dependent-load latency) become one.  For
+// C <= 512: a workgroup then streams at most 0.5 + 0.5 MB of weights; above that the skinny kernels' N / 32 workgroups
+// stream them faster than 16 workgroups can.  Plain fp32 fma chains in index order.
+constexpr int GCAG_MAXC = 512;
+__global__ __launch_bounds__(256) void gca_gate_kernel(const float* __restrict__ part, int nchunks, int C,
+                                                       const float* __restrict__ w0, const float* __restrict__ b0, int hid,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       float* __restrict__ gate) {
+  __shared__ float se[1024];   // exp(m_i - mg) per chunk (nchunks <= 1024)
+  __shared__ float red[8];
+  __shared__ __attribute__((aligned(16))) float pooled[GCAG_MAXC];
+  __shared__ __attribute__((aligned(16))) float hidden[GCAG_MAXC / 2];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* pb = part + (int64_t)b * nchunks * (C + 2);
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < nchunks; i += 256) m = fmaxf(m, pb[(int64_t)i * (C + 2)]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  const float mg = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float l = 0.f;
+  for (int i = threadIdx.x; i < nchunks; i += 256) {
+    const float e = expf(pb[(int64_t)i * (C + 2)] - mg);
+    se[i] = e;
+    l += pb[(int64_t)i * (C + 2) + 1] * e;
+  }
+  l = wave_sum(l);
+  if (lane == 0) red[4 + wave] = l;
+  __syncthreads();
+  const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+  for (int c = threadIdx.x; c < C; c += 256) {   // consecutive threads read consecutive channels of a chunk
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 3 < nchunks; i += 4) {
+      s0 = fmaf(pb[(int64_t)i * (C + 2) + 2 + c], se[i], s0);
+      s1 = fmaf(pb[(int64_t)(i + 1) * (C + 2) + 2 + c], se[i + 1], s1);
+      s2 = fmaf(pb[(int64_t)(i + 2) * (C + 2) + 2 + c], se[i + 2], s2);
+      s3 = fmaf(pb[(int64_t)(i + 3) * (C + 2) + 2 + c], se[i + 3], s3);
+    }
+    for (; i < nchunks; ++i) s0 = fmaf(pb[(int64_t)i * (C + 2) + 2 + c], se[i], s0);
+    pooled[c] = ((s0 + s1) + (s2 + s3)) * inv;
+  }
+  __syncthreads();
+  typedef float f32x4g __attribute__((ext_vector_type(4)));
+  for (int h = threadIdx.x; h < hid; h += 256) {   // hidden = SiLU(W0 pooled + b0): a thread streams one weight row
+    const f32x4g* wr = (const f32x4g*)(w0 + (int64_t)h * C);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int c4 = 0; c4 < C / 4; ++c4) {
+      const f32x4g wv = wr[c4], pv = *(const f32x4g*)(pooled + 4 * c4);
+      a0 = fmaf(wv[0], pv[0], a0);
+      a1 = fmaf(wv[1], pv[1], a1);
+      a2 = fmaf(wv[2], pv[2], a2);
+      a3 = fmaf(wv[3], pv[3], a3);
+    }
+    const float v = ((a0 + a1) + (a2 + a3)) + b0[h];
+    hidden[h] = v / (1.0f + expf(-v));
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < C; n += 256) {     // gate = sigmoid(W2 hidden + b2)
+    const float* wr = w2 + (int64_t)n * hid;
+    float a0 = 0.f, a1 = 0.f;
+    int h = 0;
+    if ((hid & 3) == 0) {
+      float a2 = 0.f, a3 = 0.f;
+      for (; h < hid; h += 4) {
+        const f32x4g wv = *(const f32x4g*)(wr + h), hv = *(const f32x4g*)(hidden + h);
+        a0 = fmaf(wv[0], hv[0], a0);
+        a1 = fmaf(wv[1], hv[1], a1);
+        a2 = fmaf(wv[2], hv[2], a2);
+        a3 = fmaf(wv[3], hv[3], a3);
+      }
+      a0 += a2;
+      a1 += a3;
+    } else {
+      for (; h < hid; ++h) a0 = fmaf(wr[h], hidden[h], a0);
+    }
+    const float v = (a0 + a1) + b2[n];
+    gate[(int64_t)b * C + n] = 1.0f / (1.0f + expf(-v));
+  }
+}
+
+bool gca_gate_fused_ok(int C, int hid) {
+  return C % 4 == 0 && C <= GCAG_MAXC && hid <= GCAG_MAXC / 2 && hid > 0;
+}
+
+static int launch_gca_partial(const float* x, const float* wk, const float* bk, float* scratch, int B, int HW, int C, int rows,
+                              int chunks, hipStream_t s) {
+  size_t smem = (size_t)(4 * C + 8) * sizeof(float);
+  const int C4 = C / 4;
+  dim3 grid(chunks, B), blk(256);
+  if (C4 == 32) hipLaunchKernelGGL((gca_partial_kernel<1, 2>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
+  else if (C4 <= 64) hipLaunchKernelGGL((gca_partial_kernel<1, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
+  else if (C4 <= 128) hipLaunchKernelGGL((gca_partial_kernel<2, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
+  else if (C4 <= 256) hipLaunchKernelGGL((gca_partial_kernel<4, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
+  else hipLaunchKernelGGL((gca_partial_kernel<8, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// pooling partials + the gate in two launches: gate[b][c] = sigmoid(W2 SiLU(W0 pooled_b + b0) + b2)
+int launch_gca_gate(const float* x, const float* wk, const float* bk, float* scratch, const float* w0, const float* b0, int hid,
+                    const float* w2, const float* b2, float* gate, int B, int HW, int C, hipStream_t s) {
+  KD_REQUIRE(gca_gate_fused_ok(C, hid), "fused GlobalContext gate needs C % 4 == 0, C <= 512, hidden <= 256");
+  KD_REQUIRE((((uintptr_t)w0 | (uintptr_t)w2) & 15) == 0, "fused GlobalContext gate: 16-byte aligned weights");
+  const int rows = gca_rows(HW, B), chunks = (HW + rows - 1) / rows;
+  if (launch_gca_partial(x, wk, bk, scratch, B, HW, C, rows, chunks, s)) return 1;
+  hipLaunchKernelGGL(gca_gate_kernel, dim3(B), dim3(256), 0, s, scratch, chunks, C, w0, b0, hid, w2, b2, gate);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 size_t gca_scratch_floats(int B, int HW, int C) {
   int rows = gca_rows(HW, B), chunks = (HW + rows - 1) / rows;
   return (size_t)B * chunks * (C + 2);
@@ -290,14 +404,7 @@ int launch_gca_pool(const float* x, const float* wk, const float* bk, float* /*l
                     float* scratch, int B, int HW, int C, hipStream_t s) {
   KD_REQUIRE(C % 4 == 0 && C <= 64 * 4 * GCA_MAXT, "gca needs C % 4 == 0 and C <= 2048");
   const int rows = gca_rows(HW, B), chunks = (HW + rows - 1) / rows;
-  size_t smem = (size_t)(4 * C + 8) * sizeof(float);
-  const int C4 = C / 4;
-  dim3 grid(chunks, B), blk(256);
-  if (C4 == 32) hipLaunchKernelGGL((gca_partial_kernel<1, 2>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
-  else if (C4 <= 64) hipLaunchKernelGGL((gca_partial_kernel<1, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
-  else if (C4 <= 128) hipLaunchKernelGGL((gca_partial_kernel<2, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
-  else if (C4 <= 256) hipLaunchKernelGGL((gca_partial_kernel<4, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
-  else hipLaunchKernelGGL((gca_partial_kernel<8, 1>), grid, blk, smem, s, x, wk, bk, scratch, HW, C, rows);
+  if (launch_gca_partial(x, wk, bk, scratch, B, HW, C, rows, chunks, s)) return 1;
   hipLaunchKernelGGL(gca_combine_kernel, dim3(B, (C + 15) / 16), dim3(256), 0, s, scratch, pooled, chunks, C);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
