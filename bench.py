@@ -422,6 +422,9 @@ def grid_workload(args, world, rank, device, distributed, barrier, canvases_list
     for _ in range(max(1, warmup)):
         sample_fn.warm({st: range(1, gb[st] + 1) for st in (1, 2, 3)}, cond[0])
 
+    if distributed:
+        D.connect_ranks(None, slab_dev)   # RCCL send / recv connections between every pair, outside the timed region
+
     from imagen_pytorch import _engine as E
 
     lib = E.load()

@@ -191,6 +191,38 @@ class ExchangePlan:
         return max(free)
 
 
+_connected = set()
+
+
+def _connect_all(group, device, world: int, rank: int) -> None:
+    """RCCL sets up a send / recv connection the first time a pair uses it, inside the group call that carries the
+    operation; in the run itself the ranks reach their exchange calls at different times.  One synchronised batch in
+    which every rank exchanges a word with every other rank (all ranks enter it together, right after the caller's
+    barrier or at the first grid) leaves only enqueueing to the later calls.  Done once per process and group."""
+    key = (id(group), world)
+    if world < 2 or key in _connected or dist.get_backend(group) != "nccl":
+        return
+    glob = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    tx = torch.zeros(world, device=device)
+    rx = torch.empty(world, device=device)
+    ops = []
+    for r in range(world):
+        if r != rank:
+            ops.append(dist.P2POp(dist.isend, tx[r:r + 1], glob(r), group))
+            ops.append(dist.P2POp(dist.irecv, rx[r:r + 1], glob(r), group))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    torch.cuda.synchronize(device)
+    _connected.add(key)
+
+
+def connect_ranks(group=None, device: Optional[torch.device] = None) -> None:
+    """Sets up the point-to-point connections of `sample_grids` ahead of the first grid (call it on every rank, e.g. behind
+    the warm-up): otherwise the first exchange of a process pays for them."""
+    if dist.is_initialized() and device is not None and torch.device(device).type == "cuda":
+        _connect_all(group, torch.device(device), dist.get_world_size(group), dist.get_rank(group))
+
+
 def _cut_item(item: Item, patch: torch.Tensor, overlap: float, orientation: int) -> torch.Tensor:
     kind = item[0]
     if kind == "low":
@@ -292,6 +324,8 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
     index = [{p: n for n, p in enumerate(pos)} for pos in patch_pos]
     start_low = [None] * ncanvas if lowres is None else [None if l is None else list(l) for l in lowres]
     plan = ExchangePlan(patch_pos, orientations, stages, world, pipeline, stage_cost)
+    if world > 1 and device is not None and torch.device(device).type == "cuda":
+        _connect_all(group, torch.device(device), world, rank)
     local: Dict[STask, torch.Tensor] = {}     # finished patches sampled on this rank
     have: Dict[Item, torch.Tensor] = {}       # strips / previous-stage patches received from other ranks
     pending: Dict[Tuple[int, int], tuple] = {}   # (src, wave) -> (works, buffer, items) of a bundle in flight
