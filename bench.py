@@ -40,7 +40,14 @@ DOMINANT = ("wino_fused_gn128_kernel: fused Winograd F(2x2,3x3) 3x3 convs of the
             "in the kernel (sixteen waves, persistent workgroups, items of 16x8 pixels x 128 output channels)")
 WINO4 = ("conv_buf_kernel: the 36 position GEMMs of Winograd F(4x4,3x3) - the ResnetBlock 3x3 convs with Cin >= 512 "
          "(buffer-DMA implicit-GEMM kernel, batched over the positions)")
+WINO4_X3 = ("gemm_bf16x3_kernel: the 36 position GEMMs of Winograd F(4x4,3x3) - the ResnetBlock 3x3 convs with Cin >= 512 - as "
+            "fp32 products on the bf16 matrix pipe (three bf16 pieces per fp32 operand, six exact products per k-step, fp32 "
+            "accumulation; LDS-DMA ring fed by loader waves)")
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix = vector peak (v_mfma_f32_32x32x2_f32, exact fp32)
+# dense bf16 matrix peak (MI355X_MICROARCH.md "~2.5 PF dense": v_mfma_f32_32x32x16_bf16 at 32 cycles per SIMD, 1024 CU-SIMDs,
+# 2.4 GHz).  The bf16x3 GEMMs (kernels_gemm_bf16x3.hip) issue SIX bf16 MACs per fp32 MAC: their fp32-equivalent ceiling is
+# a sixth of this, 419 TFLOP/s
+BF16_PEAK_TFLOPS = 2516.6
 SR_UNET_KW = dict(dim=128, dim_mults=(1, 2, 4, 8), num_resnet_blocks=2, memory_efficient=True,
                   layer_attns=(False, False, False, True), layer_cross_attns=(False, False, True, True),
                   init_conv_to_final_conv_residual=True, cond_images_channels=3)  # train_ultra_res.py:39-48
@@ -119,13 +126,15 @@ def kernel_classes(lib, handle, iters=3):
     for _, label, macs, us, mfma in rows:
         us, macs, mfma = float(us), int(macs), int(mfma)
         total_us += us
-        m = re.match(r"(wino_in|wino_out|wino gemm|wino4_in|wino4_out|wino4 gemm) M(\d+) Cin(\d+) Cout(\d+)", label)
+        m = re.match(r"(wino_in|wino_out|wino gemm|wino4_in|wino4_out|wino4 gemm bf16x3|wino4 gemm) M(\d+) Cin(\d+) Cout(\d+)", label)
         if label.startswith("conv k3"):
             add("conv_buf_kernel: direct 3x3 convs", us, 2.0 * macs, 2.0 * mfma)
         elif label.startswith("wino fused"):
             add(DOMINANT, us, 2.0 * macs, 2.0 * mfma)
         elif m and m.group(1) == "wino gemm":
             add("conv_buf_kernel: Winograd F(2x2,3x3) position GEMMs", us, 2.0 * macs, 2.0 * mfma)
+        elif m and m.group(1) == "wino4 gemm bf16x3":   # `mfma` = the bf16 MACs (6 per fp32 MAC of the 36 GEMMs)
+            add(WINO4_X3, us, 2.0 * macs, 2.0 * mfma)
         elif m and m.group(1) == "wino4 gemm":
             add(WINO4, us, 2.0 * macs, 2.0 * mfma)
         elif m and m.group(1).startswith("wino4"):  # transforms move 3.25x the map: read 1x / write 2.25x (in), the reverse (out)
@@ -147,7 +156,11 @@ def kernel_classes(lib, handle, iters=3):
     out = []
     for key, (n, us, flop, issued, nbytes) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
         e = {"kernel": key, "launches": n, "ms": us / 1e3, "avg_us": us / n, "share": us / total_us}
-        if flop:
+        if flop and key == WINO4_X3:
+            e.update(bound="mfma", achieved=issued / us / 1e6, unit="TFLOP/s (bf16 MFMA)", peak=BF16_PEAK_TFLOPS,
+                     frac=issued / us / 1e6 / BF16_PEAK_TFLOPS, achieved_fp32_equiv=issued / 6.0 / us / 1e6,
+                     achieved_direct_equiv=flop / us / 1e6, issued_tflop_per_step=issued / 1e12)
+        elif flop:
             e.update(bound="mfma", achieved=issued / us / 1e6, unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
                      frac=issued / us / 1e6 / FP32_PEAK_TFLOPS, achieved_direct_equiv=flop / us / 1e6,
                      issued_tflop_per_step=issued / 1e12)
@@ -557,6 +570,9 @@ def main():
     ap.add_argument("--no-cond-table", action="store_true",
                     help="compute the time conditioning in every step instead of restoring it from the per-schedule table "
                          "(profiles: keeps the one-off table build, 250 x 21 launches, out of a 7-step trace)")
+    ap.add_argument("--fp32-mfma-gemms", action="store_true",
+                    help="sr: the F(4x4,3x3) position GEMMs on the fp32 MFMA pipe (conv_buf_kernel) instead of the bf16x3 "
+                         "kernel - the A/B of profiles/README.md")
     ap.add_argument("--no-line-grid", action="store_true",
                     help="sr: leave the nested `grid` object (8x8 grid patches/s for 1 and 3 canvases) out of the line")
     ap.add_argument("--line-grid-steps", type=int, default=4, help="timesteps per stage of the nested grid runs")
@@ -612,9 +628,12 @@ def main():
 
     lib = E.load()
     unet = build_unet(0)
+    if args.fp32_mfma_gemms:
+        unet.gemm_bf16x3 = -1
     handle = unet.engine(BATCH, SIZE, device, with_text=False)
     macs = lib.kd_unet_macs(handle)            # algorithmic: the direct convolutions the reference computes
     mfma_macs = lib.kd_unet_mfma_macs(handle)  # issued on the matrix cores (Winograd layers: 16/36 of theirs)
+    mfma_bf16_macs = lib.kd_unet_mfma_bf16_macs(handle)  # bf16 MACs of the bf16x3 GEMMs (6 per fp32 MAC; not in mfma_macs)
     flop_per_step = 2.0 * macs
     launches = lib.kd_unet_num_launches(handle)
     cond_launches = lib.kd_unet_num_cond_launches(handle)
@@ -683,6 +702,9 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         dev_ms_per_step = dev_ms / args.steps
         step_issued = 2.0 * mfma_macs / (dev_ms_per_step * 1e-3) / 1e12
+        step_issued_bf16 = 2.0 * mfma_bf16_macs / (dev_ms_per_step * 1e-3) / 1e12
+        # share of the step's time the matrix pipe would be busy at its nominal rates: fp32 MFMA work + bf16 MFMA work
+        step_pipe_frac = step_issued / FP32_PEAK_TFLOPS + step_issued_bf16 / BF16_PEAK_TFLOPS
         step_direct = flop_per_step / (dev_ms_per_step * 1e-3) / 1e12
         kernels = kernel_classes(lib, handle) if world == 1 and not args.no_kernel_classes else None
         dom = next((k for k in (kernels or []) if k["kernel"] == DOMINANT), None)
@@ -711,15 +733,18 @@ def main():
                 traffic_source=("profile-derived, not measured in this run: " + prof["source"]) if prof.get("source") else None)
         else:  # multi-GPU runs / --no-kernel-classes: no per-launch profile, whole-step pipe utilisation instead
             roof.update(kernel="whole denoising step (per-launch profile skipped)", achieved=step_issued,
-                        frac=step_issued / FP32_PEAK_TFLOPS, achieved_direct_equiv=step_direct, traffic=None)
+                        frac=step_pipe_frac, achieved_direct_equiv=step_direct, traffic=None)
         roof["step"] = {
-            "issued_tflops": step_issued, "frac_issued": step_issued / FP32_PEAK_TFLOPS,
+            "issued_tflops": step_issued, "issued_bf16_tflops": step_issued_bf16, "frac_issued": step_pipe_frac,
             "direct_equiv_tflops": step_direct, "device_ms": dev_ms_per_step,
             "algorithmic_tflop_per_step": flop_per_step / 1e12, "issued_tflop_per_step": 2.0 * mfma_macs / 1e12,
+            "issued_bf16_tflop_per_step": 2.0 * mfma_bf16_macs / 1e12,
             "traffic_bytes_per_step": prof.get("bytes_per_step"),
             "note": "one denoising-step graph = UNet forward + x0 / quantile / DDPM update; device time by HIP events "
-                    "on the launch stream; issued = what the conv / GEMM launches put on the matrix cores "
-                    "(kd_unet_mfma_macs), direct_equiv = 2 x 229.2 GMAC/sample x 16 of SURVEY §8d / time"}
+                    "on the launch stream; issued = what the conv / GEMM launches put on the fp32 matrix pipe "
+                    "(kd_unet_mfma_macs), issued_bf16 = the bf16 MFMA work of the bf16x3 GEMMs (kd_unet_mfma_bf16_macs, six "
+                    "bf16 MACs per fp32 MAC), frac_issued = issued / 157.3 + issued_bf16 / 2516.6 (the share of the step the "
+                    "matrix pipe is busy at nominal rates), direct_equiv = 2 x 229.2 GMAC/sample x 16 of SURVEY §8d / time"}
         roof["kernels"] = kernels
         out = {
             "metric": "denoising-steps/sec (64->256 SR UNet, bs16)",
@@ -732,6 +757,11 @@ def main():
             "config": {"workload": "BASELINE configs[2]: stage-2 super-res UNet 64->256 (train_ultra_res.py:39-48, "
                                    "3 cond channels), batch 16 per GPU, cosine schedule T=250, dynamic thresholding, "
                                    "random-init weights, Philox noise on device, hipGraph-replayed step",
+                       "arithmetic": ("fp32 values and fp32 accumulation everywhere"
+                                      + ("; the position GEMMs of the F(4x4,3x3) layers form each fp32 product from six exact "
+                                         "bf16 MFMA products of three-piece operands (a = ah + am + al exactly) - error against "
+                                         "fp64 at or below the fp32 MFMA path's (tests/test_kernels_gpu.py, "
+                                         "test_fullsize_gpu.py), same parity bounds" if mfma_bf16_macs else "")),
                        "batch_per_gpu": BATCH, "image_size": SIZE, "launches_per_step": launches,
                        "launches_per_step_from_cond_table": launches if args.no_cond_table else launches - cond_launches + 1,
                        "cond_table": ("off" if args.no_cond_table else

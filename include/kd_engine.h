@@ -96,6 +96,11 @@ typedef struct kd_unet_config {
    * many input channels whose GEMMs fill the chip; 0 = default (512), < 0 = never.  fp32 throughout; per-conv relative
    * L2 against fp64 3-4e-6 (F(2x2,3x3): 5e-7) - inside the 2e-5 the UNet forward is held to. */
   int wino43_min_cin;
+  /* The position GEMMs of those F(4x4,3x3) layers on the bf16 matrix pipe, every fp32 operand carried as three bf16
+   * pieces (a = ah + am + al exactly) and six exact products accumulated in fp32 per k-step (kernels_gemm_bf16x3.hip):
+   * fp32-class results - error against fp64 not above the fp32 MFMA path's - at 3/8 of its matrix cycles.
+   * 0 = default (where tiles % 256 == 0, Cout % 128 == 0), < 0 = never (fp32 MFMA). */
+  int gemm_bf16x3;
 } kd_unet_config_t;
 
 /* One named parameter tensor of the UNet's state_dict (key WITHOUT the `unets.N.` prefix,
@@ -127,6 +132,8 @@ int64_t kd_unet_macs(const kd_unet_t* u);
  * kd_unet_macs where a 3x3 conv runs as Winograd F(2x2,3x3) (16/36 of its MACs) and by the
  * step-invariant share of the init / final conv that is hoisted out of the step */
 int64_t kd_unet_mfma_macs(const kd_unet_t* u);
+/* bf16 MACs the plan's bf16x3 GEMMs issue per forward (six per fp32 MAC of theirs; not included in kd_unet_mfma_macs) */
+int64_t kd_unet_mfma_bf16_macs(const kd_unet_t* u);
 int kd_unet_num_launches(const kd_unet_t* u);
 /* ... of which conditioning launches (functions of log_snr / lowres_log_snr / text only): the sampler replaces them by ONE
  * gather per iteration when it runs from the conditioning table (kd_sample_args_t::cond_table). */
@@ -278,10 +285,15 @@ int kd_conv3x3_winograd_nhwc(const float* d_x, const float* d_w_oihw, const floa
  * path for the deepest layers (kernels_wino4.hip): weight transform, input transform, 36 batched GEMMs, output transform.
  * Needs H % 4 == 0, W % 4 == 0, B (H/4) (W/4) % 128 == 0, Cin % 32 == 0, Cout % 64 == 0.  d_out_stats (may be NULL):
  * [B, G, 2] = (mean, rstd) of y per image and group of Cout / G channels from the partial sums the output transform
- * leaves for the next GroupNorm; needs (Cout / G) % 16 == 0. */
+ * leaves for the next GroupNorm; needs (Cout / G) % 16 == 0.  gemm_bf16x3 != 0: the GEMMs on the bf16 matrix pipe as the
+ * plan runs them by default (kd_unet_config_t::gemm_bf16x3; needs B (H/4) (W/4) % 256 == 0 and Cout % 128 == 0 as well). */
 int kd_conv3x3_winograd4_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias, const float* d_res,
                               float* d_y, int B, int H, int W, int Cin, int Cout, int G, float eps,
-                              float* d_out_stats, void* stream);
+                              float* d_out_stats, int gemm_bf16x3, void* stream);
+/* C[g][M][N] = A[g][M][K] B[g][N][K]^T (fp32, row-major) through the bf16x3 GEMM of kernels_gemm_bf16x3.hip: both
+ * operands split into three bf16 planes, six bf16 MFMAs per k-step, fp32 accumulation.  Needs M % 256 == 0,
+ * N % 128 == 0, K % 32 == 0, 6 G M K and 6 G N K below 2^32 bytes. */
+int kd_gemm_bf16x3(const float* d_a, const float* d_b, float* d_c, int G, int M, int N, int K, void* stream);
 /* ResnetBlock `Block` in one pass over x: conv3x3(SiLU(FiLM(GroupNorm_G(x)))) + bias (+ d_res), the form the
  * plan uses for those layers: statistics, a per-(image, channel) affine fold, and the fused Winograd kernel
  * with the activation applied to the raw patch in LDS (the activated map is never written).  d_scale_shift

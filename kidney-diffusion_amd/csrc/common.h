@@ -119,6 +119,32 @@ int launch_wino4_in(const float* x, int ldx, const float* stats, const float* ga
 int launch_wino4_out(const float* D, const float* bias, const float* res, int ldres, float* y, int ldy, double* seg_partial,
                      int B, int H, int W, int C, hipStream_t s);
 
+// ---- fp32 GEMMs on the bf16 matrix pipe (kernels_gemm_bf16x3.hip): operands as three bf16 planes in k-chunk-major order,
+// planes[p][g][k / 16][row][k % 16], p = 0 high, 1 middle, 2 low piece (a = ah + am + al exactly); C[g][M][N] =
+// A[g][M][K] B[g][N][K]^T with six bf16 MFMAs per k-step - fp32-class results (error against fp64 not above the fp32 MFMA's)
+constexpr int X3_BK = 16;
+// the three pieces of two consecutive values, each pair packed in a dword (v_cvt_pk_bf16_f32: round to nearest even;
+// every subtraction is exact)
+__device__ __forceinline__ void x3_split(const float __attribute__((ext_vector_type(2))) a, uint32_t& h, uint32_t& m,
+                                         uint32_t& l) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  const b2 hb = __builtin_convertvector(a, b2);
+  const f2 r1 = a - __builtin_convertvector(hb, f2);
+  const b2 mb = __builtin_convertvector(r1, b2);
+  const f2 r2 = r1 - __builtin_convertvector(mb, f2);
+  const b2 lb = __builtin_convertvector(r2, b2);
+  h = __builtin_bit_cast(uint32_t, hb);
+  m = __builtin_bit_cast(uint32_t, mb);
+  l = __builtin_bit_cast(uint32_t, lb);
+}
+bool gemm_bf16x3_ok(int G, int64_t M, int N, int K);   // M % 256 == 0, N % 128 == 0, K % 32 == 0, planes < 4 GB
+int launch_split3(const float* x, void* planes, int G, int R, int K, hipStream_t s);   // x [G][R][K] -> 3 G R K bf16
+int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, int N, int K, hipStream_t s);
+// launch_wino4_in writing V as the three planes the bf16x3 GEMM reads ([3][36][C/16][Mt][16] bf16; Mt % 8 == 0, C % 16 == 0)
+int launch_wino4_in3(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
+                     const float* scale_shift, int ld_ss, void* V3, int B, int H, int W, int C, int G, hipStream_t s);
+
 // ---- fused Winograd F(2x2,3x3) conv + GroupNorm / FiLM / SiLU (kernels_wino_fused128.hip): items of 16 x 8 pixels x 128
 // output channels, Cin <= 2048.  The kernel evaluates SiLU as u / (1 + 2^u) on u = -log2(e) (A x + B): the affine of
 // launch_gn_fold / launch_gn_fold_seg carries WF_AB_SCALE and the weights packed for it WF_U_SCALE = -ln 2 (the conv is

@@ -148,6 +148,7 @@ struct kd_unet {
   size_t ws_bytes = 0;
   int64_t macs = 0;       // algorithmic MACs of one forward as the reference computes it
   int64_t mfma_macs = 0;  // MACs the per-step conv / GEMM launches issue on the matrix cores
+  int64_t mfma_bf16_macs = 0;  // ... bf16 MACs of the bf16x3 GEMMs (six per fp32 MAC; not part of mfma_macs)
   int time_cond_dim = 0;
   // per-call I/O (read by the ops at run time)
   const float *in_x = nullptr, *in_lowres = nullptr, *in_cond = nullptr, *in_log_snr = nullptr,
@@ -880,7 +881,9 @@ struct Builder {
     float* U = cached("wino4:" + conv_prefix, (size_t)36 * Cout * Cin,
                       [&](float* dst) { KD_THROW_IF(launch_wino4_pack(wsrc, dst, Cout, Cin, 0)); });
     emit_gn_stats(x, gamma, beta, ss_col, nullptr);
-    T V = alloc(1, 1, (int)(36 * Mt), Cin);
+    // the 36 GEMMs as fp32-class products on the bf16 matrix pipe (kernels_gemm_bf16x3.hip) where the shape fits its tile
+    const bool x3 = cfg.gemm_bf16x3 >= 0 && !to_text && !to_static && gemm_bf16x3_ok(36, Mt, Cout, Cin);
+    T V = x3 ? alloc_bytes((size_t)36 * Mt * Cin * 6) : alloc(1, 1, (int)(36 * Mt), Cin);
     T D = alloc(1, 1, (int)(36 * Mt), Cout);
     T y = alloc(Bx, H, W, Cout);
     const std::string shape = " M" + std::to_string((int64_t)Bx * HW) + " Cin" + std::to_string(Cin) + " Cout" +
@@ -891,16 +894,29 @@ struct Builder {
       const int ld = tmlp_total, ldx = x.LD();
       emit([=](hipStream_t s) {
         const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
+        if (x3) return launch_wino4_in3(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s);
         return launch_wino4_in(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s);
       }, "wino4_in" + shape);
     }
-    ConvOpt o;
-    o.wz_rows = (int)Mt;
-    o.wz_count = 36;
-    o.dst = &D;
-    o.macs_override = (int64_t)Bx * HW * Cout * Cin * 9;   // the algorithmic MACs of the 3x3 conv it replaces
-    conv(V, U, nullptr, Cout, 1, 1, 0, o);
-    if (!to_text && !to_static) u->op_label.back() = "wino4 gemm" + shape;
+    if (x3) {
+      const float* U3 = cached("wino4x3:" + conv_prefix, ((size_t)36 * Cout * Cin * 3 + 1) / 2,
+                               [&](float* dst) { KD_THROW_IF(launch_split3(U, dst, 36, Cout, Cin, 0)); });
+      const size_t vo = V.off, d_o = D.off;
+      const int64_t macs = (int64_t)Bx * HW * Cout * Cin * 9;   // the algorithmic MACs of the 3x3 conv it replaces
+      emit([=](hipStream_t s) { return launch_gemm_bf16x3(uu->P(vo), U3, uu->P(d_o), 36, (int)Mt, Cout, Cin, s); },
+           "wino4 gemm bf16x3" + shape, macs);
+      u->macs += macs;
+      u->op_mfma.back() = 6 * 36 * Mt * Cout * Cin;   // bf16 MACs
+      u->mfma_bf16_macs += u->op_mfma.back();
+    } else {
+      ConvOpt o;
+      o.wz_rows = (int)Mt;
+      o.wz_count = 36;
+      o.dst = &D;
+      o.macs_override = (int64_t)Bx * HW * Cout * Cin * 9;   // the algorithmic MACs of the 3x3 conv it replaces
+      conv(V, U, nullptr, Cout, 1, 1, 0, o);
+      if (!to_text && !to_static) u->op_label.back() = "wino4 gemm" + shape;
+    }
     {
       const bool sg = seg_on && Cout % 64 == 0;   // GroupNorm partials of y for whichever layer normalises it next
       const size_t sgo = sg ? add_seg(y, 0, Cout / 16, (H / 4) * (W / 4)) : 0;

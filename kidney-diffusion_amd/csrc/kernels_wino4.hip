@@ -11,6 +11,8 @@
 //
 //   wino4_pack (plan build)  OIHW weights            -> U [36][Cout][Cin]
 //   wino4_in   (per step)    GroupNorm+FiLM+SiLU(x)  -> V [36][Mt][Cin]     (the normalised map is never written)
+//   wino4_in3  (per step)    the same, V as three bf16 planes [3][36][Cin/16][Mt][16] for the bf16x3 GEMM
+//                            (kernels_gemm_bf16x3.hip: fp32-class products on the bf16 matrix pipe)
 //   wino4_out  (per step)    D [36][Mt][Cout]        -> y NHWC + bias (+ residual), and the GroupNorm partial sums of y
 //                                                       for the layer that normalises it next (SegSrc, common.h)
 //
@@ -93,16 +95,29 @@ int launch_wino4_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s
 }
 
 // One thread: one 6x6 input tile x TWO channels (8-byte accesses); threads run along the channels (a wave reads / writes
-// 512 contiguous bytes)
+// 512 contiguous bytes).
+// PLANES: V as the three bf16 planes of the bf16x3 GEMM (kernels_gemm_bf16x3.hip), [3][36][C/16][nt][16]: a wave = 8
+// consecutive tiles x the 16 channels of one k-chunk (it writes 256 consecutive bytes per position and plane, and reads
+// 64 bytes per pixel and tile - the four waves of a workgroup take four consecutive chunks, 256 bytes per pixel)
+template <bool PLANES>
 __global__ __launch_bounds__(256) void wino4_in_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ scale_shift, int ld_ss,
                                                        float* __restrict__ V, int B, int H, int W, int C, int G, int64_t nt) {
   const int Ht = H >> 2, Wt = W >> 2, C2 = C >> 1;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nt * C2) return;
-  const int c = (int)(idx % C2) * 2;
-  const int64_t t = idx / C2;
+  if (idx >= nt * C2) return;   // (PLANES: whole waves, nt % 8 == 0 and C % 16 == 0)
+  int c;
+  int64_t t;
+  if (PLANES) {
+    const int64_t w = idx >> 6;
+    const int lane = (int)(idx & 63), nkc = C / X3_BK;
+    c = (int)(w % nkc) * X3_BK + (lane & 7) * 2;
+    t = (w / nkc) * 8 + (lane >> 3);
+  } else {
+    c = (int)(idx % C2) * 2;
+    t = idx / C2;
+  }
   const int tx = (int)(t % Wt);
   const int ty = (int)((t / Wt) % Ht);
   const int b = (int)(t / ((int64_t)Wt * Ht));
@@ -148,6 +163,26 @@ __global__ __launch_bounds__(256) void wino4_in_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 6; ++r) u[r][s] = tcol[r];
   }
+  if (PLANES) {
+    // dword (two bf16) units: position stride nt C / 2, plane stride 36 of them
+    const int64_t pstride = nt * C2, plane = 36 * pstride;
+    uint32_t* out = (uint32_t*)V + ((int64_t)(c / X3_BK) * nt + t) * (X3_BK / 2) + (c % X3_BK) / 2;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      f32x2 trow[6];
+      w4_bt(u[r], trow);
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        uint32_t h, m, l;
+        x3_split(trow[s], h, m, l);
+        uint32_t* o = out + (int64_t)(r * 6 + s) * pstride;
+        o[0] = h;
+        o[plane] = m;
+        o[2 * plane] = l;
+      }
+    }
+    return;
+  }
   float* out = V + t * C + c;
   const int64_t pstride = nt * C;
 #pragma unroll
@@ -167,8 +202,20 @@ int launch_wino4_in(const float* x, int ldx, const float* stats, const float* ga
   KD_REQUIRE(H % 4 == 0 && W % 4 == 0 && ldx >= C && C % 2 == 0 && ldx % 2 == 0 && ((uintptr_t)x & 7) == 0,
              "Winograd F(4x4,3x3) input transform needs H % 4 == 0, W % 4 == 0 and even C / row stride");
   const int64_t nt = (int64_t)B * (H / 4) * (W / 4), total = nt * (C / 2);
-  hipLaunchKernelGGL(wino4_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, stats, gamma, beta,
-                     scale_shift, ld_ss, V, B, H, W, C, G, nt);
+  hipLaunchKernelGGL(wino4_in_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, stats, gamma,
+                     beta, scale_shift, ld_ss, V, B, H, W, C, G, nt);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_wino4_in3(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
+                     const float* scale_shift, int ld_ss, void* V3, int B, int H, int W, int C, int G, hipStream_t s) {
+  const int64_t nt = (int64_t)B * (H / 4) * (W / 4), total = nt * (C / 2);
+  KD_REQUIRE(H % 4 == 0 && W % 4 == 0 && ldx >= C && C % X3_BK == 0 && ldx % 2 == 0 && ((uintptr_t)x & 7) == 0 && nt % 8 == 0 &&
+                 ((uintptr_t)V3 & 3) == 0,
+             "Winograd F(4x4,3x3) input transform to bf16x3 planes needs H % 4 == 0, W % 4 == 0, C % 16 == 0, tiles % 8 == 0");
+  hipLaunchKernelGGL(wino4_in_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, stats, gamma, beta,
+                     scale_shift, ld_ss, (float*)V3, B, H, W, C, G, nt);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

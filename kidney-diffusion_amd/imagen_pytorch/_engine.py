@@ -54,6 +54,7 @@ class kd_unet_config_t(C.Structure):
         ("mid_attn_plain", C.c_int),
         ("wino_slice_mb", C.c_int),
         ("wino43_min_cin", C.c_int),
+        ("gemm_bf16x3", C.c_int),
     ]
 
 
@@ -110,6 +111,7 @@ SIGNATURES = {
     "kd_unet_weight_bytes": (C.c_int64, [C.c_void_p]),
     "kd_unet_macs": (C.c_int64, [C.c_void_p]),
     "kd_unet_mfma_macs": (C.c_int64, [C.c_void_p]),
+    "kd_unet_mfma_bf16_macs": (C.c_int64, [C.c_void_p]),
     "kd_unet_num_launches": (C.c_int, [C.c_void_p]),
     "kd_unet_num_cond_launches": (C.c_int, [C.c_void_p]),
     "kd_unet_cond_table_build_ms": (C.c_float, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -127,7 +129,8 @@ SIGNATURES = {
     "kd_sample_last": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "kd_conv2d_nhwc": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]),
     "kd_conv3x3_winograd_nhwc": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
-    "kd_conv3x3_winograd4_nhwc": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_void_p]),
+    "kd_conv3x3_winograd4_nhwc": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "kd_gemm_bf16x3": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "kd_gn_conv3x3_winograd_fused_nhwc": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "kd_init_conv_nchw": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
     "kd_groupnorm_silu_nhwc": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),

@@ -13,7 +13,7 @@ import torch
 
 here = os.path.dirname(os.path.abspath(__file__))
 lib = ctypes.CDLL(os.path.join(here, "libbf16x3.so"))
-lib.bf16x3_split.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+lib.bf16x3_split.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 lib.bf16x3_gemm.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
 
 
@@ -40,14 +40,14 @@ def main():
         g = torch.Generator(device=dev).manual_seed(1)
         A = torch.randn(G, M, K, device=dev, generator=g)
         B = torch.randn(G, N, K, device=dev, generator=g) * 0.05
-        A3 = torch.empty(3, G, M, K, device=dev, dtype=torch.int16)
-        B3 = torch.empty(3, G, N, K, device=dev, dtype=torch.int16)
+        A3 = torch.empty(3, G, K // 16, M, 16, device=dev, dtype=torch.int16)   # k-chunk-major planes
+        B3 = torch.empty(3, G, K // 16, N, 16, device=dev, dtype=torch.int16)
         C = torch.empty(G, M, N, device=dev)
-        assert lib.bf16x3_split(A.data_ptr(), A3.data_ptr(), A.numel(), stream) == 0
-        assert lib.bf16x3_split(B.data_ptr(), B3.data_ptr(), B.numel(), stream) == 0
+        assert lib.bf16x3_split(A.data_ptr(), A3.data_ptr(), G, M, K, stream) == 0
+        assert lib.bf16x3_split(B.data_ptr(), B3.data_ptr(), G, N, K, stream) == 0
         torch.cuda.synchronize()
         # the three planes add back to the fp32 value exactly (or to within the last bit of a denormal tail)
-        rec = sum(p.view(torch.bfloat16).double() for p in A3)
+        rec = sum(p.view(torch.bfloat16).double() for p in A3).permute(0, 2, 1, 3).reshape(G, M, K)
         print(f"G{G} M{M} N{N} K{K}: split residual {float((rec - A.double()).abs().max()):.2e}", flush=True)
         del rec
         # exact reference on a slice (fp64 on the whole thing is slow and large)
@@ -65,13 +65,13 @@ def main():
         Bt = B.transpose(1, 2)
         t = timed(lambda: torch.bmm(A, Bt, out=C))
         report("torch.bmm fp32", t, C)
-        for nprod in (6, 3, 1):
+        for nprod in (6, 3, 1, 16, 13, 11):   # 1x: four loader waves issue the DMAs
             C.zero_()
             rc = lib.bf16x3_gemm(A3.data_ptr(), B3.data_ptr(), C.data_ptr(), G, M, N, K, nprod, stream)
             assert rc == 0, rc
             t = timed(lambda: lib.bf16x3_gemm(A3.data_ptr(), B3.data_ptr(), C.data_ptr(), G, M, N, K, nprod, stream))
-            report(f"bf16x3 n={nprod}", t, C)
-        t = timed(lambda: lib.bf16x3_split(A.data_ptr(), A3.data_ptr(), A.numel(), stream))
+            report(f"bf16x3 n={nprod % 10}" + (" +loaders" if nprod > 10 else ""), t, C)
+        t = timed(lambda: lib.bf16x3_split(A.data_ptr(), A3.data_ptr(), G, M, K, stream))
         print(f"  split of A     {t:8.3f} ms  ({A.numel() * 10 / t / 1e6:.0f} GB/s)", flush=True)
         del A, B, A3, B3, C
 

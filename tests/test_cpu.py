@@ -351,7 +351,7 @@ def test_library_loads_and_exports_every_symbol_the_header_declares():
         assert hasattr(lib, sym), f"libkd_engine.so does not export {sym}"
     assert set(E.SIGNATURES) == declared, "ctypes table and header disagree"
     assert lib.kd_version() == 1
-    assert C.sizeof(E.kd_unet_config_t) == 4 * (2 + 4 * E.KD_MAX_LEVELS + 24)  # ints only, header order
+    assert C.sizeof(E.kd_unet_config_t) == 4 * (2 + 4 * E.KD_MAX_LEVELS + 25)  # ints only, header order
     assert lib.kd_quantile_workspace_bytes(4) == 4 * 16 + 4 * 4 * 256 * 4
 
 
@@ -472,7 +472,7 @@ def test_kernels_with_counted_vmcnt_waits_use_no_scratch(tmp_path):
     if not Path(hipcc).exists():
         pytest.skip("hipcc not available")
     csrc = ROOT / "kidney-diffusion_amd" / "csrc"
-    srcs = ("kernels_conv.hip", "kernels_wino_fused128.hip", "kernels_init.hip")
+    srcs = ("kernels_conv.hip", "kernels_wino_fused128.hip", "kernels_init.hip", "kernels_gemm_bf16x3.hip")
 
     def compile_one(src):
         return subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", str(csrc / src),

@@ -173,18 +173,29 @@ def test_conv3x3_winograd_matches_direct(lib, device, B, H, W, Cin, Cout):
 WINO4_REL = 8e-6
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,res,stats", [
-    (16, 16, 16, 1024, 1024, False, True),   # the SR UNet's deepest level at the benchmark's batch: Mt = 256
-    (16, 32, 32, 512, 512, True, True),      # its 32x32 level, residual in the output transform
-    (4, 32, 32, 64, 192, True, False),       # Mt = 256 over four images, three 64-channel blocks
-    (1, 64, 64, 32, 64, False, True),        # one image, Mt = 256, short K
-    (16, 16, 16, 2048, 128, False, True),    # the concat convs' K
-    (8, 16, 16, 512, 256, True, True),       # Mt = 128: one 128-row tile per weight slab (batch 8 at the 16x16 level)
-    (16, 16, 16, 768, 768, True, True),      # configs[1] (train.py:30-39, dim_mults 1,2,3,4) at batch 16: the 16x16 up level,
-    (16, 16, 16, 1280, 768, False, True),    # ... its concat conv (768 + 512 skip channels), twelve 64-channel blocks
-    (16, 16, 16, 1536, 768, False, False),   # K = 1536 (48 chunks of 32)
+# x3: the 36 position GEMMs on the bf16 matrix pipe (three bf16 pieces per fp32 operand, six exact products per k-step,
+# fp32 accumulation - kernels_gemm_bf16x3.hip), the plan's default where tiles % 256 == 0 and Cout % 128 == 0: held to the
+# SAME bounds as the fp32 MFMA GEMMs
+@pytest.mark.parametrize("B,H,W,Cin,Cout,res,stats,x3", [
+    (16, 16, 16, 1024, 1024, False, True, 0),   # the SR UNet's deepest level at the benchmark's batch: Mt = 256
+    (16, 16, 16, 1024, 1024, False, True, 1),
+    (16, 32, 32, 512, 512, True, True, 0),      # its 32x32 level, residual in the output transform
+    (16, 32, 32, 512, 512, True, True, 1),
+    (4, 32, 32, 64, 192, True, False, 0),       # Mt = 256 over four images, three 64-channel blocks
+    (1, 64, 64, 32, 64, False, True, 0),        # one image, Mt = 256, short K
+    (16, 16, 16, 2048, 128, False, True, 0),    # the concat convs' K
+    (16, 16, 16, 2048, 128, False, True, 1),    # ... one 128-column tile, 128 k-stages
+    (8, 16, 16, 512, 256, True, True, 0),       # Mt = 128: one 128-row tile per weight slab (batch 8 at the 16x16 level)
+    (16, 16, 16, 768, 768, True, True, 0),      # configs[1] (train.py:30-39, dim_mults 1,2,3,4) at batch 16: the 16x16 up level,
+    (16, 16, 16, 768, 768, True, True, 1),
+    (16, 16, 16, 1280, 768, False, True, 0),    # ... its concat conv (768 + 512 skip channels), twelve 64-channel blocks
+    (16, 16, 16, 1280, 768, False, True, 1),
+    (16, 16, 16, 1536, 768, False, False, 0),   # K = 1536 (48 chunks of 32)
+    (4, 32, 32, 32, 128, True, True, 1),        # the shortest K the bf16x3 kernel takes: two stages (its ring holds four)
+    (4, 32, 32, 64, 256, False, True, 1),       # four stages
+    (16, 64, 64, 512, 256, True, True, 1),      # Mt = 4096: sixteen 256-row tiles per position, 1152 workgroups
 ])
-def test_conv3x3_winograd4_matches_direct(lib, device, B, H, W, Cin, Cout, res, stats):
+def test_conv3x3_winograd4_matches_direct(lib, device, B, H, W, Cin, Cout, res, stats, x3):
     E = _E()
     h = torch.randn(B, Cin, H, W, generator=g(1)) * 1.2 + 0.2
     x = F.silu(h)                       # what these layers see: an activated, normalised map
@@ -203,12 +214,12 @@ def test_conv3x3_winograd4_matches_direct(lib, device, B, H, W, Cin, Cout, res, 
     ostats = torch.full((B, G, 2), float("nan"), device=device)
     call = lambda out: E.check(lib.kd_conv3x3_winograd4_nhwc(
         E.ptr(xd), E.ptr(wd), E.ptr(bd), E.ptr(rd) if res else None, E.ptr(out), B, H, W, Cin, Cout, G, 1e-5,
-        E.ptr(ostats) if want_stats else None, E.current_stream()))
+        E.ptr(ostats) if want_stats else None, x3, E.current_stream()))
     call(y)
     got = y.permute(0, 3, 1, 2).cpu().double()
     assert torch.isfinite(got).all()
     err = float((got - ref).norm() / ref.norm())
-    print(f"F(4x4,3x3) Cin {Cin} {H}x{W}: rel-L2 {err:.2e}, max {float((got - ref).abs().max() / ref.abs().max()):.2e}")
+    print(f"F(4x4,3x3){' bf16x3' if x3 else ''} Cin {Cin} {H}x{W}: rel-L2 {err:.2e}, max {float((got - ref).abs().max() / ref.abs().max()):.2e}")
     assert err <= WINO4_REL, err
     assert float((got - ref).abs().max()) <= 5e-5 * float(ref.abs().max()), "element-wise outlier"
     if want_stats:
@@ -225,8 +236,52 @@ def test_conv3x3_winograd4_rejects_unsupported_shapes(lib, device):
     E = _E()
     t = torch.zeros(16, device=device)
     for shape in [(1, 18, 16, 32, 64), (1, 16, 16, 32, 64), (16, 16, 16, 48, 64), (16, 16, 16, 32, 96)]:
-        rc = lib.kd_conv3x3_winograd4_nhwc(E.ptr(t), E.ptr(t), None, None, E.ptr(t), *shape, 8, 1e-5, None, E.current_stream())
+        rc = lib.kd_conv3x3_winograd4_nhwc(E.ptr(t), E.ptr(t), None, None, E.ptr(t), *shape, 8, 1e-5, None, 0, E.current_stream())
         assert rc != 0 and b"F(4x4,3x3)" in lib.kd_last_error()
+    # shapes the fp32 path takes and the bf16x3 GEMM's tile does not: refused, not silently computed another way
+    for shape in [(8, 16, 16, 512, 256), (16, 16, 16, 512, 192)]:
+        rc = lib.kd_conv3x3_winograd4_nhwc(E.ptr(t), E.ptr(t), None, None, E.ptr(t), *shape, 8, 1e-5, None, 1, E.current_stream())
+        assert rc != 0 and b"bf16x3" in lib.kd_last_error()
+
+
+# The GEMM by itself against fp64, next to torch's fp32 product of the same operands: the six-product bf16 form is held
+# to the fp32 product's error (it measures at or below it), element-wise and in the norm.
+@pytest.mark.parametrize("G,M,N,K,scale_b", [
+    (36, 256, 128, 32, 1.0),       # one tile per position, two k-stages
+    (3, 512, 256, 96, 0.05),       # six stages (the ring wraps), 2 x 2 tiles
+    (36, 1024, 512, 512, 0.05),    # the 32x32 level's GEMMs at batch 16
+    (2, 256, 128, 4096, 1e-3),     # a long accumulation
+    (5, 256, 384, 64, 30.0),       # a grid that is not a multiple of 8 (identity workgroup order)
+])
+def test_gemm_bf16x3_matches_fp64(lib, device, G, M, N, K, scale_b):
+    E = _E()
+    a = (torch.randn(G, M, K, generator=g(5)) * torch.logspace(-3, 3, K)).to(device)   # 6 decades along k
+    b = (torch.randn(G, N, K, generator=g(6)) * scale_b).to(device)
+    a[0, 0, :4] = torch.tensor([0.0, -0.0, 1e-30, 1e30], device=device)   # zeros, a tiny and a huge value
+    c = torch.full((G, M, N), float("nan"), device=device)
+    E.check(lib.kd_gemm_bf16x3(E.ptr(a), E.ptr(b), E.ptr(c), G, M, N, K, E.current_stream()))
+    ref = torch.bmm(a.double(), b.double().transpose(1, 2))
+    f32 = torch.bmm(a, b.transpose(1, 2)).double()
+    assert torch.isfinite(c).all()
+    bound = torch.bmm(a.double().abs(), b.double().abs().transpose(1, 2))   # sum_k |a| |b|: what the errors scale with
+    e_x3 = ((c.double() - ref).abs() / bound.clamp_min(1e-300))
+    e_32 = ((f32 - ref).abs() / bound.clamp_min(1e-300))
+    print(f"bf16x3 G{G} M{M} N{N} K{K}: max err / sum|a||b| {float(e_x3.max()):.2e} (fp32 bmm {float(e_32.max()):.2e}), "
+          f"rms {float(e_x3.pow(2).mean().sqrt()):.2e} (fp32 {float(e_32.pow(2).mean().sqrt()):.2e})")
+    assert float(e_x3.max()) <= max(2.0 * float(e_32.max()), 2.0 ** -23), float(e_x3.max())
+    rms = lambda e: float(e.pow(2).mean().sqrt())   # (per element, relative to its own sum |a| |b|: one huge row does not decide it)
+    assert rms(e_x3) <= max(1.25 * rms(e_32), 2.0 ** -25), (rms(e_x3), rms(e_32))   # 2^-25: half an fp32 ulp of sum |a| |b|
+    c2 = torch.empty_like(c)
+    E.check(lib.kd_gemm_bf16x3(E.ptr(a), E.ptr(b), E.ptr(c2), G, M, N, K, E.current_stream()))
+    assert torch.equal(c, c2)
+
+
+def test_gemm_bf16x3_rejects_unsupported_shapes(lib, device):
+    E = _E()
+    t = torch.zeros(16, device=device)
+    for shape in [(1, 128, 128, 32), (1, 256, 64, 32), (1, 256, 128, 16), (36, 4096 * 8, 128, 2048)]:
+        rc = lib.kd_gemm_bf16x3(E.ptr(t), E.ptr(t), E.ptr(t), *shape, E.current_stream())
+        assert rc != 0 and b"bf16x3" in lib.kd_last_error()
 
 
 def test_conv3x3_winograd_rejects_unsupported_shapes(lib, device):
