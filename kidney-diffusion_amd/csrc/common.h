@@ -140,7 +140,10 @@ __device__ __forceinline__ void x3_split(const float __attribute__((ext_vector_t
 }
 bool gemm_bf16x3_ok(int G, int64_t M, int N, int K);   // M % 256 == 0, N % 128 == 0, K % 32 == 0, planes < 4 GB
 int launch_split3(const float* x, void* planes, int G, int R, int K, hipStream_t s);   // x [G][R][K] -> 3 G R K bf16
-int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, int N, int K, hipStream_t s);
+// ws: gemm_bf16x3_workspace_bytes() bytes (slabs and arrival words of the stream-K hand-offs), zeroed once when allocated;
+// one per stream of launches
+size_t gemm_bf16x3_workspace_bytes();
+int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, int N, int K, void* ws, hipStream_t s);
 // launch_wino4_in writing V as the three planes the bf16x3 GEMM reads ([3][36][C/16][Mt][16] bf16; Mt % 8 == 0, C % 16 == 0)
 int launch_wino4_in3(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
                      const float* scale_shift, int ld_ss, void* V3, int B, int H, int W, int C, int G, hipStream_t s);

@@ -200,13 +200,14 @@ struct kd_unet {
   std::vector<char> cond_tab_row_ok;   // [T]: rows are built on demand, for the steps a call walks
   float cond_tab_build_ms = -1.f;    // device time and row count of the last build (kd_unet_cond_table_build_ms)
   int cond_tab_build_rows = 0, cond_tab_build_runs = 0;
+  void* x3_ws = nullptr;   // workspace of the bf16x3 GEMMs' hand-offs (launch_gemm_bf16x3), allocated with the first such layer
 
   float* P(size_t off) const { return (float*)((off & COND_FLAG) ? cond_ws + (off & ~COND_FLAG) : ws + off); }
   ~kd_unet() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
     void* frees[] = {ws, s_pred, s_x0, s_thresh, s_time, s_tables, s_iter, s_seed, s_qws, s_pred_null, cond_ws, cond_tab,
-                     d_cond_segs};
+                     d_cond_segs, x3_ws};
     for (void* p : frees)
       if (p) (void)hipFree(p);
     if (s_tables_pinned) (void)hipHostFree(s_tables_pinned);
@@ -903,7 +904,11 @@ struct Builder {
                                [&](float* dst) { KD_THROW_IF(launch_split3(U, dst, 36, Cout, Cin, 0)); });
       const size_t vo = V.off, d_o = D.off;
       const int64_t macs = (int64_t)Bx * HW * Cout * Cin * 9;   // the algorithmic MACs of the 3x3 conv it replaces
-      emit([=](hipStream_t s) { return launch_gemm_bf16x3(uu->P(vo), U3, uu->P(d_o), 36, (int)Mt, Cout, Cin, s); },
+      if (!u->x3_ws) {
+        KD_HIP_THROW(hipMalloc(&u->x3_ws, gemm_bf16x3_workspace_bytes()));
+        KD_HIP_THROW(hipMemset(u->x3_ws, 0, gemm_bf16x3_workspace_bytes()));
+      }
+      emit([=](hipStream_t s) { return launch_gemm_bf16x3(uu->P(vo), U3, uu->P(d_o), 36, (int)Mt, Cout, Cin, uu->x3_ws, s); },
            "wino4 gemm bf16x3" + shape, macs);
       u->macs += macs;
       u->op_mfma.back() = 6 * 36 * Mt * Cout * Cin;   // bf16 MACs

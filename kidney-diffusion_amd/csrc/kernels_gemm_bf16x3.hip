@@ -92,19 +92,47 @@ int launch_split3(const float* x, void* planes, int G, int R, int K, hipStream_t
   return 0;
 }
 
-// A3 [3][G][K/16][M][16], B3 [3][G][K/16][N][16] bf16; C [G][M][N] fp32.  Grid: 1-D, (M / 256) (N / 128) G workgroups of 768
+// A3 [3][G][K/16][M][16], B3 [3][G][K/16][N][16] bf16; C [G][M][N] fp32.
+//
+// Persistent: P = min(tiles, CUs) workgroups.  Workgroup q (the q-th of its XCD's contiguous eighth, see below) computes
+// tiles q, q + P, q + 2 P, ... of the (g, M tile, N tile) order - whole rounds, in which the workgroups that share an
+// operand tile walk k in step and a k-chunk crosses the fabric into the XCD's L2 once.  (Contiguous stream-K runs were
+// measured first and lost 40-60 % per stage: neighbouring workgroups sit 1/8 tile apart in k, the reuse distance of a
+// chunk outgrows the 4 MB of L2.)  The R = tiles mod P tiles left over are cut in k into S = min(8, P / R, K / 128) parts,
+// one per workgroup q < S R: without that the 288 tiles of the 16 x 16 level's GEMMs take two rounds on 256 CUs for 1.125
+// rounds of work.  The parts of a tile meet without waiting for one another (two launches on different streams may
+// share the chip; a workgroup waiting for one that is not resident could wait for ever): every part publishes its
+// accumulators in a slab (plain stores, every wave's vmcnt(0), barrier, one agent-scope release) and draws a ticket from
+// the tile's counter (relaxed agent-scope add); the part that draws the last one takes the slabs (one agent-scope
+// acquire, barrier, plain loads), adds them IN PART ORDER, its own included, and stores the tile - the result does not
+// depend on who came last - and zeroes the counter for the next launch (launches are ordered on the stream).
+// The LDS ring does not drain between tiles: the loaders run up to three stages into the next tile while the computing
+// waves store the last one.
+struct X3Yes { static constexpr bool value = true; };
+struct X3No { static constexpr bool value = false; };
+constexpr int X3_FLAG_STRIDE = 32;   // dwords: one 128-byte line per counter
+constexpr int X3_MAX_WG = 512;       // slabs / counters of the workspace
+constexpr int X3_MAX_SPLIT = 8;
+
 __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __restrict__ A3, const uint16_t* __restrict__ B3,
-                                                          float* __restrict__ C, int G, int M, int N, int K) {
-  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE_B];
+                                                          float* __restrict__ C, int G, int M, int N, int K, int S,
+                                                          float* __restrict__ slab, uint32_t* __restrict__ counters) {
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE_B + 64];   // the ring + one word for the hand-off
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mtiles = M / BM, ntiles = N / BN;
-  // XCD x (workgroup ids x, x + 8, ...) takes the x-th eighth of the (g, M tile, N tile) order
-  unsigned n = blockIdx.x;
-  if ((gridDim.x & 7) == 0) n = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int nt = n % ntiles, mt = (n / ntiles) % mtiles, g = n / (ntiles * mtiles);
-  const int m0 = mt * BM, n0 = nt * BN;
   const int nk = K / BK;
+  const int P = gridDim.x;
+  // XCD x (workgroup ids x, x + 8, ...) takes the x-th eighth of every round: neighbours in the tile order share an L2
+  int q = blockIdx.x;
+  if ((P & 7) == 0) q = (blockIdx.x & 7) * (P >> 3) + (blockIdx.x >> 3);
+  const int tiles = mtiles * ntiles * G, rounds = tiles / P, R = tiles - rounds * P;
+  const bool tail = q < S * R;                        // this workgroup has a part of a left-over tile
+  const int part = tail ? q % S : 0;
+  const int tail_k0 = part * nk / S, tail_k1 = (part + 1) * nk / S;
+  const int nseg = rounds + (tail ? 1 : 0);
+  const int T = rounds * nk + (tail ? tail_k1 - tail_k0 : 0);   // stage units of this workgroup
+  auto seg_tile = [&](int sg) __attribute__((always_inline)) { return sg < rounds ? sg * P + q : rounds * P + q / S; };
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
   if (wave >= 8) {
     // loader l moves pieces 9 l .. 9 l + 8 of the 36 of every stage (0..23: A plane id / 8, rows 32 (id % 8); 24..35: B
@@ -112,44 +140,52 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     // LDS (row = lane >> 1, slot = lane & 1), read from source slot (lane & 1) ^ ((row >> 3) & 1) of the same row
     const int l = wave - 8;
     const uint32_t planeA = (uint32_t)((int64_t)G * M * K * 2), planeB = (uint32_t)((int64_t)G * N * K * 2);
-    const uint32_t gA = (uint32_t)((int64_t)g * M * K * 2), gB = (uint32_t)((int64_t)g * N * K * 2);
     const i32x4 rsA = make_rsrc(A3, 3u * planeA), rsB = make_rsrc(B3, 3u * planeB);
     const uint32_t voff = (uint32_t)((lane >> 1) * ROWB + (((lane & 1) ^ ((lane >> 4) & 1)) * 16));
     const uint32_t chunkA = (uint32_t)(M * ROWB), chunkB = (uint32_t)(N * ROWB);
-    auto issue_stage = [&](int kc) {
-      const int st = kc & (NST - 1);
+    // the next unit to fetch: number ic, stage ik of segment iseg (which ends before stage ik1)
+    int ic = 0, iseg = 0, ik = 0, ik1 = 0;
+    uint32_t baseA = 0, baseB = 0;   // byte offsets of the tile's rows of stage 0 in plane 0
+    auto locate = [&]() __attribute__((always_inline)) {
+      const int it = seg_tile(iseg);
+      const int nt = it % ntiles, mt = (it / ntiles) % mtiles, g = it / (ntiles * mtiles);
+      baseA = (uint32_t)((int64_t)g * M * K * 2) + (uint32_t)(mt * BM * ROWB);
+      baseB = (uint32_t)((int64_t)g * N * K * 2) + (uint32_t)(nt * BN * ROWB);
+      ik = iseg < rounds ? 0 : tail_k0;
+      ik1 = iseg < rounds ? nk : tail_k1;
+    };
+    locate();
+    auto issue_next = [&]() __attribute__((always_inline)) {
+      const int st = ic & (NST - 1);
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const int id = l * 9 + q;
+      for (int j = 0; j < 9; ++j) {
+        const int id = l * 9 + j;
         const bool isA = id < 24;
         const int pl = isA ? id >> 3 : (id - 24) >> 2;
         const int pr = isA ? id & 7 : (id - 24) & 3;
         const uint32_t dst = lds0 + (uint32_t)(st * STAGE_B + (isA ? 0 : B_OFF) + (pl * (isA ? BM : BN) + pr * 32) * ROWB);
-        const uint32_t soff = isA ? (uint32_t)pl * planeA + gA + (uint32_t)kc * chunkA + (uint32_t)((m0 + pr * 32) * ROWB)
-                                  : (uint32_t)pl * planeB + gB + (uint32_t)kc * chunkB + (uint32_t)((n0 + pr * 32) * ROWB);
+        const uint32_t soff = isA ? (uint32_t)pl * planeA + baseA + (uint32_t)ik * chunkA + (uint32_t)(pr * 32 * ROWB)
+                                  : (uint32_t)pl * planeB + baseB + (uint32_t)ik * chunkB + (uint32_t)(pr * 32 * ROWB);
         dma16(isA ? rsA : rsB, dst, voff, soff);
       }
+      ++ic;
+      if (++ik == ik1 && ++iseg < nseg) locate();
     };
-    issue_stage(0);
-    if (nk > 1) issue_stage(1);
-    if (nk > 2) issue_stage(2);
-    if (nk > 2) wait_vm<18>(); else if (nk > 1) wait_vm<9>(); else wait_vm<0>();
+    for (int j = 0; j < 3 && ic < T; ++j) issue_next();
+    if (T > 2) wait_vm<18>(); else if (T > 1) wait_vm<9>(); else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    for (int kc = 0; kc < nk; ++kc) {   // the barriers of the computing waves' stages
-      if (kc + 2 < nk) wait_vm<9>(); else wait_vm<0>();   // stage kc + 1 landed (stage kc + 2 may be in flight)
+    for (int c = 0; c < T; ++c) {   // the barriers of the computing waves' stages, one for one
+      if (c + 2 < T) wait_vm<9>(); else wait_vm<0>();   // unit c + 1 landed (unit c + 2 may be in flight)
       __builtin_amdgcn_s_barrier();
-      if (kc + 3 < nk) issue_stage(kc + 3);   // into the buffer of stage kc - 1, whose fragments were read before stage kc - 1 ran
+      if (ic < T) issue_next();   // into the buffer of unit c - 1, whose fragments were read before unit c ran
     }
+    if (tail && S > 1)   // the hand-off's barriers
+      for (int j = 0; j < 3; ++j) __builtin_amdgcn_s_barrier();
     return;
   }
   const int wm = wave >> 1, wn = wave & 1;            // 4 x 2 waves of 64 x 64
+  // (never zeroed: the first MFMAs of a segment take a zero C operand instead)
   f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int fr = lane & 31, fh = lane >> 5;
   const int fslot = (fh ^ ((fr >> 3) & 1)) * 16;
   const char* fa = lds + (wm * 64 + fr) * ROWB + fslot;           // + stage, plane, 32-row block
@@ -157,67 +193,232 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
   struct Frags {
     bf16x8 a[3][2], b[3][2];
   };
-  auto read_frags = [&](Frags& f, int kc) {
-    const int so = (kc & (NST - 1)) * STAGE_B;
+  auto read_a = [&](Frags& f, int c, int p) __attribute__((always_inline)) {
+    const int so = (c & (NST - 1)) * STAGE_B;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int i = 0; i < 2; ++i) f.a[p][i] = *(const bf16x8*)(fa + so + p * BM * ROWB + i * 32 * ROWB);
+  };
+  auto read_b = [&](Frags& f, int c, int p) __attribute__((always_inline)) {
+    const int so = (c & (NST - 1)) * STAGE_B;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        f.a[p][i] = *(const bf16x8*)(fa + so + p * BM * ROWB + i * 32 * ROWB);
-        f.b[p][i] = *(const bf16x8*)(fb + so + p * BN * ROWB + i * 32 * ROWB);
+    for (int i = 0; i < 2; ++i) f.b[p][i] = *(const bf16x8*)(fb + so + p * BN * ROWB + i * 32 * ROWB);
+  };
+  // accumulators <-> slab: registers (i, j, 4 r4 .. 4 r4 + 3) of every lane side by side (1 KB rows per wave); slab q is
+  // workgroup q's.  Buffer accesses, the lane's part in one VGPR and the rest in the scalar offset: no per-store address
+  // registers (64-bit addresses of sixty-four stores get hoisted out of the stage loop and spilled)
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsS =
+      __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, (int)((size_t)X3_MAX_WG * BM * BN * sizeof(float)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)((int64_t)G * M * N * 4), 0x00020000);
+  // the lane's part of the offsets, recomputed where it is used (from an opaque copy of the lane id: two registers less
+  // held across the stage loop)
+  auto lane_offsets = [&](int& vS, int& vC) __attribute__((always_inline)) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    vS = (wave * 64 + ln) * 16;
+    vC = ((wm * 64 + 4 * (ln >> 5)) * N + wn * 64 + (ln & 31)) * 4;
+  };
+  auto put_slab = [&](int which) __attribute__((always_inline)) {
+    int vS, vC;
+    lane_offsets(vS, vC);
+    int s0 = which * (BM * BN * 4);
+    asm volatile("" : "+s"(s0));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const u32x4 v = {__float_as_uint(acc[i][j][4 * r4]), __float_as_uint(acc[i][j][4 * r4 + 1]),
+                           __float_as_uint(acc[i][j][4 * r4 + 2]), __float_as_uint(acc[i][j][4 * r4 + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsS, vS, s0 + ((i * 2 + j) * 4 + r4) * (512 * 16), 0);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  // C/D layout of 32x32 tiles: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+  // nparts = 0: the tile = the accumulators; nparts > 0: the tile = slab[first] + slab[first + 1] + ... in that order
+  auto store_tile = [&](int tile, int first, int nparts) __attribute__((always_inline)) {
+    int vS, vC;
+    lane_offsets(vS, vC);
+    const int nt = tile % ntiles, mt = (tile / ntiles) % mtiles, g = tile / (ntiles * mtiles);
+    int Nv = N, w0 = first * (BM * BN * 4);
+    asm volatile("" : "+s"(Nv), "+s"(w0));   // (opaque: the scalar offsets below are not to be hoisted out of the loop)
+    const int s0 = ((g * M + mt * BM) * Nv + nt * BN) * 4;   // (G M N floats < 2^29: gemm_bf16x3_ok)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          float o[4];
+          if (nparts > 0) {
+            u32x4 v[X3_MAX_SPLIT];
+#pragma unroll
+            for (int pt = 0; pt < X3_MAX_SPLIT; ++pt)
+              if (pt < nparts)
+                v[pt] = __builtin_amdgcn_raw_buffer_load_b128(rsS, vS, w0 + pt * (BM * BN * 4) + ((i * 2 + j) * 4 + r4) * (512 * 16), 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o[e] = __uint_as_float(v[0][e]);
+#pragma unroll
+              for (int pt = 1; pt < X3_MAX_SPLIT; ++pt)
+                if (pt < nparts) o[e] += __uint_as_float(v[pt][e]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * r4 + e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * r4 + e;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[e]), rsC, vC, s0 + ((i * 32 + (r & 3) + 8 * (r >> 2)) * Nv + j * 32) * 4, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
   };
-  // one stage: barrier (stage kc + 1 landed, the loaders may refill the buffer of stage kc - 1), fragments of stage
-  // kc + 1 into `nxt`, the MFMAs of stage kc on `cur`
-  auto stage = [&](int kc, const Frags& cur, Frags& nxt) {
+  volatile uint32_t* word = (volatile uint32_t*)(lds + NST * STAGE_B);
+  auto hand_barrier = [&]() __attribute__((always_inline)) {   // (the raw barrier does not wait for this wave's LDS store of the word)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};   // am bm, al bh, ah bl, am bh, ah bm, ah bh
+  };
+  // one part of a left-over tile is done: three barriers on every path (the loaders run the same number)
+  auto hand_off = [&](int tile) __attribute__((always_inline)) {
+    uint32_t* cnt = counters + (size_t)(q / S) * X3_FLAG_STRIDE;
+    put_slab(q);
+    hand_barrier();                                   // 1
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *word = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    hand_barrier();                                   // 2
+    const bool last = *word == (uint32_t)(S - 1);     // every part is published: the tile is this workgroup's to finish
+    if (last && tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all S have drawn: zero for the next launch
+    }
+    hand_barrier();                                   // 3
+    if (last) store_tile(tile, q - part, S);
+  };
+  // one stage: barrier (unit c + 1 landed, the loaders may refill the buffer of unit c - 1), the 24 MFMAs of unit c in
+  // the order al bh, am bh, am bm, ah bh, ah bm, ah bl, and the fragments of unit c + 1:
+  //   behind group 0:  al <- c + 1 (in place: the product is done with it);  bl <- c (put off from the last stage - it is
+  //                    used by the last group; nothing is read behind group 5, the wait in front of group 0 would expose
+  //                    it);  ah, bh <- c + 1 into a second pair of registers
+  //   behind group 2:  am <- c + 1 (in place)          behind group 4:  bm <- c + 1 (in place)
+  //   behind group 5:  the second pair moves into ah, bh (sixteen register moves under the last MFMAs)
+  // so every operand read in place has at least three groups of MFMAs between its read and its next use, and the two
+  // operands every group needs - the high pieces - a whole stage.  (A second set for all six operands, 48 registers more,
+  // does not fit the 168 of a lane at three waves per SIMD once the loop carries the schedule's state; with all six read
+  // in place - two groups of slack on ah and bh - a stage took 1.5 x the time.)
+  // Reads past the last unit fetch a stale ring buffer nobody uses.
+  // FRESH: the first unit of a segment - its first MFMAs take a zero C operand (a separate copy of the stage: a branch
+  // inside it costs a conservative lgkmcnt(0) behind the reads that follow the first group)
+  Frags f;
+  bf16x8 ahn[2], bhn[2];
+  auto stage = [&](int c, auto FRESH) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_barrier();
+    constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 0, 1, 0, 1, 2};
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 6; ++t) {
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[PA[0]][i], f.b[PB[0]][j], decltype(FRESH)::value ? zero : acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(f, c + 1, 2);
+    read_b(f, c, 2);
+    {
+      const int so = ((c + 1) & (NST - 1)) * STAGE_B;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ahn[i] = *(const bf16x8*)(fa + so + i * 32 * ROWB);
+        bhn[i] = *(const bf16x8*)(fb + so + i * 32 * ROWB);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < 6; ++t) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[PA[t]][i], cur.b[PB[t]][j], acc[i][j], 0, 0, 0);
-      if (t == 0) {
-        // behind the first MFMAs, so that the wait the compiler puts before them (for `cur`, read one stage ago) does
-        // not also wait for the reads of `nxt`
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[PA[t]][i], f.b[PB[t]][j], acc[i][j], 0, 0, 0);
+      if (t == 2 || t == 4) {
         __builtin_amdgcn_sched_barrier(0);
-        if (kc + 1 < nk) read_frags(nxt, kc + 1);
+        if (t == 2) read_a(f, c + 1, 1);
+        if (t == 4) read_b(f, c + 1, 1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f.a[0][i] = ahn[i];
+      f.b[0][i] = bhn[i];
+    }
   };
   __builtin_amdgcn_s_barrier();
-  Frags f0, f1;
-  read_frags(f0, 0);
-  for (int kc = 0; kc < nk; kc += 2) {   // nk is even (K % 32 == 0)
-    stage(kc, f0, f1);
-    stage(kc + 1, f1, f0);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    read_a(f, 0, p);
+    read_b(f, 0, p);
   }
-  // C/D layout of 32x32 tiles: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        const int col = n0 + wn * 64 + j * 32 + fr;
-        C[((int64_t)g * M + row) * N + col] = acc[i][j][r];
-      }
+  int c = 0;
+  for (int sg = 0; sg < nseg; ++sg) {
+    const bool whole = sg < rounds;
+    const int n = whole ? nk : tail_k1 - tail_k0, tile = seg_tile(sg);
+    stage(c, X3Yes());
+    for (int v = 1; v < n; ++v) stage(c + v, X3No());
+    c += n;
+    if (whole || S == 1) store_tile(tile, 0, 0);
+    else hand_off(tile);
+  }
 }
 
 bool gemm_bf16x3_ok(int G, int64_t M, int N, int K) {
   return G > 0 && M > 0 && M % BM == 0 && N % BN == 0 && K % 32 == 0 && (int64_t)3 * G * M * K * 2 < ((int64_t)1 << 32) &&
-         (int64_t)3 * G * N * K * 2 < ((int64_t)1 << 32) && (M / BM) * (int64_t)(N / BN) * G < 0x7fffffff;
+         (int64_t)3 * G * N * K * 2 < ((int64_t)1 << 32) && (M / BM) * (int64_t)(N / BN) * G * (K / BK) < 0x7fffffff &&
+         (int64_t)G * M * N < ((int64_t)1 << 29);
 }
 
-int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, int N, int K, hipStream_t s) {
+// workgroups of the launch: one per CU, or one per tile when there are fewer tiles
+int gemm_bf16x3_workgroups(int G, int M, int N) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  const int64_t tiles = (int64_t)(M / BM) * (N / BN) * G;
+  return (int)(tiles < cus ? tiles : cus);
+}
+size_t gemm_bf16x3_workspace_bytes() {   // a slab and a counter per workgroup
+  return (size_t)X3_MAX_WG * BM * BN * sizeof(float) + (size_t)X3_MAX_WG * X3_FLAG_STRIDE * sizeof(uint32_t);
+}
+
+// ws: gemm_bf16x3_workspace_bytes() bytes, zeroed once when allocated (the kernel leaves the counters zero); one per
+// stream of launches (a plan's launches are ordered on its stream)
+int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, int N, int K, void* ws, hipStream_t s) {
   KD_REQUIRE(gemm_bf16x3_ok(G, M, N, K), "bf16x3 GEMM needs M % 256 == 0, N % 128 == 0, K % 32 == 0 and operand planes < 4 GB");
-  KD_REQUIRE((((uintptr_t)A3 | (uintptr_t)B3) & 15) == 0, "bf16x3 GEMM needs 16-byte aligned operand planes");
-  const dim3 grid((unsigned)((M / BM) * (N / BN) * G));
-  hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C, G, M, N, K);
+  KD_REQUIRE((((uintptr_t)A3 | (uintptr_t)B3 | (uintptr_t)ws) & 15) == 0 && ws, "bf16x3 GEMM needs 16-byte aligned operand planes and a workspace");
+  const int P = gemm_bf16x3_workgroups(G, M, N);
+  KD_REQUIRE(P <= X3_MAX_WG, "bf16x3 GEMM: more workgroups than the workspace holds");
+  // the tiles left over after the whole rounds, cut in k into S parts of at least eight stages
+  const int tiles = (M / BM) * (N / BN) * G, R = tiles % P, nk = K / BK;
+  int S = 1;
+  if (R) {
+    S = P / R;
+    if (S > X3_MAX_SPLIT) S = X3_MAX_SPLIT;
+    if (S > nk / 8) S = nk / 8;
+    if (S < 1) S = 1;
+  }
+  float* slab = (float*)ws;
+  uint32_t* counters = (uint32_t*)((char*)ws + (size_t)X3_MAX_WG * BM * BN * sizeof(float));
+  hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C, G, M, N, K, S,
+                     slab, counters);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
