@@ -869,7 +869,14 @@ struct Builder {
     // worth six times the per-conv rounding error), 256 -> 128 at 128 x 128 626 -> 737 (+18 %), at 256 x 256 +17 %
     // (round 4, with the input transform 13 % faster: Cin = 256 on the 64 x 64 level alone, 9 layers, gives 32.74 -> 32.59 ms
     // per forward - 0.5 % for six times those layers' rounding error: the threshold stays at 512)
-    return x.C >= (cfg.wino43_min_cin > 0 ? cfg.wino43_min_cin : 512);
+    // With the position GEMMs on the bf16 pipe (bf16x3, 1.5 x the fp32 MFMA rate) the hand-over moves down to Cin >= 256
+    // on maps of up to 65536 pixels - same box, per layer: 256 -> 256 at 64 x 64 (batch 16) 330 us fused F(2x2,3x3) against
+    // 129 + 82 + 48 (GEMM + transforms), nine layers, -0.64 ms per forward; the larger maps stay: 256 -> 128 at 128 x 128
+    // 688 against 256 + 378 + ~100, at 256 x 256 2618 against 934 + 1514 + ~400 (the transforms write 3.4 x the map)
+    int thr = cfg.wino43_min_cin > 0 ? cfg.wino43_min_cin : 512;
+    if (cfg.wino43_min_cin == 0 && cfg.gemm_bf16x3 >= 0 && gemm_bf16x3_ok(36, Mt, cout, x.C) && (int64_t)x.B * x.H * x.W <= 65536)
+      thr = 256;
+    return x.C >= thr;
   }
   T wino4_block(const T& x, const std::string& gn_prefix, int ss_col, const std::string& conv_prefix, int Cout,
                 const T* res) {

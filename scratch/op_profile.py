@@ -12,9 +12,11 @@ import bench  # noqa: E402
 from imagen_pytorch import _engine as E  # noqa: E402
 
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+w43 = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # Unet.wino43_min_cin (0 = default)
 dev = torch.device("cuda:0")
 lib = E.load()
 unet = bench.build_unet(0)
+unet.wino43_min_cin = w43
 h = unet.engine(bench.BATCH, bench.SIZE, dev, with_text=False)
 x, lowres, _, cond = bench.synthetic_inputs(bench.BATCH, dev)
 t = torch.zeros(bench.BATCH, device=dev)

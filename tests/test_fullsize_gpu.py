@@ -123,7 +123,8 @@ def test_c3_sr_unet_forward_and_sampler_steps_match_oracle(device, c3, conv_algo
 
 def test_c3_sr_unet_at_the_benchmark_batch_matches_oracle(device, c3):
     """The plan bench.py times: batch 16, where the 31 ResnetBlock 3x3 convs with Cin >= 512 (the 32x32 and 16x16 levels)
-    run as Winograd F(4x4,3x3) and the other 25 as the fused F(2x2,3x3) kernel (at batch 2, above, the deep levels do not
+    and, with the position GEMMs on the bf16 pipe, the 9 with Cin = 256 on the 64x64 level run as Winograd F(4x4,3x3) and the
+    other 16 as the fused F(2x2,3x3) kernel (at batch 2, above, the deep levels do not
     fill whole 128-row tile slabs and stay on F(2x2,3x3)).  One forward against the oracle (7.3 TFLOP on the host)."""
     import ctypes as C
     from imagen_pytorch import _engine as E
@@ -146,14 +147,16 @@ def test_c3_sr_unet_at_the_benchmark_batch_matches_oracle(device, c3):
         buf = C.create_string_buffer(1 << 20)
         E.check(E.load().kd_unet_profile(pu.engine(B, S, device, with_text=False), 1, buf, len(buf), E.current_stream()))
         labels = buf.value.decode()
-        assert labels.count("wino4 gemm") == (31 if w43 == 0 else 0), labels.count("wino4 gemm")
-        assert labels.count("wino4 gemm bf16x3") == (31 if (w43, x3) == (0, 0) else 0), labels.count("wino4 gemm bf16x3")
-        assert labels.count("wino fused") == (25 if w43 == 0 else 56), labels.count("wino fused")
+        # (with the bf16x3 GEMMs the hand-over to F(4x4,3x3) moves from Cin >= 512 to Cin >= 256 on the 64 x 64 level: 9 layers more)
+        n4 = {(0, 0): 40, (0, -1): 31, (-1, 0): 0}[w43, x3]
+        assert labels.count("wino4 gemm") == n4, labels.count("wino4 gemm")
+        assert labels.count("wino4 gemm bf16x3") == (n4 if x3 == 0 else 0), labels.count("wino4 gemm bf16x3")
+        assert labels.count("wino fused") == 56 - n4, labels.count("wino fused")
         del pu
-    print(f"C3 forward at batch 16: rel-L2 {errs[0, 0]:.3e} with F(4x4,3x3) on 31 layers (bf16x3 GEMMs), "
+    print(f"C3 forward at batch 16: rel-L2 {errs[0, 0]:.3e} with F(4x4,3x3) on 40 layers (bf16x3 GEMMs), "
           f"{errs[0, -1]:.3e} with fp32 MFMA GEMMs, {errs[-1, 0]:.3e} without F(4x4,3x3)")
     assert all(e < FWD_REL_L2 for e in errs.values()), errs
-    assert errs[0, 0] < 1.25 * errs[0, -1] + 1e-7, errs   # the bf16x3 products cost no accuracy against fp32 MFMA
+    assert errs[0, 0] < 1.5 * errs[0, -1] + 1e-7, errs   # (nine layers more on F(4x4,3x3); the bf16x3 products themselves cost nothing)
 
 
 # ------------------------------------------------------------------------------- C1: end to end
