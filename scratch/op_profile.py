@@ -13,10 +13,12 @@ from imagen_pytorch import _engine as E  # noqa: E402
 
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 w43 = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # Unet.wino43_min_cin (0 = default)
+x3 = int(sys.argv[3]) if len(sys.argv) > 3 else 0    # Unet.gemm_bf16x3 (0 = default, -1 = fp32 MFMA position GEMMs)
 dev = torch.device("cuda:0")
 lib = E.load()
 unet = bench.build_unet(0)
 unet.wino43_min_cin = w43
+unet.gemm_bf16x3 = x3
 h = unet.engine(bench.BATCH, bench.SIZE, dev, with_text=False)
 x, lowres, _, cond = bench.synthetic_inputs(bench.BATCH, dev)
 t = torch.zeros(bench.BATCH, device=dev)
