@@ -282,6 +282,47 @@ def test_gemm_bf16x3_matches_fp64(lib, device, G, M, N, K, scale_b):
     assert torch.equal(c, c2)
 
 
+def test_gemm_bf16x3_two_launches_sharing_the_chip_do_not_depend_on_each_other(lib, device):
+    """The parts of a left-over tile meet through slabs and a ticket counter and never wait for one another, so two such
+    launches on different streams (two plans of a grid run) may share the CUs in any interleaving: same bits as alone."""
+    import threading
+
+    E = _E()
+    shapes = [(36, 256, 1024, 1024), (36, 1024, 512, 256)]   # 288 tiles (32 cut in 8) and 576 tiles (64 cut in 2)
+    data, alone = [], []
+    for i, (G, M, N, K) in enumerate(shapes):
+        a = torch.randn(G, M, K, generator=g(20 + i)).to(device)
+        b = (torch.randn(G, N, K, generator=g(30 + i)) * 0.05).to(device)
+        c = torch.empty(G, M, N, device=device)
+        E.check(lib.kd_gemm_bf16x3(E.ptr(a), E.ptr(b), E.ptr(c), G, M, N, K, E.current_stream()))
+        data.append((a, b))
+        alone.append(c.clone())
+    streams = [torch.cuda.Stream(device=device) for _ in shapes]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        G, M, N, K = shapes[i]
+        a, b = data[i]
+        try:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(12):
+                    c = torch.full((G, M, N), float("nan"), device=device)
+                    E.check(lib.kd_gemm_bf16x3(E.ptr(a), E.ptr(b), E.ptr(c), G, M, N, K, streams[i].cuda_stream))
+                    if not torch.equal(c, alone[i]):
+                        errors.append((i, float((c - alone[i]).abs().max())))
+        except Exception as e:   # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(shapes))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors[:4]
+
+
 def test_gemm_bf16x3_rejects_unsupported_shapes(lib, device):
     E = _E()
     t = torch.zeros(16, device=device)
