@@ -194,6 +194,11 @@ __global__ __launch_bounds__(256) void wino4_in_kernel(const float* __restrict__
   }
 }
 
+// (Round 4, measured and removed, plane form: the four lanes of a quad transposing four positions' dwords (DPP quad_perm) so
+// that every lane stores 16 bytes - whole 128-byte lines per wave instruction instead of 32 bytes per tile: 186.6 us against
+// 186.0 on 65536 pixels x 512 channels.  The kernel is bound by the WRITE rate of the memory side: 442 MB written + 185 MB read
+// in 186 us, and its fp32 form 302 MB written in 129 us - 2.3-2.4 TB/s of writes either way, while the read-mostly kernels of
+// the engine (gate_add, wino4_out) move 5.5-6.0 TB/s.)
 // (Round 4, measured and removed: a 16-byte variant - one thread = tile x FOUR channels x one half of the transformed rows,
 // 30 of the 36 pixels each - took 1715 us per step over the 31 launches against 1369 us of this kernel: the width of the
 // accesses is not what limits it.)
