@@ -99,7 +99,9 @@ typedef struct kd_unet_config {
   /* The position GEMMs of those F(4x4,3x3) layers on the bf16 matrix pipe, every fp32 operand carried as three bf16
    * pieces (a = ah + am + al exactly) and six exact products accumulated in fp32 per k-step (kernels_gemm_bf16x3.hip):
    * fp32-class results - error against fp64 not above the fp32 MFMA path's - at 3/8 of its matrix cycles.
-   * 0 = default (where tiles % 256 == 0, Cout % 128 == 0), < 0 = never (fp32 MFMA). */
+   * 0 = default (where tiles % 256 == 0, Cout % 128 == 0; the input transform writes V as the three planes), < 0 = never
+   * (fp32 MFMA); 2 = as 0 with V written as fp32 and split by the GEMM's loader waves on the way into LDS (the form a GEMM
+   * whose activation comes from another kernel would use; here the transform gains less than the GEMMs lose). */
   int gemm_bf16x3;
 } kd_unet_config_t;
 
@@ -285,15 +287,17 @@ int kd_conv3x3_winograd_nhwc(const float* d_x, const float* d_w_oihw, const floa
  * path for the deepest layers (kernels_wino4.hip): weight transform, input transform, 36 batched GEMMs, output transform.
  * Needs H % 4 == 0, W % 4 == 0, B (H/4) (W/4) % 128 == 0, Cin % 32 == 0, Cout % 64 == 0.  d_out_stats (may be NULL):
  * [B, G, 2] = (mean, rstd) of y per image and group of Cout / G channels from the partial sums the output transform
- * leaves for the next GroupNorm; needs (Cout / G) % 16 == 0.  gemm_bf16x3 != 0: the GEMMs on the bf16 matrix pipe as the
- * plan runs them by default (kd_unet_config_t::gemm_bf16x3; needs B (H/4) (W/4) % 256 == 0 and Cout % 128 == 0 as well). */
+ * leaves for the next GroupNorm; needs (Cout / G) % 16 == 0.  gemm_bf16x3 = 1: the GEMMs on the bf16 matrix pipe as the
+ * plan runs them by default (V in plane form), 2: V as fp32, split by the GEMM's loader waves (kd_unet_config_t::gemm_bf16x3;
+ * both need B (H/4) (W/4) % 256 == 0 and Cout % 128 == 0 as well). */
 int kd_conv3x3_winograd4_nhwc(const float* d_x, const float* d_w_oihw, const float* d_bias, const float* d_res,
                               float* d_y, int B, int H, int W, int Cin, int Cout, int G, float eps,
                               float* d_out_stats, int gemm_bf16x3, void* stream);
 /* C[g][M][N] = A[g][M][K] B[g][N][K]^T (fp32, row-major) through the bf16x3 GEMM of kernels_gemm_bf16x3.hip: both
- * operands split into three bf16 planes, six bf16 MFMAs per k-step, fp32 accumulation.  Needs M % 256 == 0,
- * N % 128 == 0, K % 32 == 0, 6 G M K and 6 G N K below 2^32 bytes. */
-int kd_gemm_bf16x3(const float* d_a, const float* d_b, float* d_c, int G, int M, int N, int K, void* stream);
+ * operands split into three bf16 planes, six bf16 MFMAs per k-step, fp32 accumulation.  a_planes != 0: both operands
+ * split beforehand (the plan's form: weights once, activations by the kernel that writes them); a_planes = 0: A stays fp32
+ * and is split by the kernel's loader waves on its way into LDS.  Same planes, same bits.  Needs M % 256 == 0, N % 128 == 0, K % 32 == 0, 6 G M K and 6 G N K below 2^32 bytes. */
+int kd_gemm_bf16x3(const float* d_a, const float* d_b, float* d_c, int G, int M, int N, int K, int a_planes, void* stream);
 /* ResnetBlock `Block` in one pass over x: conv3x3(SiLU(FiLM(GroupNorm_G(x)))) + bias (+ d_res), the form the
  * plan uses for those layers: statistics, a per-(image, channel) affine fold, and the fused Winograd kernel
  * with the activation applied to the raw patch in LDS (the activated map is never written).  d_scale_shift

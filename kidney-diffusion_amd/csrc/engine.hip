@@ -891,7 +891,11 @@ struct Builder {
     emit_gn_stats(x, gamma, beta, ss_col, nullptr);
     // the 36 GEMMs as fp32-class products on the bf16 matrix pipe (kernels_gemm_bf16x3.hip) where the shape fits its tile
     const bool x3 = cfg.gemm_bf16x3 >= 0 && !to_text && !to_static && gemm_bf16x3_ok(36, Mt, Cout, Cin);
-    T V = x3 ? alloc_bytes((size_t)36 * Mt * Cin * 6) : alloc(1, 1, (int)(36 * Mt), Cin);
+    // V written as planes by the input transform (default), or (2) as fp32, split by the GEMM's loader waves on the way into
+    // LDS: the transform then writes a third less and is that much faster (-0.47 ms over the 40 layers), but the loaders'
+    // vector work beside the MFMA waves costs the GEMMs 15-25 % (+0.93 ms)
+    const bool x3_planes = x3 && cfg.gemm_bf16x3 != 2;
+    T V = x3_planes ? alloc_bytes((size_t)36 * Mt * Cin * 6) : alloc(1, 1, (int)(36 * Mt), Cin);
     T D = alloc(1, 1, (int)(36 * Mt), Cout);
     T y = alloc(Bx, H, W, Cout);
     const std::string shape = " M" + std::to_string((int64_t)Bx * HW) + " Cin" + std::to_string(Cin) + " Cout" +
@@ -902,7 +906,7 @@ struct Builder {
       const int ld = tmlp_total, ldx = x.LD();
       emit([=](hipStream_t s) {
         const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
-        if (x3) return launch_wino4_in3(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s);
+        if (x3_planes) return launch_wino4_in3(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s);
         return launch_wino4_in(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s);
       }, "wino4_in" + shape);
     }
@@ -915,7 +919,7 @@ struct Builder {
         KD_HIP_THROW(hipMalloc(&u->x3_ws, gemm_bf16x3_workspace_bytes()));
         KD_HIP_THROW(hipMemset(u->x3_ws, 0, gemm_bf16x3_workspace_bytes()));
       }
-      emit([=](hipStream_t s) { return launch_gemm_bf16x3(uu->P(vo), U3, uu->P(d_o), 36, (int)Mt, Cout, Cin, uu->x3_ws, s); },
+      emit([=](hipStream_t s) { return launch_gemm_bf16x3(uu->P(vo), U3, uu->P(d_o), 36, (int)Mt, Cout, Cin, uu->x3_ws, s, !x3_planes); },
            "wino4 gemm bf16x3" + shape, macs);
       u->macs += macs;
       u->op_mfma.back() = 6 * 36 * Mt * Cout * Cin;   // bf16 MACs

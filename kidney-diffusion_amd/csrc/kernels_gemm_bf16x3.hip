@@ -114,6 +114,10 @@ constexpr int X3_FLAG_STRIDE = 32;   // dwords: one 128-byte line per counter
 constexpr int X3_MAX_WG = 512;       // slabs / counters of the workspace
 constexpr int X3_MAX_SPLIT = 8;
 
+// A_F32: the A operand comes as plain fp32 [G][M][K] rows and the loader waves split it on its way into LDS (buffer_load to
+// registers two stages ahead, nine VALU operations per pair of values, ds_write_b64 of the three planes) - the producer
+// writes 4 instead of 6 bytes per element, and its writes are what bound it (kernels_wino4.hip)
+template <bool A_F32>
 __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __restrict__ A3, const uint16_t* __restrict__ B3,
                                                           float* __restrict__ C, int G, int M, int N, int K, int S,
                                                           float* __restrict__ slab, uint32_t* __restrict__ counters) {
@@ -134,6 +138,93 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
   const int T = rounds * nk + (tail ? tail_k1 - tail_k0 : 0);   // stage units of this workgroup
   auto seg_tile = [&](int sg) __attribute__((always_inline)) { return sg < rounds ? sg * P + q : rounds * P + q / S; };
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  if (A_F32 && wave >= 8) {
+    // loader l: rows 16 l .. 16 l + 15 of every 64-row block of the A tile (lane -> row = lane >> 2, quarter = lane & 3 of
+    // its 64 bytes of a stage: 16 bytes, four values, per load; four loads per stage), and pieces 3 l .. 3 l + 2 of the 12
+    // of the B planes (LDS-DMA, as in the other form).  Unit u's A values are loaded three stages ahead into registers (two
+    // sets), split and written to LDS one stage ahead; its B pieces are issued three stages ahead.
+    const int l = wave - 8;
+    const uint32_t planeB = (uint32_t)((int64_t)G * N * K * 2);
+    const i32x4 rsB = make_rsrc(B3, 3u * planeB);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A3, 0, (int)((int64_t)G * M * K * 4), 0x00020000);
+    const uint32_t voffB = (uint32_t)((lane >> 1) * ROWB + (((lane & 1) ^ ((lane >> 4) & 1)) * 16));
+    const uint32_t chunkB = (uint32_t)(N * ROWB);
+    const int arow = l * 16 + (lane >> 2), aq = lane & 3;
+    const uint32_t voffA = (uint32_t)((arow * K + aq * 4) * 4);
+    // LDS position of the lane's 8 bytes of a plane row: 16-byte slot (aq >> 1) ^ ((row >> 3) & 1), half aq & 1
+    const int ldsA = arow * ROWB + ((((aq >> 1) ^ ((arow >> 3) & 1)) * 16) + (aq & 1) * 8);
+    int ic = 0, iseg = 0, ik = 0, ik1 = 0;
+    uint32_t baseA = 0, baseB = 0;
+    auto locate = [&]() __attribute__((always_inline)) {
+      const int it = seg_tile(iseg);
+      const int nt = it % ntiles, mt = (it / ntiles) % mtiles, g = it / (ntiles * mtiles);
+      baseA = (uint32_t)(((int64_t)g * M + mt * BM) * K * 4);
+      baseB = (uint32_t)((int64_t)g * N * K * 2) + (uint32_t)(nt * BN * ROWB);
+      ik = iseg < rounds ? 0 : tail_k0;
+      ik1 = iseg < rounds ? nk : tail_k1;
+    };
+    locate();
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x4 ra[2][4];   // the A values of the two units in flight
+    auto issue_next = [&](auto SET) __attribute__((always_inline)) {
+      constexpr int set = decltype(SET)::value;
+      const int st = ic & (NST - 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        ra[set][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA, baseA + (uint32_t)(ik * (BK * 4)) + (uint32_t)(j * 64 * K * 4), 0);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int id = l * 3 + j, pl = id >> 2, pr = id & 3;
+        const uint32_t dst = lds0 + (uint32_t)(st * STAGE_B + B_OFF + (pl * BN + pr * 32) * ROWB);
+        dma16(rsB, dst, voffB, (uint32_t)pl * planeB + baseB + (uint32_t)ik * chunkB + (uint32_t)(pr * 32 * ROWB));
+      }
+      ++ic;
+      if (++ik == ik1 && ++iseg < nseg) locate();
+    };
+    auto write_unit = [&](int u, auto SET) __attribute__((always_inline)) {   // split + store the A planes of unit u
+      constexpr int set = decltype(SET)::value;
+      char* dst = lds + (u & (NST - 1)) * STAGE_B + ldsA;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t h0, m0, l0, h1, m1, l1;
+        const f32x2 v01 = {__uint_as_float(ra[set][j][0]), __uint_as_float(ra[set][j][1])};
+        const f32x2 v23 = {__uint_as_float(ra[set][j][2]), __uint_as_float(ra[set][j][3])};
+        x3_split(v01, h0, m0, l0);
+        x3_split(v23, h1, m1, l1);
+        *(u32x2*)(dst + j * 64 * ROWB) = u32x2{h0, h1};
+        *(u32x2*)(dst + BM * ROWB + j * 64 * ROWB) = u32x2{m0, m1};
+        *(u32x2*)(dst + 2 * BM * ROWB + j * 64 * ROWB) = u32x2{l0, l1};
+      }
+    };
+    // issue order per unit: 4 loads, then 3 DMAs.  In flight behind unit u's loads: its own 3 DMAs + 7 per later unit
+    issue_next(X3No());
+    if (T > 1) issue_next(X3Yes());
+    if (T > 1) wait_vm<10>(); else wait_vm<3>();
+    write_unit(0, X3No());
+    if (T > 1) wait_vm<7>(); else wait_vm<0>();
+    if (T > 2) issue_next(X3No());
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // iteration c: unit c + 1 into LDS (its loads were issued two iterations ago), barrier c, then the loads of unit c + 3
+    auto iter = [&](int c, auto SET_NEXT) __attribute__((always_inline)) {   // SET_NEXT: register set of units c + 1, c + 3
+      if (c + 1 < T) {
+        if (c + 2 < T) wait_vm<10>(); else wait_vm<3>();
+        write_unit(c + 1, SET_NEXT);
+        if (c + 2 < T) wait_vm<7>(); else wait_vm<0>();
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (ic < T) issue_next(SET_NEXT);
+    };
+    for (int c = 0; c < T; c += 2) {
+      iter(c, X3Yes());
+      if (c + 1 < T) iter(c + 1, X3No());
+    }
+    if (tail && S > 1)   // the hand-off's barriers
+      for (int j = 0; j < 3; ++j) __builtin_amdgcn_s_barrier();
+    return;
+  }
   if (wave >= 8) {
     // loader l moves pieces 9 l .. 9 l + 8 of the 36 of every stage (0..23: A plane id / 8, rows 32 (id % 8); 24..35: B
     // plane (id - 24) / 4, rows 32 ((id - 24) % 4)).  A piece = 32 rows x 32 bytes = 1 KB of consecutive memory: lane ->
@@ -379,6 +470,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
 
 bool gemm_bf16x3_ok(int G, int64_t M, int N, int K) {
   return G > 0 && M > 0 && M % BM == 0 && N % BN == 0 && K % 32 == 0 && (int64_t)3 * G * M * K * 2 < ((int64_t)1 << 32) &&
+         (int64_t)G * M * K * 4 < ((int64_t)1 << 32) &&
          (int64_t)3 * G * N * K * 2 < ((int64_t)1 << 32) && (M / BM) * (int64_t)(N / BN) * G * (K / BK) < 0x7fffffff &&
          (int64_t)G * M * N < ((int64_t)1 << 29);
 }
@@ -401,7 +493,8 @@ size_t gemm_bf16x3_workspace_bytes() {   // a slab and a counter per workgroup
 
 // ws: gemm_bf16x3_workspace_bytes() bytes, zeroed once when allocated (the kernel leaves the counters zero); one per
 // stream of launches (a plan's launches are ordered on its stream)
-int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, int N, int K, void* ws, hipStream_t s) {
+// a_f32: A is plain fp32 [G][M][K] (split by the kernel's loader waves) instead of three planes
+int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, int N, int K, void* ws, hipStream_t s, bool a_f32) {
   KD_REQUIRE(gemm_bf16x3_ok(G, M, N, K), "bf16x3 GEMM needs M % 256 == 0, N % 128 == 0, K % 32 == 0 and operand planes < 4 GB");
   KD_REQUIRE((((uintptr_t)A3 | (uintptr_t)B3 | (uintptr_t)ws) & 15) == 0 && ws, "bf16x3 GEMM needs 16-byte aligned operand planes and a workspace");
   const int P = gemm_bf16x3_workgroups(G, M, N);
@@ -417,8 +510,12 @@ int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, i
   }
   float* slab = (float*)ws;
   uint32_t* counters = (uint32_t*)((char*)ws + (size_t)X3_MAX_WG * BM * BN * sizeof(float));
-  hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C, G, M, N, K, S,
-                     slab, counters);
+  if (a_f32)
+    hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C, G, M, N,
+                       K, S, slab, counters);
+  else
+    hipLaunchKernelGGL(gemm_bf16x3_kernel<false>, dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C, G, M, N,
+                       K, S, slab, counters);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

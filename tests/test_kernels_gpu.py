@@ -193,7 +193,9 @@ WINO4_REL = 8e-6
     (16, 16, 16, 1536, 768, False, False, 0),   # K = 1536 (48 chunks of 32)
     (4, 32, 32, 32, 128, True, True, 1),        # the shortest K the bf16x3 kernel takes: two stages (its ring holds four)
     (4, 32, 32, 64, 256, False, True, 1),       # four stages
-    (16, 64, 64, 512, 256, True, True, 1),      # Mt = 4096: sixteen 256-row tiles per position, 1152 workgroups
+    (16, 64, 64, 512, 256, True, True, 1),      # Mt = 4096: sixteen 256-row tiles per position, 1152 tiles
+    (16, 32, 32, 512, 512, True, True, 2),      # x3 = 2: V as fp32, split by the GEMM's loader waves on the way into LDS
+    (16, 16, 16, 1280, 768, False, True, 2),
 ])
 def test_conv3x3_winograd4_matches_direct(lib, device, B, H, W, Cin, Cout, res, stats, x3):
     E = _E()
@@ -257,13 +259,14 @@ def test_conv3x3_winograd4_rejects_unsupported_shapes(lib, device):
     (13, 512, 384, 128, 1.0),      # 78 tiles: fewer than CUs, one tile per workgroup
     (33, 2048, 128, 64, 1.0),      # 264 tiles: one round + 8 tiles, four k-stages: too short to cut (S = 1)
 ])
-def test_gemm_bf16x3_matches_fp64(lib, device, G, M, N, K, scale_b):
+@pytest.mark.parametrize("a_planes", [1, 0])   # 1: A in plane form (the plan's); 0: A as fp32, split by the kernel's loader waves
+def test_gemm_bf16x3_matches_fp64(lib, device, G, M, N, K, scale_b, a_planes):
     E = _E()
     a = (torch.randn(G, M, K, generator=g(5)) * torch.logspace(-3, 3, K)).to(device)   # 6 decades along k
     b = (torch.randn(G, N, K, generator=g(6)) * scale_b).to(device)
     a[0, 0, :4] = torch.tensor([0.0, -0.0, 1e-30, 1e30], device=device)   # zeros, a tiny and a huge value
     c = torch.full((G, M, N), float("nan"), device=device)
-    E.check(lib.kd_gemm_bf16x3(E.ptr(a), E.ptr(b), E.ptr(c), G, M, N, K, E.current_stream()))
+    E.check(lib.kd_gemm_bf16x3(E.ptr(a), E.ptr(b), E.ptr(c), G, M, N, K, a_planes, E.current_stream()))
     ref = torch.bmm(a.double(), b.double().transpose(1, 2))
     f32 = torch.bmm(a, b.transpose(1, 2)).double()
     assert torch.isfinite(c).all()
@@ -278,8 +281,8 @@ def test_gemm_bf16x3_matches_fp64(lib, device, G, M, N, K, scale_b):
     # terms inside a step still shows - 1.4 x it, 3.4e-8)
     assert rms(e_x3) <= max(1.5 * rms(e_32), 2.0 ** -25), (rms(e_x3), rms(e_32))   # 2^-25: half an fp32 ulp of sum |a| |b|
     c2 = torch.empty_like(c)
-    E.check(lib.kd_gemm_bf16x3(E.ptr(a), E.ptr(b), E.ptr(c2), G, M, N, K, E.current_stream()))
-    assert torch.equal(c, c2)
+    E.check(lib.kd_gemm_bf16x3(E.ptr(a), E.ptr(b), E.ptr(c2), G, M, N, K, 1 - a_planes, E.current_stream()))
+    assert torch.equal(c, c2)   # the other form of the A operand: the same planes, the same bits
 
 
 def test_gemm_bf16x3_two_launches_sharing_the_chip_do_not_depend_on_each_other(lib, device):
@@ -294,7 +297,7 @@ def test_gemm_bf16x3_two_launches_sharing_the_chip_do_not_depend_on_each_other(l
         a = torch.randn(G, M, K, generator=g(20 + i)).to(device)
         b = (torch.randn(G, N, K, generator=g(30 + i)) * 0.05).to(device)
         c = torch.empty(G, M, N, device=device)
-        E.check(lib.kd_gemm_bf16x3(E.ptr(a), E.ptr(b), E.ptr(c), G, M, N, K, E.current_stream()))
+        E.check(lib.kd_gemm_bf16x3(E.ptr(a), E.ptr(b), E.ptr(c), G, M, N, K, 1, E.current_stream()))
         data.append((a, b))
         alone.append(c.clone())
     streams = [torch.cuda.Stream(device=device) for _ in shapes]
@@ -308,7 +311,7 @@ def test_gemm_bf16x3_two_launches_sharing_the_chip_do_not_depend_on_each_other(l
             with torch.cuda.stream(streams[i]):
                 for _ in range(12):
                     c = torch.full((G, M, N), float("nan"), device=device)
-                    E.check(lib.kd_gemm_bf16x3(E.ptr(a), E.ptr(b), E.ptr(c), G, M, N, K, streams[i].cuda_stream))
+                    E.check(lib.kd_gemm_bf16x3(E.ptr(a), E.ptr(b), E.ptr(c), G, M, N, K, 1, streams[i].cuda_stream))
                     if not torch.equal(c, alone[i]):
                         errors.append((i, float((c - alone[i]).abs().max())))
         except Exception as e:   # noqa: BLE001
@@ -327,7 +330,7 @@ def test_gemm_bf16x3_rejects_unsupported_shapes(lib, device):
     E = _E()
     t = torch.zeros(16, device=device)
     for shape in [(1, 128, 128, 32), (1, 256, 64, 32), (1, 256, 128, 16), (36, 4096 * 8, 128, 2048)]:
-        rc = lib.kd_gemm_bf16x3(E.ptr(t), E.ptr(t), E.ptr(t), *shape, E.current_stream())
+        rc = lib.kd_gemm_bf16x3(E.ptr(t), E.ptr(t), E.ptr(t), *shape, 0, E.current_stream())
         assert rc != 0 and b"bf16x3" in lib.kd_last_error()
 
 
