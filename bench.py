@@ -565,8 +565,9 @@ def main():
     ap.add_argument("--grid-gather", choices=("all", "root"), default="all",
                     help="grid: the one collective after the last wave - all-gather of the final patches to every rank "
                          "(default; BASELINE's 'RCCL all-gather ... to reassemble the stitched canvas') or a gather to rank 0")
-    ap.add_argument("--grid-batch", type=int, default=1,
-                    help="--workload grid: patches of a wave per sample() call in stages 1-2 (1 = the reference's way)")
+    ap.add_argument("--grid-batch", type=int, default=4,
+                    help="--workload grid: same-wave patches of a rank per sample() call in stages 1-2 (1 = the reference's way, one "
+                         "patch per call; 1 GPU, 8 timesteps: 2.48 patches/s at 1, 2.63 at 4, 2.62 at 8)")
     ap.add_argument("--no-cond-table", action="store_true",
                     help="compute the time conditioning in every step instead of restoring it from the per-schedule table "
                          "(profiles: keeps the one-off table build, 250 x 21 launches, out of a 7-step trace)")
