@@ -4,7 +4,7 @@
 //                          3 x 8 significant bits hold the 24 of an fp32 mantissa),
 //   a b = ah bh + (ah bm + am bh) + (ah bl + al bh + am bm) + terms <= 2^-24 |a b|,
 //
-// six v_mfma_f32_32x32x16_bf16 per 16-deep k-step, every product exact, accumulated in fp32 from the smallest terms up.
+// six v_mfma_f32_32x32x16_bf16 per 16-deep k-step, every product exact, accumulated in fp32.
 // The result is as close to the exact product as the fp32 MFMA's (measured against fp64 on the shapes below: rms error
 // 3.4e-7 .. 1.4e-6 of the result's rms, fp32 MFMA 4.1e-7 .. 1.6e-6; scratch/bf16x3/, profiles/README.md "bf16x3") -
 // this is fp32 arithmetic issued on a faster pipe, not a reduced precision: the bf16 pipe issues 16 x the MACs per clock
@@ -19,12 +19,14 @@
 //              buffer_load ... lds of the ring of four 36 KB stages (BK = 16), three stages ahead.  (A wave whose DMA
 //              waits for a slot in the memory pipeline cannot issue MFMAs meanwhile; with loaders of their own the
 //              K = 512 launches took 0.41 instead of 0.51 ms.)  The fragments of stage i + 1 are read while the 24 MFMAs
-//              of stage i run (two register sets); one barrier per stage.  The two 16-byte slots of a 32-byte row are
+//              of stage i run, into the registers the products are done with (see `stage`); one barrier per stage.  The
+//              kernel is persistent: whole rounds of tiles, left-over tiles cut in k (below).  The two 16-byte slots of a 32-byte row are
 //              swapped in rows 8..15 of every 16, on the source side of the DMA and in the read: conflict-free
 //              ds_read_b128 fragments.  Workgroup ids are mapped so that every XCD works through one contiguous eighth
 //              of the (g, M tile, N tile) order: an operand tile crosses the fabric into one L2.
-//   bound      the matrix pipe at the clock the chip sustains under bf16 MFMA load: 1.24-1.37 PFLOP/s of bf16 issued
-//              (2.5 nominal), 190-230 TFLOP/s of fp32-equivalent work against 113-154 of the fp32 MFMA path.
+//   bound      the matrix pipe at the clock the chip sustains under bf16 MFMA load: a bare six-product loop issues 1.24-1.37
+//              PFLOP/s of bf16 (2.5 nominal); in the plan the launches run at 0.85-1.25 = 140-210 TFLOP/s of fp32-equivalent
+//              work against 120-136 of the fp32 MFMA kernel on the same GEMMs (1.37-1.63 x per launch).
 #include "common.h"
 
 namespace kd {
