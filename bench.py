@@ -135,6 +135,8 @@ def kernel_classes(lib, handle, iters=3):
             add("conv_buf_kernel: Winograd F(2x2,3x3) position GEMMs", us, 2.0 * macs, 2.0 * mfma)
         elif m and m.group(1) == "wino4 gemm bf16x3":   # `mfma` = the bf16 MACs (6 per fp32 MAC of the 36 GEMMs)
             add(WINO4_X3, us, 2.0 * macs, 2.0 * mfma)
+        elif label.startswith("wino4 x3 sum"):   # the left-over tiles' k-parts added up: time of the same GEMMs (not a launch of the class's count)
+            cls[WINO4_X3][1] += us
         elif m and m.group(1) == "wino4 gemm":
             add(WINO4, us, 2.0 * macs, 2.0 * mfma)
         elif m and m.group(1).startswith("wino4"):  # transforms move 3.25x the map: read 1x / write 2.25x (in), the reverse (out)

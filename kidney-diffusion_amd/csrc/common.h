@@ -144,8 +144,12 @@ int launch_split3(const float* x, void* planes, int G, int R, int K, hipStream_t
 // one per stream of launches
 size_t gemm_bf16x3_workspace_bytes();
 // a_f32: A is plain fp32 [G][M][K], split into its planes by the kernel's loader waves on the way into LDS
+// The tiles left over after the whole rounds of the persistent kernel are cut in k; their parts' accumulators are added by a
+// second launch (launch_gemm_bf16x3_sum; with_sum = true: launched here)
 int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, int N, int K, void* ws, hipStream_t s,
-                       bool a_f32 = false);
+                       bool a_f32 = false, bool with_sum = true);
+bool gemm_bf16x3_needs_sum(int G, int M, int N, int K);
+int launch_gemm_bf16x3_sum(float* C, int G, int M, int N, int K, const void* ws, hipStream_t s);
 // launch_wino4_in writing V as the three planes the bf16x3 GEMM reads ([3][36][C/16][Mt][16] bf16; Mt % 8 == 0, C % 16 == 0)
 int launch_wino4_in3(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
                      const float* scale_shift, int ld_ss, void* V3, int B, int H, int W, int C, int G, hipStream_t s);

@@ -919,11 +919,14 @@ struct Builder {
         KD_HIP_THROW(hipMalloc(&u->x3_ws, gemm_bf16x3_workspace_bytes()));
         KD_HIP_THROW(hipMemset(u->x3_ws, 0, gemm_bf16x3_workspace_bytes()));
       }
-      emit([=](hipStream_t s) { return launch_gemm_bf16x3(uu->P(vo), U3, uu->P(d_o), 36, (int)Mt, Cout, Cin, uu->x3_ws, s, !x3_planes); },
+      emit([=](hipStream_t s) { return launch_gemm_bf16x3(uu->P(vo), U3, uu->P(d_o), 36, (int)Mt, Cout, Cin, uu->x3_ws, s, !x3_planes, false); },
            "wino4 gemm bf16x3" + shape, macs);
       u->macs += macs;
       u->op_mfma.back() = 6 * 36 * Mt * Cout * Cin;   // bf16 MACs
       u->mfma_bf16_macs += u->op_mfma.back();
+      if (gemm_bf16x3_needs_sum(36, (int)Mt, Cout, Cin))   // the left-over tiles' k-parts (its own launch: the whole chip adds them)
+        emit([=](hipStream_t s) { return launch_gemm_bf16x3_sum(uu->P(d_o), 36, (int)Mt, Cout, Cin, uu->x3_ws, s); },
+             "wino4 x3 sum" + shape);
     } else {
       ConvOpt o;
       o.wz_rows = (int)Mt;

@@ -102,18 +102,16 @@ int launch_split3(const float* x, void* planes, int G, int R, int K, hipStream_t
 // measured first and lost 40-60 % per stage: neighbouring workgroups sit 1/8 tile apart in k, the reuse distance of a
 // chunk outgrows the 4 MB of L2.)  The R = tiles mod P tiles left over are cut in k into S = min(8, P / R, K / 128) parts,
 // one per workgroup q < S R: without that the 288 tiles of the 16 x 16 level's GEMMs take two rounds on 256 CUs for 1.125
-// rounds of work.  The parts of a tile meet without waiting for one another (two launches on different streams may
-// share the chip; a workgroup waiting for one that is not resident could wait for ever): every part publishes its
-// accumulators in a slab (plain stores, every wave's vmcnt(0), barrier, one agent-scope release) and draws a ticket from
-// the tile's counter (relaxed agent-scope add); the part that draws the last one takes the slabs (one agent-scope
-// acquire, barrier, plain loads), adds them IN PART ORDER, its own included, and stores the tile - the result does not
-// depend on who came last - and zeroes the counter for the next launch (launches are ordered on the stream).
+// rounds of work.  A part leaves its accumulators in a slab; `sum_slabs_kernel`, launched behind this one, adds a tile's
+// slabs IN PART ORDER and stores the tile (the whole chip reads the 32 x 8 x 128 KB, 3-5 us).  (First form: the parts met
+// inside the launch - slab, agent-scope release, a ticket from the tile's counter, the last arriver acquires and adds the
+// slabs alone, nobody waits: correct under any interleaving of two launches, but one CU reading 1 MB at its L2 rate
+// cost ~15 us at the end of every launch.)
 // The LDS ring does not drain between tiles: the loaders run up to three stages into the next tile while the computing
 // waves store the last one.
 struct X3Yes { static constexpr bool value = true; };
 struct X3No { static constexpr bool value = false; };
-constexpr int X3_FLAG_STRIDE = 32;   // dwords: one 128-byte line per counter
-constexpr int X3_MAX_WG = 512;       // slabs / counters of the workspace
+constexpr int X3_MAX_WG = 512;       // slabs of the workspace
 constexpr int X3_MAX_SPLIT = 8;
 
 // A_F32: the A operand comes as plain fp32 [G][M][K] rows and the loader waves split it on its way into LDS (buffer_load to
@@ -122,8 +120,8 @@ constexpr int X3_MAX_SPLIT = 8;
 template <bool A_F32>
 __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __restrict__ A3, const uint16_t* __restrict__ B3,
                                                           float* __restrict__ C, int G, int M, int N, int K, int S,
-                                                          float* __restrict__ slab, uint32_t* __restrict__ counters) {
-  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE_B + 64];   // the ring + one word for the hand-off
+                                                          float* __restrict__ slab) {
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE_B];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mtiles = M / BM, ntiles = N / BN;
@@ -223,8 +221,6 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
       iter(c, X3Yes());
       if (c + 1 < T) iter(c + 1, X3No());
     }
-    if (tail && S > 1)   // the hand-off's barriers
-      for (int j = 0; j < 3; ++j) __builtin_amdgcn_s_barrier();
     return;
   }
   if (wave >= 8) {
@@ -272,8 +268,6 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
       __builtin_amdgcn_s_barrier();
       if (ic < T) issue_next();   // into the buffer of unit c - 1, whose fragments were read before unit c ran
     }
-    if (tail && S > 1)   // the hand-off's barriers
-      for (int j = 0; j < 3; ++j) __builtin_amdgcn_s_barrier();
     return;
   }
   const int wm = wave >> 1, wn = wave & 1;            // 4 x 2 waves of 64 x 64
@@ -328,72 +322,24 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
         }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
-  // C/D layout of 32x32 tiles: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-  // nparts = 0: the tile = the accumulators; nparts > 0: the tile = slab[first] + slab[first + 1] + ... in that order
-  auto store_tile = [&](int tile, int first, int nparts) __attribute__((always_inline)) {
+  // C/D layout of 32x32 tiles: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  auto store_tile = [&](int tile) __attribute__((always_inline)) {
     int vS, vC;
     lane_offsets(vS, vC);
     const int nt = tile % ntiles, mt = (tile / ntiles) % mtiles, g = tile / (ntiles * mtiles);
-    int Nv = N, w0 = first * (BM * BN * 4);
-    asm volatile("" : "+s"(Nv), "+s"(w0));   // (opaque: the scalar offsets below are not to be hoisted out of the loop)
+    int Nv = N;
+    asm volatile("" : "+s"(Nv));   // (opaque: the 64 scalar offsets below are not to be hoisted out of the loop)
     const int s0 = ((g * M + mt * BM) * Nv + nt * BN) * 4;   // (G M N floats < 2^29: gemm_bf16x3_ok)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          float o[4];
-          if (nparts > 0) {
-            u32x4 v[X3_MAX_SPLIT];
-#pragma unroll
-            for (int pt = 0; pt < X3_MAX_SPLIT; ++pt)
-              if (pt < nparts)
-                v[pt] = __builtin_amdgcn_raw_buffer_load_b128(rsS, vS, w0 + pt * (BM * BN * 4) + ((i * 2 + j) * 4 + r4) * (512 * 16), 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              o[e] = __uint_as_float(v[0][e]);
-#pragma unroll
-              for (int pt = 1; pt < X3_MAX_SPLIT; ++pt)
-                if (pt < nparts) o[e] += __uint_as_float(v[pt][e]);
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * r4 + e];
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * r4 + e;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[e]), rsC, vC, s0 + ((i * 32 + (r & 3) + 8 * (r >> 2)) * Nv + j * 32) * 4, 0);
-          }
-        }
+        for (int r = 0; r < 16; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rsC, vC,
+                                                s0 + ((i * 32 + (r & 3) + 8 * (r >> 2)) * Nv + j * 32) * 4, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-  };
-  volatile uint32_t* word = (volatile uint32_t*)(lds + NST * STAGE_B);
-  auto hand_barrier = [&]() __attribute__((always_inline)) {   // (the raw barrier does not wait for this wave's LDS store of the word)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
-  // one part of a left-over tile is done: three barriers on every path (the loaders run the same number)
-  auto hand_off = [&](int tile) __attribute__((always_inline)) {
-    uint32_t* cnt = counters + (size_t)(q / S) * X3_FLAG_STRIDE;
-    put_slab(q);
-    hand_barrier();                                   // 1
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      *word = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    hand_barrier();                                   // 2
-    const bool last = *word == (uint32_t)(S - 1);     // every part is published: the tile is this workgroup's to finish
-    if (last && tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all S have drawn: zero for the next launch
-    }
-    hand_barrier();                                   // 3
-    if (last) store_tile(tile, q - part, S);
   };
   // one stage: barrier (unit c + 1 landed, the loaders may refill the buffer of unit c - 1), the 24 MFMAs of unit c in
   // the order al bh, am bh, am bm, ah bh, ah bm, ah bl, and the fragments of unit c + 1:
@@ -465,8 +411,8 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     stage(c, X3Yes());
     for (int v = 1; v < n; ++v) stage(c + v, X3No());
     c += n;
-    if (whole || S == 1) store_tile(tile, 0, 0);
-    else hand_off(tile);
+    if (whole || S == 1) store_tile(tile);
+    else put_slab(q);   // slab q = S x (left-over tile) + part
   }
 }
 
@@ -475,6 +421,27 @@ bool gemm_bf16x3_ok(int G, int64_t M, int N, int K) {
          (int64_t)G * M * K * 4 < ((int64_t)1 << 32) &&
          (int64_t)3 * G * N * K * 2 < ((int64_t)1 << 32) && (M / BM) * (int64_t)(N / BN) * G * (K / BK) < 0x7fffffff &&
          (int64_t)G * M * N < ((int64_t)1 << 29);
+}
+
+// The left-over tiles of gemm_bf16x3_kernel: tile t = slab[S t] + slab[S t + 1] + ... in that order.  A slab holds the
+// accumulators of a 256 x 128 tile in register order: float4 index ((i 2 + j) 4 + r4) 512 + wave 64 + lane = rows
+// wm 64 + i 32 + 8 r4 + 4 (lane >> 5) + 0..3, column wn 64 + j 32 + (lane & 31) (wm = wave >> 1, wn = wave & 1).
+// Grid: 32 workgroups of 256 per left-over tile.
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slab, float* __restrict__ C, int G, int M, int N,
+                                                        int S, int first_tile) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int t = blockIdx.x >> 5, e = (blockIdx.x & 31) * 256 + threadIdx.x;   // left-over tile, float4 of its slab
+  const f32x4* s = (const f32x4*)(slab + (size_t)t * S * (BM * BN)) + e;
+  f32x4 v = s[0];
+  for (int p = 1; p < S; ++p) v += s[(size_t)p * (BM * BN / 4)];
+  const int lane = e & 63, wave = (e >> 6) & 7, r4 = (e >> 9) & 3, ij = e >> 11;
+  const int mtiles = M / BM, ntiles = N / BN, tile = first_tile + t;
+  const int nt = tile % ntiles, mt = (tile / ntiles) % mtiles, g = tile / (ntiles * mtiles);
+  const int row = mt * BM + (wave >> 1) * 64 + (ij >> 1) * 32 + 8 * r4 + 4 * (lane >> 5);
+  const int col = nt * BN + (wave & 1) * 64 + (ij & 1) * 32 + (lane & 31);
+  float* c = C + ((int64_t)g * M + row) * N + col;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c[(int64_t)k * N] = v[k];
 }
 
 // workgroups of the launch: one per CU, or one per tile when there are fewer tiles
@@ -489,35 +456,61 @@ int gemm_bf16x3_workgroups(int G, int M, int N) {
   const int64_t tiles = (int64_t)(M / BM) * (N / BN) * G;
   return (int)(tiles < cus ? tiles : cus);
 }
-size_t gemm_bf16x3_workspace_bytes() {   // a slab and a counter per workgroup
-  return (size_t)X3_MAX_WG * BM * BN * sizeof(float) + (size_t)X3_MAX_WG * X3_FLAG_STRIDE * sizeof(uint32_t);
+size_t gemm_bf16x3_workspace_bytes() {   // a slab per workgroup
+  return (size_t)X3_MAX_WG * BM * BN * sizeof(float);
 }
 
-// ws: gemm_bf16x3_workspace_bytes() bytes, zeroed once when allocated (the kernel leaves the counters zero); one per
-// stream of launches (a plan's launches are ordered on its stream)
+// the tiles left over after the whole rounds (R of them, the first is tile `first`), cut in k into S parts of an equal, even
+// number of at least eight stages; S = 1: not cut
+static void x3_leftover(int G, int M, int N, int K, int P, int* R, int* S, int* first) {
+  const int tiles = (M / BM) * (N / BN) * G, nk = K / BK;
+  *R = tiles % P;
+  *first = tiles - *R;
+  int s = 1;
+  if (*R) {
+    s = P / *R;
+    if (s > X3_MAX_SPLIT) s = X3_MAX_SPLIT;
+    if (s > nk / 8) s = nk / 8;
+    while (s > 1 && (nk % (2 * s)) != 0) --s;
+    if (s < 1) s = 1;
+  }
+  *S = s;
+}
+bool gemm_bf16x3_needs_sum(int G, int M, int N, int K) {
+  int R, S, first;
+  x3_leftover(G, M, N, K, gemm_bf16x3_workgroups(G, M, N), &R, &S, &first);
+  return R && S > 1;
+}
+int launch_gemm_bf16x3_sum(float* C, int G, int M, int N, int K, const void* ws, hipStream_t s) {
+  int R, S, first;
+  x3_leftover(G, M, N, K, gemm_bf16x3_workgroups(G, M, N), &R, &S, &first);
+  if (!(R && S > 1)) return 0;
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)(R * 32)), dim3(256), 0, s, (const float*)ws, C, G, M, N, S, first);
+  KD_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ws: gemm_bf16x3_workspace_bytes() bytes (the slabs of the left-over tiles' parts); one per stream of launches (a plan's
+// launches are ordered on its stream)
 // a_f32: A is plain fp32 [G][M][K] (split by the kernel's loader waves) instead of three planes
-int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, int N, int K, void* ws, hipStream_t s, bool a_f32) {
+// with_sum = false: the caller launches launch_gemm_bf16x3_sum behind it (where gemm_bf16x3_needs_sum)
+int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, int N, int K, void* ws, hipStream_t s, bool a_f32,
+                       bool with_sum) {
   KD_REQUIRE(gemm_bf16x3_ok(G, M, N, K), "bf16x3 GEMM needs M % 256 == 0, N % 128 == 0, K % 32 == 0 and operand planes < 4 GB");
   KD_REQUIRE((((uintptr_t)A3 | (uintptr_t)B3 | (uintptr_t)ws) & 15) == 0 && ws, "bf16x3 GEMM needs 16-byte aligned operand planes and a workspace");
   const int P = gemm_bf16x3_workgroups(G, M, N);
   KD_REQUIRE(P <= X3_MAX_WG, "bf16x3 GEMM: more workgroups than the workspace holds");
-  // the tiles left over after the whole rounds, cut in k into S parts of at least eight stages
-  const int tiles = (M / BM) * (N / BN) * G, R = tiles % P, nk = K / BK;
-  int S = 1;
-  if (R) {
-    S = P / R;
-    if (S > X3_MAX_SPLIT) S = X3_MAX_SPLIT;
-    if (S > nk / 8) S = nk / 8;
-    if (S < 1) S = 1;
-  }
+  int R, S, first;
+  x3_leftover(G, M, N, K, P, &R, &S, &first);
   float* slab = (float*)ws;
-  uint32_t* counters = (uint32_t*)((char*)ws + (size_t)X3_MAX_WG * BM * BN * sizeof(float));
   if (a_f32)
     hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C, G, M, N,
-                       K, S, slab, counters);
+                       K, S, slab);
   else
     hipLaunchKernelGGL(gemm_bf16x3_kernel<false>, dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C, G, M, N,
-                       K, S, slab, counters);
+                       K, S, slab);
+  KD_HIP_CHECK(hipGetLastError());
+  if (with_sum && R && S > 1) hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)(R * 32)), dim3(256), 0, s, slab, C, G, M, N, S, first);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

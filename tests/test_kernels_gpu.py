@@ -286,8 +286,9 @@ def test_gemm_bf16x3_matches_fp64(lib, device, G, M, N, K, scale_b, a_planes):
 
 
 def test_gemm_bf16x3_two_launches_sharing_the_chip_do_not_depend_on_each_other(lib, device):
-    """The parts of a left-over tile meet through slabs and a ticket counter and never wait for one another, so two such
-    launches on different streams (two plans of a grid run) may share the CUs in any interleaving: same bits as alone."""
+    """No workgroup of the persistent kernel waits for another (the k-parts of a left-over tile leave their accumulators in
+    slabs of the launch's own workspace, a second launch adds them), so two such launches on different streams (two plans of
+    a grid run) may share the CUs in any interleaving: same bits as alone."""
     import threading
 
     E = _E()
