@@ -260,13 +260,17 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
       ++ic;
       if (++ik == ik1 && ++iseg < nseg) locate();
     };
-    for (int j = 0; j < 3 && ic < T; ++j) issue_next();
-    if (T > 2) wait_vm<18>(); else if (T > 1) wait_vm<9>(); else wait_vm<0>();
+    // four units ahead: unit c + 4 goes into the buffer of unit c, whose fragments were all read during stage c - 1
+    for (int j = 0; j < NST && ic < T; ++j) issue_next();
+    if (T > 3) wait_vm<27>(); else if (T > 2) wait_vm<18>(); else if (T > 1) wait_vm<9>(); else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     for (int c = 0; c < T; ++c) {   // the barriers of the computing waves' stages, one for one
-      if (c + 2 < T) wait_vm<9>(); else wait_vm<0>();   // unit c + 1 landed (unit c + 2 may be in flight)
+#ifndef X3_EXP_NOWAIT   // (timing experiment of profiles/README.md: the loaders do not wait for their DMAs - wrong results)
+      // unit c + 1 landed (units c + 2, c + 3 may be in flight)
+      if (c + 3 < T) wait_vm<18>(); else if (c + 2 < T) wait_vm<9>(); else wait_vm<0>();
+#endif
       __builtin_amdgcn_s_barrier();
-      if (ic < T) issue_next();   // into the buffer of unit c - 1, whose fragments were read before unit c ran
+      if (ic < T) issue_next();
     }
     return;
   }
@@ -341,13 +345,16 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
         __builtin_amdgcn_sched_barrier(0);
       }
   };
-  // one stage: barrier (unit c + 1 landed, the loaders may refill the buffer of unit c - 1), the 24 MFMAs of unit c in
+  // one stage: barrier (unit c + 1 landed, the loaders may refill the buffer of unit c), the 24 MFMAs of unit c in
   // the order al bh, am bh, am bm, ah bh, ah bm, ah bl, and the fragments of unit c + 1:
-  //   behind group 0:  al <- c + 1 (in place: the product is done with it);  bl <- c (put off from the last stage - it is
-  //                    used by the last group; nothing is read behind group 5, the wait in front of group 0 would expose
-  //                    it);  ah, bh <- c + 1 into a second pair of registers
+  //   behind group 0:  al <- c + 1 (in place: the product is done with it);  ah, bh, bl <- c + 1 into second registers (the
+  //                    last group still needs them; nothing is read behind group 5, the wait in front of group 0 would
+  //                    expose it)
   //   behind group 2:  am <- c + 1 (in place)          behind group 4:  bm <- c + 1 (in place)
-  //   behind group 5:  the second pair moves into ah, bh (sixteen register moves under the last MFMAs)
+  //   behind group 5:  the second registers move into ah, bh, bl (24 register moves under the last MFMAs)
+  // All of unit c + 1 is read during stage c, so the loaders may refill its buffer one stage later: a ring of four buffers,
+  // the DMAs FOUR units ahead (with bl read one stage late - in place - they ran three ahead, and the computing waves spent
+  // 13 % of a launch at the barrier waiting for DMAs to land)
   // so every operand read in place has at least three groups of MFMAs between its read and its next use, and the two
   // operands every group needs - the high pieces - a whole stage.  (A second set for all six operands, 48 registers more,
   // does not fit the 168 of a lane at three waves per SIMD once the loop carries the schedule's state; with all six read
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
   // FRESH: the first unit of a segment - its first MFMAs take a zero C operand (a separate copy of the stage: a branch
   // inside it costs a conservative lgkmcnt(0) behind the reads that follow the first group)
   Frags f;
-  bf16x8 ahn[2], bhn[2];
+  bf16x8 ahn[2], bhn[2], bln[2];
   auto stage = [&](int c, auto FRESH) __attribute__((always_inline)) {
     __builtin_amdgcn_s_barrier();
     constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 0, 1, 0, 1, 2};
@@ -368,13 +375,13 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[PA[0]][i], f.b[PB[0]][j], decltype(FRESH)::value ? zero : acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_a(f, c + 1, 2);
-    read_b(f, c, 2);
     {
       const int so = ((c + 1) & (NST - 1)) * STAGE_B;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         ahn[i] = *(const bf16x8*)(fa + so + i * 32 * ROWB);
         bhn[i] = *(const bf16x8*)(fb + so + i * 32 * ROWB);
+        bln[i] = *(const bf16x8*)(fb + so + 2 * BN * ROWB + i * 32 * ROWB);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -396,6 +403,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     for (int i = 0; i < 2; ++i) {
       f.a[0][i] = ahn[i];
       f.b[0][i] = bhn[i];
+      f.b[2][i] = bln[i];
     }
   };
   __builtin_amdgcn_s_barrier();
