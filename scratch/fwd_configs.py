@@ -3,7 +3,7 @@
 #   unet1c  train.py:30-41            base 64x64 seg-cond (text dim 3, 4 cond channels)  (configs[1])
 #   unet2   train_ultra_res.py:39-48  SR 64->256                           (configs[2], the headline)
 #   unet3   train_ultra_res.py:51-60  SR 256->1024                         (configs[3] stage 3)
-# usage: python scratch/fwd_configs.py <name> <batch> [size]
+# usage: python scratch/fwd_configs.py <name> <batch> [size] [wino43_min_cin] [gemm_bf16x3]
 import sys, time, ctypes as C, torch
 sys.path.insert(0, 'kidney-diffusion_amd')
 import imagen_pytorch as ip
@@ -35,6 +35,10 @@ with torch.device('meta'):
 u = u.to_empty(device=dev)
 for p in u.parameters():
     torch.nn.init.normal_(p, std=0.02)
+if len(sys.argv) > 4:
+    u.wino43_min_cin = int(sys.argv[4])
+if len(sys.argv) > 5:
+    u.gemm_bf16x3 = int(sys.argv[5])
 with_text = bool(kw.get('cond_on_text'))
 t0 = time.time(); h = u.engine(B, S, dev, with_text=with_text)
 print(name, 'B', B, 'S', S, 'plan %.1f s' % (time.time() - t0), 'hbm GB %.1f' % (lib.kd_unet_hbm_bytes(h) / 1e9),
