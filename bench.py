@@ -126,7 +126,7 @@ def kernel_classes(lib, handle, iters=3):
     for _, label, macs, us, mfma in rows:
         us, macs, mfma = float(us), int(macs), int(mfma)
         total_us += us
-        m = re.match(r"(wino_in|wino_out|wino gemm|wino4_in|wino4_out|wino4 gemm bf16x3|wino4 gemm) M(\d+) Cin(\d+) Cout(\d+)", label)
+        m = re.match(r"(wino_in|wino_out|wino gemm|wino4_in3|wino4_in|wino4_out|wino4 gemm bf16x3|wino4 gemm) M(\d+) Cin(\d+) Cout(\d+)", label)
         if label.startswith("conv k3"):
             add("conv_buf_kernel: direct 3x3 convs", us, 2.0 * macs, 2.0 * mfma)
         elif label.startswith("wino fused"):
@@ -139,10 +139,14 @@ def kernel_classes(lib, handle, iters=3):
             cls[WINO4_X3][1] += us
         elif m and m.group(1) == "wino4 gemm":
             add(WINO4, us, 2.0 * macs, 2.0 * mfma)
-        elif m and m.group(1).startswith("wino4"):  # transforms move 3.25x the map: read 1x / write 2.25x (in), the reverse (out)
-            ch = int(m.group(3)) if m.group(1) == "wino4_in" else int(m.group(4))
+        elif m and m.group(1).startswith("wino4"):
+            # per pixel and channel: the input transform reads the map once (4 B) and writes V, 2.25 values: 9 B as fp32,
+            # 13.5 B as the three bf16 planes of the bf16x3 GEMM (6 B per value); the output transform reads D (9 B) and
+            # writes the map (4 B)
+            ch = int(m.group(4)) if m.group(1) == "wino4_out" else int(m.group(3))
+            per = {"wino4_in": 13.0, "wino4_in3": 17.5, "wino4_out": 13.0}[m.group(1)]
             add("wino4_in_kernel + wino4_out_kernel (Winograd F(4x4,3x3) transforms, GroupNorm/FiLM/SiLU and statistics fused)", us,
-                nbytes=13.0 * int(m.group(2)) * ch)
+                nbytes=per * int(m.group(2)) * ch)
         elif m:  # transforms move 5x the map: read 1x / write 4x (in), read 4x / write 1x (out)
             ch = int(m.group(3)) if m.group(1) == "wino_in" else int(m.group(4))
             add("wino_in_kernel + wino_out_kernel (Winograd transforms)", us, nbytes=20.0 * int(m.group(2)) * ch)
@@ -214,16 +218,15 @@ def host_cpu_info():
     return dict(model=model, logical=logical, physical=physical, affinity=affinity, cgroup_quota=quota, threads=threads)
 
 
-CPU_BATCH = 8
 PARITY_TOL = 2e-5   # rel-L2 of one UNet forward, engine vs CPU fp32 oracle (the tolerance the full-size tests state)
 CPU_K0 = 125   # schedule index of the CPU baseline's first step: mid-schedule, where the UNet output drives x_(t-1)
 
 
 def cpu_baseline(unet_product, timed_steps=3):
-    """The oracle (CPU fp32 torch restatement of the reference's path) timed on this host: one warm-up step at the
-    headline batch 16, then `timed_steps` timed steps of p_sample at batch 8 (half the headline batch) with injected
-    noise; steps/s is scaled to batch 16.  Returns (json entry, inputs and outputs of the WARM-UP step for the parity
-    check against the engine - batch 16, the plan that was timed)."""
+    """The oracle (CPU fp32 torch restatement of the reference's path) timed on this host AT THE HEADLINE BATCH (16): one
+    warm-up step (also the parity reference: the engine's plan depends on the batch) and `timed_steps` timed steps of
+    p_sample with injected noise - about 12 s each on the box's 16 threads.  Returns (json entry, inputs and outputs of
+    the warm-up step for the parity check against the engine)."""
     from oracle import imagen_ref as R
     from oracle import sampler_ref as RS
 
@@ -234,10 +237,6 @@ def cpu_baseline(unet_product, timed_steps=3):
     ou.eval()
     oim = RS.Imagen([R.NullUnet(), ou], image_sizes=(64, SIZE), timesteps=(T_SCHED, T_SCHED),
                     pred_objectives=("noise", "noise"), condition_on_text=False)
-    # warm-up step at the HEADLINE batch (16): not timed, it is the reference of the parity check (the engine's plan
-    # depends on the batch - Winograd F(4x4,3x3) layers need whole 128-row tile slabs -, so the check runs the very
-    # plan that was timed); then `timed_steps` steps at batch 8 (half the work per step keeps the run bounded)
-    b = CPU_BATCH
     x16, lowres16, lowres_noise16, cond16 = synthetic_inputs(BATCH)
     sched = oim.noise_schedulers[1]
     lowres16 = oim.lowres_noise_schedule.q_sample(lowres16, torch.full((BATCH,), 0.2), lowres_noise16)
@@ -267,21 +266,24 @@ def cpu_baseline(unet_product, timed_steps=3):
         x_next, x0, noise, dt = step(x16, lowres16, cond16, CPU_K0)
         dts.append(dt)
         first = dict(x=x16, noise=noise, lowres=lowres16, cond=cond16, x_next=x_next, pred=preds[0], x0=x0)
-        x, lowres, cond = x_next[:b], lowres16[:b], cond16[:b]
+        x = x_next
         for k in range(CPU_K0 + 1, CPU_K0 + 1 + timed_steps):
-            x, _, _, dt = step(x, lowres, cond, k)
+            x, _, _, dt = step(x, lowres16, cond16, k)
             dts.append(dt)
     timed = dts[1:]
-    sec_per_step_b16 = (sum(timed) / len(timed)) * (BATCH / b)
-    entry = {"value": 1.0 / sec_per_step_b16, "unit": "denoising-steps/s (batch 16)", "cores": info["threads"],
+    sec_per_step = sum(timed) / len(timed)
+    quota = info["cgroup_quota"]
+    entry = {"value": 1.0 / sec_per_step, "unit": "denoising-steps/s (batch 16)", "cores": info["threads"],
              "kind": "port",
              "cpu_model": info["model"],
              "host": {k: info[k] for k in ("logical", "physical", "affinity", "cgroup_quota")},
-             "sample": f"oracle p_sample (UNet forward + x0 / dynamic threshold / posterior / noise) on CPU at batch {b} "
-                       f"(half the headline batch), 1 warm-up at batch {BATCH} ({dts[0]:.2f} s; the parity reference) + {len(timed)} timed steps "
-                       f"({', '.join(f'{d:.2f}' for d in timed)} s), mean scaled x{BATCH // b} to batch 16; "
-                       f"torch {torch.__version__} oneDNN fp32, torch.set_num_threads({info['threads']}) = "
-                       f"min(physical cores, affinity, cgroup quota)"}
+             "sample": f"oracle p_sample (UNet forward + x0 / dynamic threshold / posterior / noise) on CPU at the headline batch "
+                       f"{BATCH}: 1 warm-up step ({dts[0]:.2f} s; the parity reference) + {len(timed)} timed steps "
+                       f"({', '.join(f'{d:.2f}' for d in timed)} s), mean; torch {torch.__version__} oneDNN fp32, "
+                       f"torch.set_num_threads({info['threads']}) = min(physical cores, affinity, cgroup quota): "
+                       + (f"{info['threads']} threads = the CPU quota of this box's cgroup, on a host of {info['physical']} "
+                          f"physical cores - NOT all host cores, which the box is not given"
+                          if quota and quota < info["physical"] else f"all {info['physical']} physical cores of the host")}
     return entry, first
 
 
@@ -461,10 +463,17 @@ def grid_workload(args, world, rank, device, distributed, barrier, canvases_list
         if canv is not None:
             assert all(torch.isfinite(c).all() for c in canv)
             assert all(tuple(c.shape[-2:]) == (1024 + (n - 1) * geom.out_patch_dist,) * 2 for c in canv)
+        per_rank = None
         if distributed:
             tmax = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
+            # what each rank did in the last grid of the timed region: so that a scaling curve explains itself
+            mine = {k: xstats.get(k) for k in ("tasks_this_rank", "idle_waves_this_rank", "recv_wait_stream_s_this_rank",
+                                               "recv_wait_host_s_this_rank", "p2p_bytes_sent_by_this_rank",
+                                               "p2p_batches_posted_by_this_rank")}
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
         patches = len(pos) * ncan * steps
         orient = [G.choose_orientation(pos)] * ncan
         waves = D.merged_waves([pos] * ncan, orient)
@@ -494,6 +503,11 @@ def grid_workload(args, world, rank, device, distributed, barrier, canvases_list
                            "final_gather_bytes_per_rank": xstats.get("final_gather_bytes_per_rank", 0),
                            "blocking_syncs_per_job": xstats.get("blocking_collectives", 0),
                            "gather": args.grid_gather,
+                           "waves": xstats.get("waves"),
+                           "per_rank": per_rank,
+                           "per_rank_note": "tasks, generalised waves without a task (idle slots), seconds the rank's stream "
+                                            "stood in receive waits (HIP events around each wait; host seconds under gloo), "
+                                            "bytes sent and batches posted - of the last grid of the timed region",
                            "at_8_ranks": {"p2p_strip_bytes_per_canvas": plan8[8].p2p_bytes(0.25) / ncan,
                                           "p2p_messages": plan8[8].p2p_messages(),
                                           "whole_patch_allgather_bytes_per_canvas_round3": sum(
@@ -512,6 +526,75 @@ def grid_workload(args, world, rank, device, distributed, barrier, canvases_list
                                    "host-side inpaint-tensor assembly, all-gathers and idle wave slots)"},
         })
     return results if rank == 0 else None
+
+
+OTHER_CONFIGS = [   # (name, what, Unet kwargs, batch, image size): the UNets of the other BASELINE configs, at full dims
+    ("configs[0]", "unconditional base UNet 64x64 at batch 1 (train_uncond.py:30-36; the sample_uncond.py:49-55 path)",
+     dict(dim=256, dim_mults=(1, 2, 4, 8), cond_dim=512, num_resnet_blocks=3, layer_attns=(F_, T_, T_, T_),
+          layer_cross_attns=(F_, T_, T_, T_), lowres_cond=False, cond_on_text=False, text_embed_dim=None), 1, 64),
+    ("configs[1]", "segmentation-conditioned base UNet 64x64 at batch 16 (train.py:30-41: 4 cond channels, text dim 3; "
+                   "the sample_cond.py:40-48 path)",
+     dict(dim=256, dim_mults=(1, 2, 3, 4), cond_dim=512, text_embed_dim=3, num_resnet_blocks=3, layer_attns=(F_, T_, T_, T_),
+          layer_cross_attns=(F_, T_, T_, T_), cond_images_channels=4, lowres_cond=False, cond_on_text=True), 16, 64),
+    ("configs[3] stage 3", "unet3 256->1024 at batch 8 (train_ultra_res.py:51-60): 96 % of a cascade's work",
+     dict(**ULTRA_UNETS[3], lowres_cond=True, cond_on_text=False, text_embed_dim=None), 8, 1024),
+]
+
+
+def other_configs(device, lib, iters=2):
+    """One UNet forward of the other BASELINE configurations at the reference's dims (random-init weights built in
+    HBM): device ms by HIP events on the launch stream, the direct-convolution-equivalent and the issued TFLOP/s,
+    launches per forward.  A forward, not a sampler step (no x0 / quantile / update: < 1 % of these steps)."""
+    import gc
+
+    import imagen_pytorch as ip
+    from imagen_pytorch import _engine as E
+
+    out = []
+    for name, what, kw, B, S in OTHER_CONFIGS:
+        with torch.device("meta"):
+            u = ip.Unet(**kw)
+        u = u.to_empty(device=device)
+        gen = torch.Generator(device=device).manual_seed(7)
+        with torch.no_grad():
+            for p_ in u.parameters():
+                p_.normal_(0, 0.02, generator=gen)
+        with_text = bool(kw.get("cond_on_text"))
+        h = u.engine(B, S, device, with_text=with_text)
+        cc = kw.get("cond_images_channels", 0)
+        x = torch.randn(B, 3, S, S, device=device, generator=gen)
+        lr = torch.randn(B, 3, S, S, device=device, generator=gen) if kw["lowres_cond"] else None
+        cond = torch.rand(B, cc, S, S, device=device, generator=gen) if cc else None
+        t = torch.full((B,), 0.3, device=device)
+        tl = torch.full((B,), -1.0, device=device) if kw["lowres_cond"] else None
+        tok = hid = None
+        if with_text:
+            te = torch.tensor([0.0, 0.5, 0.2], device=device).reshape(1, 1, 3).repeat(B, 1, 1)   # sample_cond.py:37
+            tok, hid = u.text_cond(h, te, None, False, device)
+        y = torch.empty_like(x)
+
+        def fwd():
+            E.check(lib.kd_unet_forward(h, E.ptr(x), E.ptr(lr), E.ptr(cond), E.ptr(t), E.ptr(tl), E.ptr(tok), E.ptr(hid),
+                                        E.ptr(y), E.current_stream()))
+
+        fwd()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(iters):
+            fwd()
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / iters
+        assert torch.isfinite(y).all(), name
+        macs, issued, bf = lib.kd_unet_macs(h), lib.kd_unet_mfma_macs(h), lib.kd_unet_mfma_bf16_macs(h)
+        out.append({"config": name, "what": what, "batch": B, "image_size": S, "forward_ms": ms,
+                    "gmac_per_sample": macs / 1e9 / B, "direct_equiv_tflops": 2.0 * macs / ms / 1e9,
+                    "issued_fp32_mfma_tflops": 2.0 * issued / ms / 1e9, "issued_bf16_mfma_tflops": 2.0 * bf / ms / 1e9,
+                    "launches": lib.kd_unet_num_launches(h), "plan_hbm_gb": lib.kd_unet_hbm_bytes(h) / 1e9})
+        del h, u, x, lr, cond, y
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
 
 
 def rccl_ranks(distributed, backend, device):
@@ -580,7 +663,9 @@ def main():
                     help="sr: Unet.wino43_min_cin (0 = the plan's default rule; 512 = the rule of the fp32 MFMA GEMMs)")
     ap.add_argument("--no-line-grid", action="store_true",
                     help="sr: leave the nested `grid` object (8x8 grid patches/s for 1 and 3 canvases) out of the line")
-    ap.add_argument("--line-grid-steps", type=int, default=4, help="timesteps per stage of the nested grid runs")
+    ap.add_argument("--line-grid-steps", type=int, default=8, help="timesteps per stage of the nested grid runs")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="sr: leave `other_configs` (one forward of configs[0], [1] and unet3 at batch 8) out of the line")
     args = ap.parse_args()
     grid = args.workload == "grid"
     if args.steps is None:
@@ -695,7 +780,10 @@ def main():
         E.check(lib.kd_sample_build_cond_table(handle, C.byref(sc), C.byref(sa), 0, T_SCHED, 1, C.byref(built), E.current_stream()))
         ms = float(lib.kd_unet_cond_table_build_ms(handle, C.byref(rows), C.byref(runs)))
         cond_build = {"ms": ms, "rows": int(built.value), "schedule_steps": T_SCHED,
-                      "runs_of_the_conditioning_ops": int(runs.value)}
+                      "runs_of_the_conditioning_ops": int(runs.value),
+                      # > 0: the table was refused (size cap = 1/8 of the free HBM, or the allocation failed) and the
+                      # timed steps computed their conditioning themselves
+                      "refused_bytes": int(lib.kd_unet_cond_table_refused_bytes(handle))}
 
     # the >= 6x target of BASELINE.json is patch throughput of the 8x8 grid: measured by the same command, after the
     # timed region of the headline metric, on every rank (collective inside); 1 canvas (dependency bound 4.27x at 8
@@ -703,6 +791,10 @@ def main():
     grid_res = None
     if not args.no_line_grid:
         grid_res = grid_workload(args, world, rank, device, distributed, barrier, [1, 3], args.line_grid_steps, 1, 1)
+
+    others = None
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        others = other_configs(device, lib)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -790,6 +882,8 @@ def main():
                     "schedule_speedup_bound": r["config"]["schedule_speedup_bound"],
                     "exchange": r["config"]["exchange"],
                     "mfma_frac_per_gpu": r["roofline"]["frac"]} for r in grid_res}}
+        if others:
+            out["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             cpu, first = cpu_baseline(unet)
             out["cpu_baseline"] = cpu

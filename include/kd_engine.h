@@ -33,6 +33,13 @@ extern "C" {
 #define KD_MAX_LEVELS 8
 
 const char* kd_last_error(void);
+/* ABI version of this header: bumped whenever an entry point changes its arguments or a struct its layout, so that a
+ * caller built against an older header can refuse the library instead of passing short structs.  History:
+ *   1  rounds 1-3
+ *   2  round 4/5: kd_conv3x3_winograd4_nhwc gained `gemm_bf16x3` (before `stream`); kd_unet_config_t gained
+ *      `gemm_bf16x3`, kd_sample_args_t `cond_table_max_mb`; kd_unet_cond_table_refused_bytes added;
+ *      kd_unet_cond_table_build_ms takes a non-const handle (it reads the build's events on demand) */
+#define KD_ENGINE_ABI_VERSION 2
 int kd_version(void);
 /* sha256 prefix (16 hex digits) of the sources this binary was compiled from (csrc/build_id.py); a build with
  * EXTRA flags carries the suffix "+experiment".  The Python binding refuses a library whose id differs from
@@ -144,7 +151,11 @@ int kd_unet_num_cond_launches(const kd_unet_t* u);
  * conditioning-table build, < 0 if none was built
  * yet.  Rows are built on demand for the schedule steps a call walks, B steps per run of the conditioning ops (their rows
  * are independent over the batch): T / B runs for a whole schedule. */
-float kd_unet_cond_table_build_ms(const kd_unet_t* u, int* rows, int* runs);
+float kd_unet_cond_table_build_ms(kd_unet_t* u, int* rows, int* runs);
+/* > 0: the last sampling call wanted a conditioning table of this many bytes and did not get it (larger than
+ * kd_sample_args_t::cond_table_max_mb / an eighth of the free HBM, or the allocation failed): its steps then compute
+ * the conditioning themselves - same results, more launches per step */
+int64_t kd_unet_cond_table_refused_bytes(const kd_unet_t* u);
 
 /* Step-invariant text conditioning (the text branch of Unet.forward; reached by the
  * reference through sample_cond.py:36-48 / sample.py:51-60): text_to_cond, null-embedding select,

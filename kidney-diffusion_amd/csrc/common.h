@@ -140,8 +140,8 @@ __device__ __forceinline__ void x3_split(const float __attribute__((ext_vector_t
 }
 bool gemm_bf16x3_ok(int G, int64_t M, int N, int K);   // M % 256 == 0, N % 128 == 0, K % 32 == 0, planes < 4 GB
 int launch_split3(const float* x, void* planes, int G, int R, int K, hipStream_t s);   // x [G][R][K] -> 3 G R K bf16
-// ws: gemm_bf16x3_workspace_bytes() bytes (slabs and arrival words of the stream-K hand-offs), zeroed once when allocated;
-// one per stream of launches
+// ws: gemm_bf16x3_workspace_bytes() bytes (the slabs of the left-over tiles' k-parts; no initial contents needed); one per
+// stream of launches
 size_t gemm_bf16x3_workspace_bytes();
 // a_f32: A is plain fp32 [G][M][K], split into its planes by the kernel's loader waves on the way into LDS
 // The tiles left over after the whole rounds of the persistent kernel are cut in k; their parts' accumulators are added by a

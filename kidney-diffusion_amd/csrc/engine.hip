@@ -200,7 +200,10 @@ struct kd_unet {
   std::vector<char> cond_tab_row_ok;   // [T]: rows are built on demand, for the steps a call walks
   float cond_tab_build_ms = -1.f;    // device time and row count of the last build (kd_unet_cond_table_build_ms)
   int cond_tab_build_rows = 0, cond_tab_build_runs = 0;
-  void* x3_ws = nullptr;   // workspace of the bf16x3 GEMMs' hand-offs (launch_gemm_bf16x3), allocated with the first such layer
+  hipEvent_t cond_ev0 = nullptr, cond_ev1 = nullptr;   // around the last build; read lazily (cond_ev_pending)
+  bool cond_ev_pending = false;
+  int64_t cond_tab_refused_bytes = 0;   // > 0: the last sampling call wanted a table of this size and the cap / allocator refused
+  void* x3_ws = nullptr;   // slabs of the bf16x3 GEMMs' left-over tiles (launch_gemm_bf16x3), allocated with the first such layer
 
   float* P(size_t off) const { return (float*)((off & COND_FLAG) ? cond_ws + (off & ~COND_FLAG) : ws + off); }
   ~kd_unet() {
@@ -212,6 +215,8 @@ struct kd_unet {
       if (p) (void)hipFree(p);
     if (s_tables_pinned) (void)hipHostFree(s_tables_pinned);
     if (s_tables_ev) (void)hipEventDestroy(s_tables_ev);
+    if (cond_ev0) (void)hipEventDestroy(cond_ev0);
+    if (cond_ev1) (void)hipEventDestroy(cond_ev1);
   }
 };
 
@@ -908,17 +913,14 @@ struct Builder {
         const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
         if (x3_planes) return launch_wino4_in3(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s);
         return launch_wino4_in(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s);
-      }, "wino4_in" + shape);
+      }, (x3_planes ? "wino4_in3" : "wino4_in") + shape);
     }
     if (x3) {
       const float* U3 = cached("wino4x3:" + conv_prefix, ((size_t)36 * Cout * Cin * 3 + 1) / 2,
                                [&](float* dst) { KD_THROW_IF(launch_split3(U, dst, 36, Cout, Cin, 0)); });
       const size_t vo = V.off, d_o = D.off;
       const int64_t macs = (int64_t)Bx * HW * Cout * Cin * 9;   // the algorithmic MACs of the 3x3 conv it replaces
-      if (!u->x3_ws) {
-        KD_HIP_THROW(hipMalloc(&u->x3_ws, gemm_bf16x3_workspace_bytes()));
-        KD_HIP_THROW(hipMemset(u->x3_ws, 0, gemm_bf16x3_workspace_bytes()));
-      }
+      if (!u->x3_ws) KD_HIP_THROW(hipMalloc(&u->x3_ws, gemm_bf16x3_workspace_bytes()));
       emit([=](hipStream_t s) { return launch_gemm_bf16x3(uu->P(vo), U3, uu->P(d_o), 36, (int)Mt, Cout, Cin, uu->x3_ws, s, !x3_planes, false); },
            "wino4 gemm bf16x3" + shape, macs);
       u->macs += macs;

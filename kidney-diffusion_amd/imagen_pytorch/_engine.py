@@ -115,6 +115,7 @@ SIGNATURES = {
     "kd_unet_num_launches": (C.c_int, [C.c_void_p]),
     "kd_unet_num_cond_launches": (C.c_int, [C.c_void_p]),
     "kd_unet_cond_table_build_ms": (C.c_float, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "kd_unet_cond_table_refused_bytes": (C.c_int64, [C.c_void_p]),
     "kd_unet_text_cond": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "kd_unet_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_void_p]),
@@ -144,6 +145,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2   # KD_ENGINE_ABI_VERSION of include/kd_engine.h
 
 
 def lib_path() -> Path:
@@ -165,6 +167,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here means the .so is stale
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.kd_version() != ABI_VERSION:   # structs and argument lists of this binding follow ONE header version
+        raise EngineUnavailable(f"{path} speaks ABI version {lib.kd_version()}, this binding {ABI_VERSION} "
+                                "(KD_ENGINE_ABI_VERSION of include/kd_engine.h)")
     _check_build_id(lib, path)
     _lib = lib
     return lib

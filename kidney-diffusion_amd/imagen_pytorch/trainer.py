@@ -147,12 +147,56 @@ class ImagenTrainer(nn.Module):
 
     @torch.no_grad()
     def sample(self, *args, **kwargs):
+        """`ImagenTrainer.sample` (sample_uncond.py:49-55, sample_cond.py:40-48): EMA weights, the trainer's device.
+        `max_batch_size` splits the call the way the library's `imagen_sample_in_chunks` does: `batch_size` (or the
+        leading dimension of the batched tensor arguments) is cut into chunks of at most `max_batch_size`, every
+        tensor argument whose leading dimension equals the batch is cut alongside, and the outputs are joined in
+        order (tensors concatenated, PIL lists chained, per-unet lists joined per unet)."""
         kwargs.setdefault("device", self.device)
         max_batch_size = kwargs.pop("max_batch_size", None)
-        if exists(max_batch_size):
-            raise NotImplementedError("max_batch_size chunking is not used by the reference's samplers")
         with self.use_ema_unets():
+            if not exists(max_batch_size):
+                return self.imagen.sample(*args, **kwargs)
+            return self._sample_in_chunks(int(max_batch_size), *args, **kwargs)
+
+    def _sample_in_chunks(self, max_batch_size, *args, **kwargs):
+        assert max_batch_size >= 1
+        if self.imagen.unconditional:
+            batch_size = kwargs.get("batch_size")
+            if batch_size is None:   # positional form of the library: sample(texts, text_masks, ..., batch_size at 14)
+                batched = [a for a in list(args) + list(kwargs.values()) if torch.is_tensor(a) and a.dim() > 0]
+                batch_size = batched[0].shape[0] if batched else 1
+        else:
+            batched = [a for a in list(args) + list(kwargs.values()) if torch.is_tensor(a) and a.dim() > 0]
+            assert batched, "a text-conditioned sample() needs its text embeddings"
+            batch_size = batched[0].shape[0]
+        sizes = [max_batch_size] * (batch_size // max_batch_size)
+        if batch_size % max_batch_size:
+            sizes.append(batch_size % max_batch_size)
+        if len(sizes) <= 1:
             return self.imagen.sample(*args, **kwargs)
+
+        def cut(v, n0, n1):
+            return v[n0:n1] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == batch_size else v
+
+        seed = kwargs.get("seed")
+        outs, n0 = [], 0
+        for k, b in enumerate(sizes):
+            kw = {name: cut(v, n0, n0 + b) for name, v in kwargs.items()}
+            if "batch_size" in kw or self.imagen.unconditional:
+                kw["batch_size"] = b
+            if seed is not None:   # a seeded call stays reproducible and its chunks draw different noise
+                kw["seed"] = int(seed) + 1000003 * k
+            outs.append(self.imagen.sample(*[cut(a, n0, n0 + b) for a in args], **kw))
+            n0 += b
+        first = outs[0]
+        if torch.is_tensor(first):
+            return torch.cat(outs, dim=0)
+        if isinstance(first, (list, tuple)) and first and torch.is_tensor(first[0]):   # return_all_unet_outputs
+            return [torch.cat([o[i] for o in outs], dim=0) for i in range(len(first))]
+        if isinstance(first, (list, tuple)) and first and isinstance(first[0], (list, tuple)):   # ... as PIL lists per unet
+            return [[im for o in outs for im in o[i]] for i in range(len(first))]
+        return [im for o in outs for im in o]   # PIL images
 
     # ---- training surface (out of scope)
     def _no_training(self, *a, **k):

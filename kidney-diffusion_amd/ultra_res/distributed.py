@@ -10,10 +10,13 @@ patch's three neighbours are done and publish results through a `Manager().dict(
     the bottom rows of the patch above, the facing columns of the patch beside it, the facing corner of
     the diagonal one; <= 3.1 MB each at stage 3) - so a finished patch stays on the rank that sampled it and
     only those strips travel, point to point, to the <= 3 ranks that consume them (`ExchangePlan`: the whole
-    deal is a pure function of the grid, so every rank knows every message in advance).  A rank posts the
-    sends and receives of a wave in one asynchronous batch when its wave is done and waits for a bundle only
-    when a task that needs it is about to start: there is no barrier between waves (RCCL send/recv over xGMI on
-    the GPU node, gloo in the CPU tests);
+    deal is a pure function of the grid, so every rank knows every message in advance).  When its wave is done a
+    rank posts the sends and receives of that wave, one asynchronous batch per peer in an order all ranks share,
+    and waits for a bundle only when a task that needs it is about to start: there is no barrier between waves
+    (RCCL send/recv over xGMI on the GPU node, gloo in the CPU tests).  Under RCCL a batch is one group kernel
+    that completes when the peer has posted its side and the batches of one rank run in posting order, so a
+    consumer waits for its producer and for the peers of the batches this rank posted before that one - not for
+    every peer of the wave; `ExchangePlan.makespan` does not model that residual coupling (free exchange);
   * ONE all-gather of equal-sized slabs after the last wave gives every rank the final-stage patches of the
     whole canvas (SURVEY.md §8e; the north star's "RCCL all-gather to reassemble the stitched canvas");
   * several canvases can be scheduled together: their waves are merged, which is what lifts the
@@ -32,6 +35,7 @@ sampling (the HIP engine through `Imagen.sample` in production, a deterministic 
 """
 from __future__ import annotations
 
+import time
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -341,12 +345,34 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
                 waited[id(w)] = w
                 w.wait()
 
+    # how long this rank stood in receive waits: host time (gloo: the wait blocks the thread) and, where the exchange
+    # lives in HBM, the stall of the stream between two events around the wait (RCCL: the wait is a stream dependency)
+    x_cuda = world > 1 and device is not None and torch.device(device).type == "cuda"
+    wait_host_s = 0.0
+    wait_events = []
+    batches_posted = 0
+    idle_waves = 0
+
+    def timed_wait(works):
+        nonlocal wait_host_s
+        ev0 = None
+        if x_cuda:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(torch.device(device)))
+        t0 = time.perf_counter()
+        wait_all(works)
+        wait_host_s += time.perf_counter() - t0
+        if x_cuda:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record(torch.cuda.current_stream(torch.device(device)))
+            wait_events.append((ev0, ev1))
+
     def receive(src: int, g: int):
         rec = pending.pop((src, g), None)
         if rec is None:
             return
         works, buf, items = rec
-        wait_all(works)
+        timed_wait(works)
         off = 0
         for it in items:
             sh = _item_shape(it, overlap)
@@ -363,6 +389,8 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
 
     for g, wave in enumerate(plan.waves):
         mine = plan.parts[g][rank]
+        if not mine and wave:
+            idle_waves += 1   # a generalised wave in which other ranks sample and this one has nothing to do
         results: Dict[int, List[torch.Tensor]] = {}
         groups = []
         for st in sorted({t[0] for t in mine}, reverse=True):   # heaviest stage first
@@ -396,26 +424,35 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
                 local[(st, c, i, j)] = o.to(dev).float()
         if world == 1:
             continue
-        # this wave's exchange, posted in one batch and not waited for here: my strips to their consumers, and
-        # the strips other ranks produced in this wave that tasks of mine will consume later
-        ops, recvs, sends = [], [], []
-        for (src, dst), items in sorted(plan.bundles[g].items()):
-            if src == rank:
-                flat = torch.cat([_cut_item(it, local[it[1]], overlap, orientations[it[1][1]]).reshape(-1)
-                                  for it in items])
-                sent_bytes += flat.numel() * 4
-                ops.append(dist.P2POp(dist.isend, flat, dst if group is None else dist.get_global_rank(group, dst), group))
-                sends.append(flat)
-            elif dst == rank:
-                n = sum(plan.item_numel(it, overlap) for it in items)
-                ref = next(iter(local.values())) if local else None
-                dev = device if device is not None else (ref.device if ref is not None else torch.device("cpu"))
-                buf = torch.empty(n, device=dev, dtype=torch.float32)
-                ops.append(dist.P2POp(dist.irecv, buf, src if group is None else dist.get_global_rank(group, src), group))
-                recvs.append((src, buf, items))
-        if ops:
+        # this wave's exchange, not waited for here: ONE asynchronous batch per peer (my strips to it and the strips it
+        # produced in this wave that tasks of mine will consume later).  Under RCCL a batch is one group kernel that
+        # completes when the peer has posted its side, so a batch per PEER lets a consumer wait for its producer
+        # alone - a single batch per wave would complete with its slowest peer.  Every rank posts its batches in the
+        # same total order (wave, low rank, high rank): the globally smallest unfinished batch is at the head of both
+        # its ranks' queues, so the order cannot deadlock (groups on one communicator run in posting order)
+        by_pair: Dict[Tuple[int, int], list] = {}
+        for (src, dst), items in plan.bundles[g].items():
+            if rank in (src, dst):
+                by_pair.setdefault((min(src, dst), max(src, dst)), []).append((src, dst, items))
+        for pair in sorted(by_pair):
+            ops, recvs, sends = [], [], []
+            for src, dst, items in sorted(by_pair[pair], key=lambda e: e[:2]):   # low -> high first, on both sides
+                if src == rank:
+                    flat = torch.cat([_cut_item(it, local[it[1]], overlap, orientations[it[1][1]]).reshape(-1)
+                                      for it in items])
+                    sent_bytes += flat.numel() * 4
+                    ops.append(dist.P2POp(dist.isend, flat, dst if group is None else dist.get_global_rank(group, dst), group))
+                    sends.append(flat)
+                else:
+                    n = sum(plan.item_numel(it, overlap) for it in items)
+                    ref = next(iter(local.values())) if local else None
+                    dev = device if device is not None else (ref.device if ref is not None else torch.device("cpu"))
+                    buf = torch.empty(n, device=dev, dtype=torch.float32)
+                    ops.append(dist.P2POp(dist.irecv, buf, src if group is None else dist.get_global_rank(group, src), group))
+                    recvs.append((src, buf, items))
             works = dist.batch_isend_irecv(ops)
-            if len(works) == len(ops):   # one handle per operation (gloo): a consumer waits for its receive alone
+            batches_posted += 1
+            if len(works) == len(ops):   # one handle per operation (gloo)
                 k = 0
                 for op, w in zip(ops, works):
                     if op.op is dist.irecv:
@@ -458,6 +495,13 @@ def sample_grids(sample_fn: Callable, stages: Sequence[int], patch_pos: Sequence
                 for n, (c, p) in enumerate(lst):
                     own[c][index[c][p]] = parts_[r][n]
     if stats is not None:
+        wait_stream_s = 0.0
+        if wait_events:
+            torch.cuda.synchronize(torch.device(device))
+            wait_stream_s = sum(a.elapsed_time(b) for a, b in wait_events) * 1e-3
+        stats.update(recv_wait_host_s_this_rank=wait_host_s, recv_wait_stream_s_this_rank=wait_stream_s,
+                     recv_waits_this_rank=len(wait_events) if x_cuda else None, idle_waves_this_rank=idle_waves,
+                     tasks_this_rank=sum(len(p[rank]) for p in plan.parts), p2p_batches_posted_by_this_rank=batches_posted)
         stats.update(p2p_bytes_total=plan.p2p_bytes(overlap), p2p_messages_total=plan.p2p_messages(),
                      p2p_bytes_sent_by_this_rank=sent_bytes, final_gather_bytes_per_rank=gather_bytes,
                      blocking_collectives=int(world > 1 and gather in ("all", "root")), waves=len(plan.waves),

@@ -57,10 +57,14 @@ def generate_high_res_image(sample_fn: Callable, zoomed_image: torch.Tensor, mag
     return G.stitch_canvas(out, pos, geom, background=zoomed_image.to(out[0].device), patch_size=out[0].shape[-1])
 
 
-def generate_mag0_image(sample_fn: Callable, stages: Sequence[int] = (1, 2, 3), group=None) -> torch.Tensor:
+def generate_mag0_image(sample_fn: Callable, stages: Sequence[int] = (1, 2, 3), group=None,
+                        device: Optional[torch.device] = None) -> torch.Tensor:
     """`generate_image(0, args)` (sample_ultra_res.py:264-270, :463): ONE unconditional sample through the stages -
     no conditioning image, no patch position and therefore no inpainting tensors (:88-91, :149).  Under
-    torch.distributed rank 0 samples and broadcasts, so every rank starts the grid levels from the same image."""
+    torch.distributed rank 0 samples and broadcasts, so every rank starts the grid levels from the same image.
+    `device`: where the image lives on every rank.  The broadcast needs the SAME kind of tensor on every rank: device
+    memory under RCCL (backend "nccl" has no CPU tensors), host memory under gloo - so the ranks that did not sample
+    allocate their receive buffer there, and rank 0 moves its sample there first."""
     multi = dist.is_initialized() and dist.get_world_size(group) > 1
     img = None
     if not multi or dist.get_rank(group) == 0:
@@ -68,13 +72,19 @@ def generate_mag0_image(sample_fn: Callable, stages: Sequence[int] = (1, 2, 3), 
             img = sample_fn(st, [(0, 0, 0)], [img], [None], [None], [None])[0]
     if multi:
         shape = (3, G.PATCH_SIZES[stages[-1]], G.PATCH_SIZES[stages[-1]])
-        if img is None:
-            img = torch.empty(shape, dtype=torch.float32)
-        buf = img.float().contiguous()
         if dist.get_backend(group) == "gloo":
-            buf = buf.cpu()
+            xdev = torch.device("cpu")
+        elif device is not None:
+            xdev = torch.device(device)
+        elif img is not None and img.is_cuda:
+            xdev = img.device
+        else:
+            xdev = torch.device("cuda", torch.cuda.current_device())
+        buf = torch.empty(shape, dtype=torch.float32, device=xdev) if img is None else img.to(xdev).float().contiguous()
         dist.broadcast(buf, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
         img = buf
+    if device is not None:
+        img = img.to(device)
     return img[None]
 
 
@@ -87,9 +97,7 @@ def generate_all_levels(sample_fns: Dict[int, Callable], overlap: float = 0.25, 
     mask; kidney: 53x53 candidates, canvas 40960^2).  `sample_fns[level]` samples with that level's models (the
     reference loads `--unet{n}_mag{level}` checkpoints, :36-63).  `patch_filter(level, positions)` may thin a level's
     positions (tests, partial regeneration).  Returns the three images, each (1,3,W,W)."""
-    mag0 = generate_mag0_image(sample_fns[0], group=group)
-    if device is not None:
-        mag0 = mag0.to(device)
+    mag0 = generate_mag0_image(sample_fns[0], group=group, device=device)
     out = [mag0]
     for level in (1, 2):
         pos = None

@@ -19,7 +19,8 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
-EXCLUDE = ("pack_", "copyBuffer", "fillBuffer", "wino_pack")
+# (split3_kernel: the once-per-plan split of the F(4x4,3x3) weights into bf16x3 planes - plan build, not a step)
+EXCLUDE = ("pack_", "copyBuffer", "fillBuffer", "wino_pack", "split3_kernel")
 
 
 def per_kernel(path, counter):

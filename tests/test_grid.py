@@ -537,3 +537,50 @@ def test_outpaint_canvas_equals_the_reference_loop_in_row_major_order():
         G.PATCH_SIZES.clear()
         G.PATCH_SIZES.update(old)
     assert got.shape == want.shape and torch.equal(got, want)
+
+
+def _worker_batches(rank, world, port, out):
+    """Records every batch_isend_irecv call of the run: its wave-independent signature (the peers of its operations)."""
+    import torch.distributed as dist
+
+    real = dist.batch_isend_irecv
+    calls = []
+
+    def spy(ops):
+        calls.append(sorted({op.peer for op in ops}))
+        return real(ops)
+
+    D.dist.batch_isend_irecv = spy
+    try:
+        _run_grid8(world, rank, port, None, "all")
+    finally:
+        D.dist.batch_isend_irecv = real
+    out[rank] = calls
+
+
+def test_exchange_posts_one_batch_per_peer_in_the_order_every_rank_shares():
+    """a batch per (src, dst) pair, not one per wave - under RCCL a batch completes with its slowest
+    peer.  Every call carries the operations of exactly one peer, and the calls of a rank follow the plan's
+    (wave, low rank, high rank) order, which is what makes the order deadlock-free on one communicator."""
+    world = 4
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = mp.Manager().dict()
+    mp.spawn(_worker_batches, args=(world, port, out), nprocs=world, join=True)
+    old = dict(G.PATCH_SIZES)
+    G.PATCH_SIZES.update({1: 8, 2: 16, 3: 32})
+    try:
+        pos8 = [(i, j) for i in range(8) for j in range(8)]
+        pos5 = [(i, j) for i in range(5) for j in range(5) if (i, j) not in ((0, 0), (1, 3), (2, 2), (4, 0))]
+        plan = D.ExchangePlan([pos8, pos5], [-1, 1], (1, 2, 3), world, True, None)
+    finally:
+        G.PATCH_SIZES.clear()
+        G.PATCH_SIZES.update(old)
+    for r in range(world):
+        want = []
+        for g in range(len(plan.waves)):
+            pairs = sorted({(min(s_, d), max(s_, d)) for (s_, d) in plan.bundles[g] if r in (s_, d)})
+            want.extend([[a if b == r else b] for a, b in pairs])
+        assert out[r] == want, r
+        assert all(len(c) == 1 for c in out[r])

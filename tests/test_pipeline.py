@@ -180,3 +180,72 @@ def test_three_level_chain_is_mag0_then_two_grid_levels(small_patches):
     assert len(pos2) > 7
     want2 = P.generate_high_res_image(_sample_fn, mag1.clone(), 2, overlap=0.25, patch_pos=pos2[:7])
     assert torch.equal(mag2, want2) and mag2.shape[-1] == geom2.canvas_width
+
+
+def _chain_fns():
+    def fn0(stage, tasks, lows, conds, ips, ims):
+        S = G.PATCH_SIZES[stage]
+        base = torch.linspace(0, 1, S * S).reshape(1, S, S).repeat(3, 1, 1) * (0.5 + 0.1 * stage)
+        if lows[0] is not None:
+            base = base + 0.3 * F.interpolate(lows[0][None], S, mode="nearest")[0]
+        return [base]
+
+    def fn1(stage, tasks, lows, conds, ips, ims):
+        outs = _sample_fn(stage, tasks, lows, conds, ips, ims)
+        for t, o in zip(tasks, outs):
+            if (t[1] + t[2]) % 6 == 0:
+                o[:] = torch.tensor([0.75, 0.35, 0.8])[:, None, None]
+        return outs
+
+    return {0: fn0, 1: fn1, 2: _sample_fn}
+
+
+def _chain(world, rank=0, port=None, out=None):
+    import os
+
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    old_ps, old = G.PATCH_SIZE, dict(G.PATCH_SIZES)
+    G.PATCH_SIZE = 32
+    G.PATCH_SIZES.update({1: 8, 2: 16, 3: 32})
+    try:
+        fns = _chain_fns()
+        if world > 1 and rank != 0:   # only rank 0 samples the mag-0 image: the others must get it by broadcast
+            def never(*a, **k):
+                raise AssertionError("mag 0 is sampled on rank 0 alone")
+            fns[0] = never
+        keep = lambda level, pos: pos if level == 1 else pos[:7]
+        res = P.generate_all_levels(fns, overlap=0.25, patch_filter=keep, device=torch.device("cpu"))
+        if out is not None:
+            out[rank] = res
+        return res
+    finally:
+        G.PATCH_SIZE = old_ps
+        G.PATCH_SIZES.clear()
+        G.PATCH_SIZES.update(old)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+
+
+def _chain_worker(rank, world, port, out):
+    _chain(world, rank, port, out)
+
+
+def test_three_level_chain_on_two_gloo_ranks_equals_single_process():
+    """`generate_all_levels` under torch.distributed: rank 0 samples the mag-0 image, every rank receives it
+    into a buffer of the backend's kind (host memory under gloo, the rank's device under RCCL) and the two grid levels
+    run sharded; both ranks end with the images of one process, bit for bit."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    single = _chain(1)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = mp.Manager().dict()
+    mp.spawn(_chain_worker, args=(2, port, out), nprocs=2, join=True)
+    for r in range(2):
+        for got, want in zip(out[r], single):
+            assert got.shape == want.shape and torch.equal(got, want), r

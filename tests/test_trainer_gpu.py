@@ -68,6 +68,32 @@ def test_trainer_load_and_sample_use_the_ema_weights(device, tmp_path):
     assert (got2.cpu() - ref_ema).abs().max() < SAMPLE_ABS
 
 
+def test_trainer_sample_in_chunks_of_max_batch_size(device):
+    """`trainer.sample(max_batch_size=)` - the library's imagen_sample_in_chunks: the batch is cut into chunks of at most
+    that size, batched tensor arguments alongside, outputs joined in order."""
+    import imagen_pytorch as ip
+
+    oim, pim = _pair(device, seed=8, T=3)
+    trainer = ip.ImagenTrainer(imagen=pim, use_ema=False)
+    nf = RS.generator_noise_fn(21)
+    want = torch.cat([oim.sample(noise_fn=nf, batch_size=b) for b in (2, 2, 1)])
+    got = trainer.sample(batch_size=5, max_batch_size=2, noise_fn=nf)
+    assert got.shape == want.shape and (got.cpu() - want).abs().max() < SAMPLE_ABS
+    # batched tensor arguments are cut with the batch: inpainting a known half
+    inp = torch.rand(3, 3, 16, 16, generator=torch.Generator().manual_seed(3))
+    mask = torch.zeros(3, 16, 16)
+    mask[:, :, :8] = 1
+    want = torch.cat([oim.sample(noise_fn=nf, batch_size=b, inpaint_images=inp[a:a + b], inpaint_masks=mask[a:a + b],
+                                 inpaint_resample_times=2) for a, b in ((0, 2), (2, 1))])
+    got = trainer.sample(batch_size=3, max_batch_size=2, noise_fn=nf, inpaint_images=inp.to(device),
+                         inpaint_masks=mask.to(device), inpaint_resample_times=2)
+    assert (got.cpu() - want).abs().max() < SAMPLE_ABS
+    assert torch.equal(got.cpu()[:, :, :, :8], inp[:, :, :, :8])   # known pixels are pasted back exactly
+    # a chunk size that covers the batch is a plain call
+    one = trainer.sample(batch_size=2, max_batch_size=4, noise_fn=nf)
+    assert (one.cpu() - oim.sample(noise_fn=nf, batch_size=2)).abs().max() < SAMPLE_ABS
+
+
 def test_deepcopy_and_pickle_of_a_live_unet_drop_the_engine(device):
     _, pim = _pair(device)
     u = pim.unets[0]
