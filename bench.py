@@ -43,6 +43,9 @@ WINO4 = ("conv_buf_kernel: the 36 position GEMMs of Winograd F(4x4,3x3) - the Re
 WINO4_X3 = ("gemm_bf16x3_kernel: the 36 position GEMMs of Winograd F(4x4,3x3) - the ResnetBlock 3x3 convs with Cin >= 512 - as "
             "fp32 products on the bf16 matrix pipe (three bf16 pieces per fp32 operand, six exact products per k-step, fp32 "
             "accumulation; LDS-DMA ring fed by loader waves)")
+LIN_X3 = ("gemm_bf16x3_kernel, epilogue form: attention projections, feed-forward and 1x1 convs with K >= 512 as fp32 products "
+          "on the bf16 matrix pipe (fp32 activations split by the kernel's loader waves; bias / residual / gate epilogue)")
+CONV_CLASS = "conv_buf_kernel / conv_igemm_kernel / init_conv_kernel: 1x1, 2x2-s2, init and final convs, token GEMMs"
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix = vector peak (v_mfma_f32_32x32x2_f32, exact fp32)
 # dense bf16 matrix peak (MI355X_MICROARCH.md "~2.5 PF dense": v_mfma_f32_32x32x16_bf16 at 32 cycles per SIMD, 1024 CU-SIMDs,
 # 2.4 GHz).  The bf16x3 GEMMs (kernels_gemm_bf16x3.hip) issue SIX bf16 MACs per fp32 MAC: their fp32-equivalent ceiling is
@@ -127,7 +130,11 @@ def kernel_classes(lib, handle, iters=3):
         us, macs, mfma = float(us), int(macs), int(mfma)
         total_us += us
         m = re.match(r"(wino_in|wino_out|wino gemm|wino4_in3|wino4_in|wino4_out|wino4 gemm bf16x3|wino4 gemm) M(\d+) Cin(\d+) Cout(\d+)", label)
-        if label.startswith("conv k3"):
+        if label.startswith("conv k1 x3 sum"):   # the k-parts of the tiles added and the epilogue applied: time of the same GEMMs
+            cls[LIN_X3][1] += us
+        elif label.startswith("conv k1 x3"):     # `mfma` = bf16 MACs (6 per fp32 MAC)
+            add(LIN_X3, us, 2.0 * macs, 2.0 * mfma)
+        elif label.startswith("conv k3"):
             add("conv_buf_kernel: direct 3x3 convs", us, 2.0 * macs, 2.0 * mfma)
         elif label.startswith("wino fused"):
             add(DOMINANT, us, 2.0 * macs, 2.0 * mfma)
@@ -155,14 +162,13 @@ def kernel_classes(lib, handle, iters=3):
             add("linear_skinny_mfma_kernel (time MLPs, GlobalContext FCs: weight-bandwidth / latency bound)", us,
                 nbytes=4.0 * int(mk.group(2)) * int(mk.group(3)) if mk else 0.0)
         elif label.startswith("conv") or label.startswith("init conv"):
-            add("conv_buf_kernel / conv_igemm_kernel / init_conv_kernel: 1x1, 2x2-s2, init and final convs, token GEMMs", us,
-                2.0 * macs, 2.0 * (mfma or macs))
+            add(CONV_CLASS, us, 2.0 * macs, 2.0 * (mfma or macs))
         else:
             add("GroupNorm, LayerNorm, attention core, GlobalContext, concat, gate (HBM-bound)", us, nbytes=hbm_bytes(label))
     out = []
     for key, (n, us, flop, issued, nbytes) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
         e = {"kernel": key, "launches": n, "ms": us / 1e3, "avg_us": us / n, "share": us / total_us}
-        if flop and key == WINO4_X3:
+        if flop and key in (WINO4_X3, LIN_X3):
             e.update(bound="mfma", achieved=issued / us / 1e6, unit="TFLOP/s (bf16 MFMA)", peak=BF16_PEAK_TFLOPS,
                      frac=issued / us / 1e6 / BF16_PEAK_TFLOPS, achieved_fp32_equiv=issued / 6.0 / us / 1e6,
                      achieved_direct_equiv=flop / us / 1e6, issued_tflop_per_step=issued / 1e12)
@@ -173,6 +179,14 @@ def kernel_classes(lib, handle, iters=3):
         elif nbytes:
             e.update(bound="hbm", achieved=nbytes / us / 1e3, unit="GB/s", peak=8000.0, frac=nbytes / us / 1e3 / 8000.0)
         out.append(e)
+    # the class VERDICT r4 item 1 tracks: every 1x1 / 2x2-s2 / init / final conv and token GEMM, whichever kernel runs it
+    both = [e for e in out if e["kernel"] in (CONV_CLASS, LIN_X3)]
+    if len(both) == 2:
+        out.append({"kernel": "1x1 / 2x2-s2 / init / final convs and token GEMMs, both kernels together (the two entries above)",
+                    "launches": sum(e["launches"] for e in both), "ms": sum(e["ms"] for e in both),
+                    "share": sum(e["share"] for e in both),
+                    "achieved_fp32_equiv": sum(e.get("achieved_fp32_equiv", e.get("achieved", 0.0)) * e["ms"] for e in both)
+                    / sum(e["ms"] for e in both), "unit": "TFLOP/s of fp32-equivalent work"})
     return out
 
 

@@ -37,7 +37,7 @@ const char* kd_last_error(void);
  * caller built against an older header can refuse the library instead of passing short structs.  History:
  *   1  rounds 1-3
  *   2  round 4/5: kd_conv3x3_winograd4_nhwc gained `gemm_bf16x3` (before `stream`); kd_unet_config_t gained
- *      `gemm_bf16x3`, kd_sample_args_t `cond_table_max_mb`; kd_unet_cond_table_refused_bytes added;
+ *      `gemm_bf16x3` and `x3_linear`, kd_sample_args_t `cond_table_max_mb`; kd_unet_cond_table_refused_bytes, kd_linear_bf16x3 and kd_layernorm_ex added;
  *      kd_unet_cond_table_build_ms takes a non-const handle (it reads the build's events on demand) */
 #define KD_ENGINE_ABI_VERSION 2
 int kd_version(void);
@@ -110,6 +110,11 @@ typedef struct kd_unet_config {
    * (fp32 MFMA); 2 = as 0 with V written as fp32 and split by the GEMM's loader waves on the way into LDS (the form a GEMM
    * whose activation comes from another kernel would use; here the transform gains less than the GEMMs lose). */
   int gemm_bf16x3;
+  /* Token GEMMs and 1x1 convs (attention projections, feed-forward, skip convs without output statistics) on the same
+   * bf16x3 kernel in its epilogue form (bias / residual / gate, strided rows; the fp32 activations are split by the
+   * kernel's loader waves): 0 = default (K >= 512 input channels, rows % 256 == 0, Cout % 128 == 0, at least 64 tiles of
+   * 256 x 128; needs gemm_bf16x3 >= 0 and conv_algo == 0), n > 0 = K >= n, < 0 = never (conv_buf_kernel, fp32 MFMA). */
+  int x3_linear;
 } kd_unet_config_t;
 
 /* One named parameter tensor of the UNet's state_dict (key WITHOUT the `unets.N.` prefix,
@@ -309,6 +314,14 @@ int kd_conv3x3_winograd4_nhwc(const float* d_x, const float* d_w_oihw, const flo
  * split beforehand (the plan's form: weights once, activations by the kernel that writes them); a_planes = 0: A stays fp32
  * and is split by the kernel's loader waves on its way into LDS.  Same planes, same bits.  Needs M % 256 == 0, N % 128 == 0, K % 32 == 0, 6 G M K and 6 G N K below 2^32 bytes. */
 int kd_gemm_bf16x3(const float* d_a, const float* d_b, float* d_c, int G, int M, int N, int K, int a_planes, void* stream);
+/* The token-GEMM / 1x1-conv form of the same kernel, as the plan runs the attention projections, the feed-forward and
+ * the skip convs with K >= 512 (kd_unet_config_t::x3_linear): y[m][n] = sum_k x[m][k] w[n][k] + bias[n]
+ * (+ gate_src[m][n] gate[m / hw][n]) (+ res[m][n]), fp32 rows with strides ldx / ldres / ldgs / ldy (0 = dense), the
+ * activations split into their three bf16 pieces by the kernel's loader waves, the weights once.  Optional pointers may
+ * be NULL.  Replaces nn.Linear / 1x1 nn.Conv2d + the residual / GlobalContext-gate adds around them. */
+int kd_linear_bf16x3(const float* d_x, int ldx, const float* d_w, const float* d_bias, const float* d_res, int ldres,
+                     const float* d_gate_src, int ldgs, const float* d_gate, int hw, float* d_y, int ldy, int M, int N, int K,
+                     void* stream);
 /* ResnetBlock `Block` in one pass over x: conv3x3(SiLU(FiLM(GroupNorm_G(x)))) + bias (+ d_res), the form the
  * plan uses for those layers: statistics, a per-(image, channel) affine fold, and the fused Winograd kernel
  * with the activation applied to the raw patch in LDS (the activated map is never written).  d_scale_shift
@@ -339,6 +352,11 @@ int kd_groupnorm_silu_nhwc(const float* d_x, const float* d_gamma, const float* 
 /* LayerNorm over the last dim of [rows, C]; beta may be NULL (gain-only). */
 int kd_layernorm(const float* d_x, const float* d_g, const float* d_beta, float* d_y,
                  int rows, int C, float eps, void* stream);
+/* The forms the TransformerBlock's plan uses: y = LN(f(x)) g (+ beta) (+ res) with f = in_act (0 none, 1 SiLU, 2 GELU:
+ * FeedForward's Linear -> GELU -> LayerNorm when the GEMM stores the raw product), and, with d_g2 / d_y2 given, also
+ * y2 = LN(y) g2 in the same pass (attention's to_out LayerNorm + residual followed by the feed-forward's first). */
+int kd_layernorm_ex(const float* d_x, const float* d_g, const float* d_beta, const float* d_res, float* d_y, int rows, int C,
+                    float eps, int in_act, const float* d_g2, float* d_y2, void* stream);
 /* Attention with fp32 softmax.  q [B,Nq,H,D] (already scaled), k/v [B,Nk,Hkv,D] with
  * Hkv in {1,H}; out [B,Nq,H,D].  D must be 64. */
 int kd_attention(const float* d_q, const float* d_k, const float* d_v, float* d_out,

@@ -143,13 +143,28 @@ int launch_split3(const float* x, void* planes, int G, int R, int K, hipStream_t
 // ws: gemm_bf16x3_workspace_bytes() bytes (the slabs of the left-over tiles' k-parts; no initial contents needed); one per
 // stream of launches
 size_t gemm_bf16x3_workspace_bytes();
-// a_f32: A is plain fp32 [G][M][K], split into its planes by the kernel's loader waves on the way into LDS
-// The tiles left over after the whole rounds of the persistent kernel are cut in k; their parts' accumulators are added by a
-// second launch (launch_gemm_bf16x3_sum; with_sum = true: launched here)
+// The token-GEMM / 1x1-conv form of the kernel (G = 1): y[m][n] = sum_k a[m][k] w[n][k] + bias[n] (+ gate_src[m][n]
+// gate[m / hw][n]) (+ res[m][n]) with row strides; nullptr members are off
+struct X3Epi {
+  const float* bias = nullptr;
+  const float* res = nullptr;
+  const float* gate_src = nullptr;
+  const float* gate = nullptr;   // [images][N]
+  int ldres = 0, ldgs = 0;
+  int hw = 0;                    // rows per image (gate), a multiple of 256
+  int ldy = 0;                   // row stride of y (>= N)
+  int lda = 0;                   // row stride of an fp32 A (a_f32); plane-form A is always dense
+};
+bool gemm_bf16x3_epi_ok(int64_t M, int N, int K, const X3Epi& e);
+// a_f32: A is plain fp32 rows, split into its planes by the kernel's loader waves on the way into LDS
+// The tiles left over after the whole rounds of the persistent kernel - all tiles when there are fewer than CUs - are cut
+// in k; their parts' accumulators are added (and the epilogue applied) by a second launch (launch_gemm_bf16x3_sum;
+// with_sum = true: launched here)
 int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, int N, int K, void* ws, hipStream_t s,
-                       bool a_f32 = false, bool with_sum = true);
+                       bool a_f32 = false, bool with_sum = true, const X3Epi* epi = nullptr);
 bool gemm_bf16x3_needs_sum(int G, int M, int N, int K);
-int launch_gemm_bf16x3_sum(float* C, int G, int M, int N, int K, const void* ws, hipStream_t s);
+int launch_gemm_bf16x3_sum(float* C, int G, int M, int N, int K, const void* ws, hipStream_t s, const X3Epi* epi = nullptr);
+int gemm_bf16x3_workgroups(int G, int M, int N, int K);
 // launch_wino4_in writing V as the three planes the bf16x3 GEMM reads ([3][36][C/16][Mt][16] bf16; Mt % 8 == 0, C % 16 == 0)
 int launch_wino4_in3(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
                      const float* scale_shift, int ld_ss, void* V3, int B, int H, int W, int C, int G, hipStream_t s);
@@ -186,9 +201,11 @@ size_t gn_partial_bytes(int B, int HW, int C, int G);
 int launch_gn_apply_silu(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
                          const float* scale_shift /*row b: [scale(C) | shift(C)], row stride ld_ss; or null*/,
                          int ld_ss, float* y, int B, int HW, int C, int G, hipStream_t s);
-// y = LN(x)*g (+beta) (+res)
+// y = LN(f(x))*g (+beta) (+res), f = in_act (ACT_GELU: the feed-forward's Linear -> GELU -> LayerNorm with the GEMM storing
+// the raw product); g2 / y2 != nullptr: also y2 = LN(y)*g2 (the TransformerBlock's two LayerNorms around its residual)
 int launch_layernorm(const float* x, int ldx, const float* g, const float* beta, const float* res, int ldres, float* y,
-                     int rows, int C, float eps, hipStream_t s);
+                     int rows, int C, float eps, hipStream_t s, int in_act = ACT_NONE, const float* g2 = nullptr,
+                     float* y2 = nullptr);
 // dst[row][0..C) = src[row][0..C) * scale, row strides ld_src / ld_dst (dst may be src)
 int launch_copy_scale_rows(const float* src, int ld_src, float* dst, int ld_dst, int C, float scale, int64_t rows,
                            hipStream_t s);

@@ -504,6 +504,26 @@ struct Builder {
     int seg_c0 = -1, seg_cn = 0;  // channel range of y the partial buffer spans (default: this launch's own range);
                                   // launches filling slices of one tensor name the same span and share the buffer
   };
+  // a 1x1 conv / token GEMM that runs on the bf16x3 kernel's epilogue form (kernels_gemm_bf16x3.hip)
+  bool x3_linear_ok(const T& x, int Cout, int K, int stride, int pad, const ConvOpt& o) const {
+    if (cfg.gemm_bf16x3 < 0 || cfg.conv_algo != 0 || cfg.x3_linear < 0 || to_text || to_static || to_cond) return false;
+    if (K != 1 || stride != 1 || pad != 0 || o.rowrun || o.wz_rows || o.out_mode != OUT_NHWC || o.out_external) return false;
+    if (o.act != ACT_NONE || (o.want_seg && seg_on) || (o.gate_src && o.res)) return false;
+    const int min_k = cfg.x3_linear > 0 ? cfg.x3_linear : 512;
+    if (x.C < min_k || x.C % 32 || Cout % 128) return false;
+    const int64_t M = x.rows();
+    if (M % 256 || (M / 256) * (Cout / 128) < 64) return false;   // below 64 tiles the k-parts get too short
+    X3Epi e;
+    e.lda = x.LD();
+    e.ldy = o.dst ? o.dst->LD() : Cout;
+    e.res = o.res ? (const float*)16 : nullptr;
+    e.ldres = o.res ? o.res->LD() : 0;
+    e.gate_src = o.gate_src ? (const float*)16 : nullptr;
+    e.gate = o.gate_src ? (const float*)16 : nullptr;
+    e.ldgs = o.gate_src ? o.gate_src->LD() : 0;
+    e.hw = x.H * x.W;
+    return gemm_bf16x3_epi_ok(M, Cout, x.C, e);
+  }
   T conv(const T& x, const float* w, const float* bias, int Cout, int K, int stride, int pad, const ConvOpt& o) {
     int Ho = (x.H + 2 * pad - K) / stride + 1, Wo = (x.W + 2 * pad - K) / stride + 1;
     T y;
@@ -539,6 +559,48 @@ struct Builder {
     size_t ro = has_res ? o.res->at() : 0, gso = has_gs ? o.gate_src->at() : 0, go = has_gs ? o.gate->off : 0;
     kd_unet* uu = u;
     const int res_coff = o.res_coff, o_yoff = o.yoff;
+    // ---- token GEMMs / 1x1 convs with K >= 512 as fp32 products on the bf16 matrix pipe (kernels_gemm_bf16x3.hip,
+    // epilogue form: bias / residual / gate, strided rows; weights split into planes once per plan, the fp32 activations by
+    // the kernel's loader waves).  Layers whose output statistics the epilogue would have to leave (want_seg) and
+    // activations stay on conv_buf_kernel; cfg.conv_algo != 0 (the direct-convolution plans of the tests) too
+    if (x3_linear_ok(x, Cout, K, stride, pad, o)) {
+      const int64_t M = (int64_t)x.B * Ho * Wo;
+      const int Cin = x.C;
+      const float* W3 = cached("x3lin:" + std::to_string((uintptr_t)w) + ":" + std::to_string(Cout) + "x" + std::to_string(Cin),
+                               ((size_t)Cout * Cin * 3 + 1) / 2,
+                               [&](float* dst) { KD_THROW_IF(launch_split3(w, dst, 1, Cout, Cin, 0)); });
+      if (!u->x3_ws) KD_HIP_THROW(hipMalloc(&u->x3_ws, gemm_bf16x3_workspace_bytes()));
+      X3Epi base;
+      base.bias = bias;
+      base.ldres = p.ldres;
+      base.ldgs = p.ldgs;
+      base.hw = Ho * Wo;
+      base.ldy = p.ldy;
+      base.lda = p.ldx;
+      const int yoff = p.yoff;
+      auto epi_of = [=]() {
+        X3Epi e = base;
+        e.res = has_res ? uu->P(ro) + res_coff : nullptr;
+        e.gate_src = has_gs ? uu->P(gso) : nullptr;
+        e.gate = has_gs ? uu->P(go) : nullptr;
+        return e;
+      };
+      const std::string shape = " M" + std::to_string(M) + " Cin" + std::to_string(Cin) + " Cout" + std::to_string(Cout);
+      const int64_t m = o.macs_override >= 0 ? o.macs_override : M * Cout * Cin;
+      emit([=](hipStream_t s) {
+        const X3Epi e = epi_of();
+        return launch_gemm_bf16x3(uu->P(xo), W3, uu->P(yo) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, true, false, &e);
+      }, "conv k1 x3" + shape, m);
+      u->macs += m;
+      u->op_mfma.back() = 6 * M * Cout * Cin;   // bf16 MACs
+      u->mfma_bf16_macs += u->op_mfma.back();
+      if (gemm_bf16x3_needs_sum(1, (int)M, Cout, Cin))   // every tile cut in k (fewer tiles than CUs): the parts are added, and the epilogue applied, here
+        emit([=](hipStream_t s) {
+          const X3Epi e = epi_of();
+          return launch_gemm_bf16x3_sum(uu->P(yo) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, &e);
+        }, "conv k1 x3 sum" + shape);
+      return y;
+    }
     // small-M layers (batch-1 patches): split-K scratch, released right after the launch is recorded
     // (one in-order stream: the next op that reuses the block runs after the reduction)
     const int ks = conv_ksplit(p);
@@ -642,16 +704,39 @@ struct Builder {
     if (!to_text) u->macs += (int64_t)M * K * N;
   }
 
-  T layernorm(const T& x, const float* g, const float* beta, const T* res = nullptr) {
+  // in_act: applied to x on the way in (ACT_GELU: the feed-forward's GELU when its GEMM stores the raw product);
+  // g2 / y2: a second LayerNorm of the result in the same pass (y2 = LN(y) g2)
+  T layernorm(const T& x, const float* g, const float* beta, const T* res = nullptr, int in_act = ACT_NONE,
+              const float* g2 = nullptr, T* y2 = nullptr) {
     T y = alloc(x.B, x.H, x.W, x.C);
-    size_t xo = x.at(), yo = y.off, ro = res ? res->at() : 0;
+    if (g2) *y2 = alloc(x.B, x.H, x.W, x.C);
+    size_t xo = x.at(), yo = y.off, ro = res ? res->at() : 0, y2o = g2 ? y2->off : 0;
     bool hr = res != nullptr;
     int rows = (int)x.rows(), C = x.C, ldx = x.LD(), ldres = res ? res->LD() : 0;
     kd_unet* uu = u;
     emit([=](hipStream_t s) {
-      return launch_layernorm(uu->P(xo), ldx, g, beta, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), rows, C, 1e-5f, s);
-    }, "ln rows" + std::to_string(rows) + " C" + std::to_string(C));
+      return launch_layernorm(uu->P(xo), ldx, g, beta, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), rows, C, 1e-5f, s, in_act, g2,
+                              g2 ? uu->P(y2o) : nullptr);
+    }, std::string(g2 ? "ln x2 rows" : "ln rows") + std::to_string(rows) + " C" + std::to_string(C));
     return y;
+  }
+  // would linear(x, .., N) run on the bf16x3 kernel (x3_linear_ok on the flattened rows)?
+  bool linear_is_x3(const T& x, int N, const T* res = nullptr, const T* dst = nullptr) const {
+    T xf = x;
+    xf.B = 1; xf.H = 1; xf.W = (int)x.rows();
+    ConvOpt o;
+    T rf, df;
+    if (res) {
+      rf = *res;
+      rf.B = 1; rf.H = 1; rf.W = (int)res->rows();
+      o.res = &rf;
+    }
+    if (dst) {
+      df = *dst;
+      df.B = 1; df.H = 1; df.W = (int)dst->rows();
+      o.dst = &df;
+    }
+    return x3_linear_ok(xf, N, 1, 1, 0, o);
   }
 
   // GroupNorm -> [FiLM: scale/shift rows of t_ss at column ss_col] -> SiLU as its own pass (layers the fused conv
@@ -678,7 +763,7 @@ struct Builder {
   }
   // in place on a workspace tensor: normalise (and scale) the `heads` 64-wide segments at the start of each row
   void qk_norm(const T& t, int ld, int heads, const float* scale_vec) {
-    size_t off = t.off;
+    size_t off = t.at();   // (a column slice of a wider buffer: the fused q / kv projection)
     int64_t rows = t.rows();
     kd_unet* uu = u;
     emit([=](hipStream_t s) { return launch_l2norm_heads(uu->P(off), ld, rows, heads, scale_vec, s); },
@@ -742,8 +827,26 @@ struct Builder {
     int H = cfg.attn_heads, D = cfg.attn_dim_head, inner = H * D, dim = x.C;
     std::string a = plain ? pre + ".fn.fn" : pre + ".layers.0.0", f = pre + ".layers.0.1";
     T xn = layernorm(x, P(a + ".norm.g", dim), nullptr);
-    T q = linear(xn, P(a + ".to_q.weight", (int64_t)inner * dim), nullptr, inner);
-    T kv = linear(xn, P(a + ".to_kv.weight", (int64_t)2 * D * dim), nullptr, 2 * D);
+    // to_q and to_kv read the same rows: one GEMM over the stacked weights [inner + 2 D][dim], q and k / v are column
+    // slices of its output (the attention kernel takes row strides) - one launch less and fuller tiles
+    const float* wq = P(a + ".to_q.weight", (int64_t)inner * dim);
+    const float* wkv = P(a + ".to_kv.weight", (int64_t)2 * D * dim);
+    const bool qkv1 = cfg.conv_algo == 0 && kd_switch("KD_QKV_FUSED", 1) != 0;
+    T q, kv, qkv;
+    if (qkv1) {
+      const float* wqkv = cached("qkv:" + a, (size_t)(inner + 2 * D) * dim, [&](float* dst) {
+        KD_HIP_THROW(hipMemcpyAsync(dst, wq, (size_t)inner * dim * sizeof(float), hipMemcpyDeviceToDevice, 0));
+        KD_HIP_THROW(hipMemcpyAsync(dst + (size_t)inner * dim, wkv, (size_t)2 * D * dim * sizeof(float), hipMemcpyDeviceToDevice, 0));
+      });
+      qkv = linear(xn, wqkv, nullptr, inner + 2 * D);
+      q = qkv;
+      q.C = inner; q.ld = inner + 2 * D; q.coff = 0;
+      kv = qkv;
+      kv.C = 2 * D; kv.ld = inner + 2 * D; kv.coff = inner;
+    } else {
+      q = linear(xn, wq, nullptr, inner);
+      kv = linear(xn, wkv, nullptr, 2 * D);
+    }
     free(xn);
     T ckv;
     bool has_ctx = ctx != nullptr;
@@ -759,37 +862,50 @@ struct Builder {
     }
     const float* nkv = null_kv_of(a);
     if (cfg.attn_qk_norm) {
-      qk_norm(q, inner, H, q_scale_of(a));
-      qk_norm(kv, 2 * D, 1, k_scale_of(a));
+      qk_norm(q, q.LD(), H, q_scale_of(a));
+      qk_norm(kv, kv.LD(), 1, k_scale_of(a));
     }
     T o = alloc(x.B, x.H, x.W, inner);
     {
-      size_t qo = q.off, kvo = kv.off, oo = o.off, co = has_ctx ? ckv.off : 0;
+      size_t qo = q.at(), kvo = kv.at(), oo = o.off, co = has_ctx ? ckv.off : 0;
       int Bx = x.B, N = x.HW(), Nc = has_ctx ? ctx->HW() : 0;
+      const int ldq = q.LD(), ldkv = kv.LD();
       float scale = attn_scale();
       kd_unet* uu = u;
       emit([=](hipStream_t s) {
         KVSeg s0{nullptr, nullptr, 0, 0};
         if (has_ctx) s0 = KVSeg{uu->P(co), uu->P(co) + D, 2 * D, Nc};
-        KVSeg s1{uu->P(kvo), uu->P(kvo) + D, 2 * D, N};
-        return launch_attention(uu->P(qo), inner, nkv, nkv + D, s0, s1, uu->P(oo), inner, Bx, N, H, 1, scale, s);
+        KVSeg s1{uu->P(kvo), uu->P(kvo) + D, ldkv, N};
+        return launch_attention(uu->P(qo), ldq, nkv, nkv + D, s0, s1, uu->P(oo), inner, Bx, N, H, 1, scale, s);
       }, "attn N" + std::to_string(N));
       u->macs += (int64_t)Bx * H * N * (N + Nc + 1) * D * 2;
     }
-    free(q);
-    free(kv);
+    if (qkv1) {
+      free(qkv);
+    } else {
+      free(q);
+      free(kv);
+    }
     if (has_ctx) free(ckv);
     T proj = linear(o, P(a + ".to_out.0.weight", (int64_t)dim * inner), nullptr, dim);
     free(o);
-    T x1 = layernorm(proj, P(a + ".to_out.1.g", dim), nullptr, &x);
+    if (plain) {
+      T x1 = layernorm(proj, P(a + ".to_out.1.g", dim), nullptr, &x);
+      free(proj);
+      return x1;
+    }
+    // x1 = LN(proj) g + x and the feed-forward's first LayerNorm h0 = LN(x1) g' in one pass over the rows
+    T h0;
+    T x1 = layernorm(proj, P(a + ".to_out.1.g", dim), nullptr, &x, ACT_NONE, P(f + ".0.g", dim), &h0);
     free(proj);
-    if (plain) return x1;
-    // feed forward
+    // feed forward: Linear -> GELU -> LayerNorm -> Linear.  Where the first GEMM runs on the bf16x3 kernel (no activation
+    // in its epilogue) it stores the raw product and the LayerNorm applies the GELU on the way in: the same function on the
+    // same values
     int hidden = dim * cfg.ff_mult_x2 / 2;
-    T h0 = layernorm(x1, P(f + ".0.g", dim), nullptr);
-    T h1 = linear(h0, P(f + ".1.weight", (int64_t)hidden * dim), nullptr, hidden, ACT_GELU);
+    const bool gelu_late = linear_is_x3(h0, hidden);
+    T h1 = linear(h0, P(f + ".1.weight", (int64_t)hidden * dim), nullptr, hidden, gelu_late ? ACT_NONE : ACT_GELU);
     free(h0);
-    T h2 = layernorm(h1, P(f + ".3.g", hidden), nullptr);
+    T h2 = layernorm(h1, P(f + ".3.g", hidden), nullptr, nullptr, gelu_late ? ACT_GELU : ACT_NONE);
     free(h1);
     T y = linear(h2, P(f + ".4.weight", (int64_t)dim * hidden), nullptr, dim, ACT_NONE, &x1, dst);
     free(h2);

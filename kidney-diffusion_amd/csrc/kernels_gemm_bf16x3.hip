@@ -117,10 +117,13 @@ constexpr int X3_MAX_SPLIT = 8;
 // A_F32: the A operand comes as plain fp32 [G][M][K] rows and the loader waves split it on its way into LDS (buffer_load to
 // registers two stages ahead, nine VALU operations per pair of values, ds_write_b64 of the three planes) - the producer
 // writes 4 instead of 6 bytes per element, and its writes are what bound it (kernels_wino4.hip)
-template <bool A_F32>
+// EPI: the token-GEMM / 1x1-conv form (G = 1): C rows with stride e.ldy, bias, residual, per-image gate (X3Epi, common.h);
+// A rows (A_F32) with stride e.lda.  Without it the code is that of the Winograd position GEMMs, instruction for instruction.
+template <bool A_F32, bool EPI>
 __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __restrict__ A3, const uint16_t* __restrict__ B3,
                                                           float* __restrict__ C, int G, int M, int N, int K, int S,
-                                                          float* __restrict__ slab) {
+                                                          float* __restrict__ slab, X3Epi e) {
+  const int lda = EPI ? e.lda : K, ldc = EPI ? e.ldy : N;
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE_B];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,11 +149,11 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     const int l = wave - 8;
     const uint32_t planeB = (uint32_t)((int64_t)G * N * K * 2);
     const i32x4 rsB = make_rsrc(B3, 3u * planeB);
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A3, 0, (int)((int64_t)G * M * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A3, 0, (int)((int64_t)G * M * lda * 4), 0x00020000);
     const uint32_t voffB = (uint32_t)((lane >> 1) * ROWB + (((lane & 1) ^ ((lane >> 4) & 1)) * 16));
     const uint32_t chunkB = (uint32_t)(N * ROWB);
     const int arow = l * 16 + (lane >> 2), aq = lane & 3;
-    const uint32_t voffA = (uint32_t)((arow * K + aq * 4) * 4);
+    const uint32_t voffA = (uint32_t)((arow * lda + aq * 4) * 4);
     // LDS position of the lane's 8 bytes of a plane row: 16-byte slot (aq >> 1) ^ ((row >> 3) & 1), half aq & 1
     const int ldsA = arow * ROWB + ((((aq >> 1) ^ ((arow >> 3) & 1)) * 16) + (aq & 1) * 8);
     int ic = 0, iseg = 0, ik = 0, ik1 = 0;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     auto locate = [&]() __attribute__((always_inline)) {
       const int it = seg_tile(iseg);
       const int nt = it % ntiles, mt = (it / ntiles) % mtiles, g = it / (ntiles * mtiles);
-      baseA = (uint32_t)(((int64_t)g * M + mt * BM) * K * 4);
+      baseA = (uint32_t)(((int64_t)g * M + mt * BM) * lda * 4);
       baseB = (uint32_t)((int64_t)g * N * K * 2) + (uint32_t)(nt * BN * ROWB);
       ik = iseg < rounds ? 0 : tail_k0;
       ik1 = iseg < rounds ? nk : tail_k1;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
       const int st = ic & (NST - 1);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        ra[set][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA, baseA + (uint32_t)(ik * (BK * 4)) + (uint32_t)(j * 64 * K * 4), 0);
+        ra[set][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA, baseA + (uint32_t)(ik * (BK * 4)) + (uint32_t)(j * 64 * lda * 4), 0);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int id = l * 3 + j, pl = id >> 2, pr = id & 3;
@@ -300,14 +303,14 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t rsS =
       __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, (int)((size_t)X3_MAX_WG * BM * BN * sizeof(float)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)((int64_t)G * M * N * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)((int64_t)G * M * ldc * 4), 0x00020000);
   // the lane's part of the offsets, recomputed where it is used (from an opaque copy of the lane id: two registers less
   // held across the stage loop)
   auto lane_offsets = [&](int& vS, int& vC) __attribute__((always_inline)) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
     vS = (wave * 64 + ln) * 16;
-    vC = ((wm * 64 + 4 * (ln >> 5)) * N + wn * 64 + (ln & 31)) * 4;
+    vC = ((wm * 64 + 4 * (ln >> 5)) * ldc + wn * 64 + (ln & 31)) * 4;
   };
   auto put_slab = [&](int which) __attribute__((always_inline)) {
     int vS, vC;
@@ -331,9 +334,58 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     int vS, vC;
     lane_offsets(vS, vC);
     const int nt = tile % ntiles, mt = (tile / ntiles) % mtiles, g = tile / (ntiles * mtiles);
-    int Nv = N;
+    int Nv = ldc;
     asm volatile("" : "+s"(Nv));   // (opaque: the 64 scalar offsets below are not to be hoisted out of the loop)
-    const int s0 = ((g * M + mt * BM) * Nv + nt * BN) * 4;   // (G M N floats < 2^29: gemm_bf16x3_ok)
+    const int s0 = ((g * M + mt * BM) * Nv + nt * BN) * 4;   // (G M ldc floats < 2^29: gemm_bf16x3_ok)
+    if constexpr (EPI) {
+      // y = acc + bias[col] (+ gate_src[row][col] gate[image][col]) (+ res[row][col]): a lane owns one column of each of its
+      // two 32-column blocks, so bias and the gate are two scalars per lane; the added maps come in as 4-byte loads, four
+      // per map in flight (the registers of the next tile's first fragments stay live across the epilogue)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int col0 = nt * BN + wn * 64 + (ln & 31);           // + 32 j
+      const int row0 = mt * BM + wm * 64 + 4 * (ln >> 5);       // + 32 i + 8 r4 + k
+      float bj[2] = {0.f, 0.f}, gj[2] = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (e.bias) bj[j] = e.bias[col0 + j * 32];
+        if (e.gate) gj[j] = e.gate[(int64_t)((mt * BM) / e.hw) * N + col0 + j * 32];   // (hw % 256 == 0: one image per tile)
+      }
+      const __amdgpu_buffer_rsrc_t rsR =
+          __builtin_amdgcn_make_buffer_rsrc((void*)e.res, 0, e.res ? (int)((int64_t)M * e.ldres * 4) : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsG =
+          __builtin_amdgcn_make_buffer_rsrc((void*)e.gate_src, 0, e.gate_src ? (int)((int64_t)M * e.ldgs * 4) : 0, 0x00020000);
+      const int vR = (row0 * e.ldres + col0) * 4, vG = (row0 * e.ldgs + col0) * 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            float add[4] = {0.f, 0.f, 0.f, 0.f};
+            if (e.res) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                add[k] = __uint_as_float(
+                    __builtin_amdgcn_raw_buffer_load_b32(rsR, vR, ((i * 32 + 8 * r4 + k) * e.ldres + j * 32) * 4, 0));
+            }
+            if (e.gate_src) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                add[k] = fmaf(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                  rsG, vG, ((i * 32 + 8 * r4 + k) * e.ldgs + j * 32) * 4, 0)),
+                              gj[j], add[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float v = (acc[i][j][4 * r4 + k] + bj[j]) + add[k];
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vC, s0 + ((i * 32 + 8 * r4 + k) * Nv + j * 32) * 4, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -434,26 +486,38 @@ bool gemm_bf16x3_ok(int G, int64_t M, int N, int K) {
 // The left-over tiles of gemm_bf16x3_kernel: tile t = slab[S t] + slab[S t + 1] + ... in that order.  A slab holds the
 // accumulators of a 256 x 128 tile in register order: float4 index ((i 2 + j) 4 + r4) 512 + wave 64 + lane = rows
 // wm 64 + i 32 + 8 r4 + 4 (lane >> 5) + 0..3, column wn 64 + j 32 + (lane & 31) (wm = wave >> 1, wn = wave & 1).
-// Grid: 32 workgroups of 256 per left-over tile.
+// Grid: 32 workgroups of 256 per left-over tile.  EPI: the epilogue of the token-GEMM form (X3Epi), as in the kernel.
+template <bool EPI>
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slab, float* __restrict__ C, int G, int M, int N,
-                                                        int S, int first_tile) {
+                                                        int S, int first_tile, X3Epi e) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  const int t = blockIdx.x >> 5, e = (blockIdx.x & 31) * 256 + threadIdx.x;   // left-over tile, float4 of its slab
-  const f32x4* s = (const f32x4*)(slab + (size_t)t * S * (BM * BN)) + e;
+  const int t = blockIdx.x >> 5, el = (blockIdx.x & 31) * 256 + threadIdx.x;   // left-over tile, float4 of its slab
+  const f32x4* s = (const f32x4*)(slab + (size_t)t * S * (BM * BN)) + el;
   f32x4 v = s[0];
   for (int p = 1; p < S; ++p) v += s[(size_t)p * (BM * BN / 4)];
-  const int lane = e & 63, wave = (e >> 6) & 7, r4 = (e >> 9) & 3, ij = e >> 11;
+  const int lane = el & 63, wave = (el >> 6) & 7, r4 = (el >> 9) & 3, ij = el >> 11;
   const int mtiles = M / BM, ntiles = N / BN, tile = first_tile + t;
   const int nt = tile % ntiles, mt = (tile / ntiles) % mtiles, g = tile / (ntiles * mtiles);
   const int row = mt * BM + (wave >> 1) * 64 + (ij >> 1) * 32 + 8 * r4 + 4 * (lane >> 5);
   const int col = nt * BN + (wave & 1) * 64 + (ij & 1) * 32 + (lane & 31);
-  float* c = C + ((int64_t)g * M + row) * N + col;
+  const int ldc = EPI ? e.ldy : N;
+  float* c = C + ((int64_t)g * M + row) * ldc + col;
+  if constexpr (EPI) {
+    const float b = e.bias ? e.bias[col] : 0.f;
+    const float gt = e.gate ? e.gate[(int64_t)(row / e.hw) * N + col] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float add = e.res ? e.res[(int64_t)(row + k) * e.ldres + col] : 0.f;
+      if (e.gate_src) add = fmaf(e.gate_src[(int64_t)(row + k) * e.ldgs + col], gt, add);
+      c[(int64_t)k * ldc] = (v[k] + b) + add;
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) c[(int64_t)k * N] = v[k];
 }
 
-// workgroups of the launch: one per CU, or one per tile when there are fewer tiles
-int gemm_bf16x3_workgroups(int G, int M, int N) {
+static int x3_cus() {
   static int cus = 0;
   if (!cus) {
     int dev = 0, n = 0;
@@ -461,65 +525,106 @@ int gemm_bf16x3_workgroups(int G, int M, int N) {
       n = 256;
     cus = n;
   }
-  const int64_t tiles = (int64_t)(M / BM) * (N / BN) * G;
-  return (int)(tiles < cus ? tiles : cus);
+  return cus;
+}
+
+// Shape of a launch: P persistent workgroups; `rounds` whole rounds of P tiles; the R tiles left over (the first is tile
+// `first`) are cut in k into S parts of an equal, even number of at least eight stages (S = 1: not cut), one part per
+// workgroup q < S R.  With fewer tiles than CUs (token GEMMs of the 16 x 16 level: 64-128 tiles) there is no whole round:
+// every tile is cut and P = S R <= CUs.
+static void x3_shape(int G, int M, int N, int K, int* P, int* R, int* S, int* first) {
+  const int tiles = (M / BM) * (N / BN) * G, nk = K / BK, cus = x3_cus();
+  auto split_of = [&](int r, int p) {
+    int s = p / r;
+    if (s > X3_MAX_SPLIT) s = X3_MAX_SPLIT;
+    if (s > nk / 8) s = nk / 8;
+    while (s > 1 && (nk % (2 * s)) != 0) --s;
+    return s < 1 ? 1 : s;
+  };
+  if (tiles < cus) {
+    *R = tiles;
+    *first = 0;
+    *S = split_of(tiles, cus);
+    *P = tiles * *S;
+    return;
+  }
+  *P = cus;
+  *R = tiles % cus;
+  *first = tiles - *R;
+  *S = *R ? split_of(*R, cus) : 1;
+}
+
+// workgroups of the launch
+int gemm_bf16x3_workgroups(int G, int M, int N, int K) {
+  int P, R, S, first;
+  x3_shape(G, M, N, K, &P, &R, &S, &first);
+  return P;
 }
 size_t gemm_bf16x3_workspace_bytes() {   // a slab per workgroup
   return (size_t)X3_MAX_WG * BM * BN * sizeof(float);
 }
 
-// the tiles left over after the whole rounds (R of them, the first is tile `first`), cut in k into S parts of an equal, even
-// number of at least eight stages; S = 1: not cut
-static void x3_leftover(int G, int M, int N, int K, int P, int* R, int* S, int* first) {
-  const int tiles = (M / BM) * (N / BN) * G, nk = K / BK;
-  *R = tiles % P;
-  *first = tiles - *R;
-  int s = 1;
-  if (*R) {
-    s = P / *R;
-    if (s > X3_MAX_SPLIT) s = X3_MAX_SPLIT;
-    if (s > nk / 8) s = nk / 8;
-    while (s > 1 && (nk % (2 * s)) != 0) --s;
-    if (s < 1) s = 1;
-  }
-  *S = s;
-}
 bool gemm_bf16x3_needs_sum(int G, int M, int N, int K) {
-  int R, S, first;
-  x3_leftover(G, M, N, K, gemm_bf16x3_workgroups(G, M, N), &R, &S, &first);
+  int P, R, S, first;
+  x3_shape(G, M, N, K, &P, &R, &S, &first);
   return R && S > 1;
 }
-int launch_gemm_bf16x3_sum(float* C, int G, int M, int N, int K, const void* ws, hipStream_t s) {
-  int R, S, first;
-  x3_leftover(G, M, N, K, gemm_bf16x3_workgroups(G, M, N), &R, &S, &first);
+int launch_gemm_bf16x3_sum(float* C, int G, int M, int N, int K, const void* ws, hipStream_t s, const X3Epi* epi) {
+  int P, R, S, first;
+  x3_shape(G, M, N, K, &P, &R, &S, &first);
   if (!(R && S > 1)) return 0;
-  hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)(R * 32)), dim3(256), 0, s, (const float*)ws, C, G, M, N, S, first);
+  if (epi)
+    hipLaunchKernelGGL(sum_slabs_kernel<true>, dim3((unsigned)(R * 32)), dim3(256), 0, s, (const float*)ws, C, G, M, N, S, first, *epi);
+  else
+    hipLaunchKernelGGL(sum_slabs_kernel<false>, dim3((unsigned)(R * 32)), dim3(256), 0, s, (const float*)ws, C, G, M, N, S, first,
+                       X3Epi{});
   KD_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+// the epilogue form's extra conditions (G = 1): row strides that keep every byte offset below 2^31, one image per tile
+// where a per-image gate is applied, 4-byte aligned maps
+bool gemm_bf16x3_epi_ok(int64_t M, int N, int K, const X3Epi& e) {
+  if (!gemm_bf16x3_ok(1, M, N, K)) return false;
+  if (e.lda < K || e.ldy < N || (e.lda & 3)) return false;
+  if (M * (int64_t)e.lda * 4 >= ((int64_t)1 << 31) || M * (int64_t)e.ldy >= ((int64_t)1 << 29)) return false;
+  if (e.res && (e.ldres < N || M * (int64_t)e.ldres * 4 >= ((int64_t)1 << 31))) return false;
+  if (e.gate_src && (!e.gate || e.ldgs < N || e.hw <= 0 || e.hw % BM || M * (int64_t)e.ldgs * 4 >= ((int64_t)1 << 31))) return false;
+  return true;
 }
 
 // ws: gemm_bf16x3_workspace_bytes() bytes (the slabs of the left-over tiles' parts); one per stream of launches (a plan's
 // launches are ordered on its stream)
 // a_f32: A is plain fp32 [G][M][K] (split by the kernel's loader waves) instead of three planes
 // with_sum = false: the caller launches launch_gemm_bf16x3_sum behind it (where gemm_bf16x3_needs_sum)
+// epi != nullptr: the token-GEMM / 1x1-conv form (G = 1; gemm_bf16x3_epi_ok)
 int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, int N, int K, void* ws, hipStream_t s, bool a_f32,
-                       bool with_sum) {
+                       bool with_sum, const X3Epi* epi) {
   KD_REQUIRE(gemm_bf16x3_ok(G, M, N, K), "bf16x3 GEMM needs M % 256 == 0, N % 128 == 0, K % 32 == 0 and operand planes < 4 GB");
   KD_REQUIRE((((uintptr_t)A3 | (uintptr_t)B3 | (uintptr_t)ws) & 15) == 0 && ws, "bf16x3 GEMM needs 16-byte aligned operand planes and a workspace");
-  const int P = gemm_bf16x3_workgroups(G, M, N);
+  KD_REQUIRE(!epi || (G == 1 && gemm_bf16x3_epi_ok(M, N, K, *epi) && (a_f32 || epi->lda == K)),
+             "bf16x3 GEMM, epilogue form: G = 1, row strides >= the row, byte offsets < 2^31, one image per 256-row tile under a gate");
+  int P, R, S, first;
+  x3_shape(G, M, N, K, &P, &R, &S, &first);
   KD_REQUIRE(P <= X3_MAX_WG, "bf16x3 GEMM: more workgroups than the workspace holds");
-  int R, S, first;
-  x3_leftover(G, M, N, K, P, &R, &S, &first);
   float* slab = (float*)ws;
-  if (a_f32)
-    hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C, G, M, N,
-                       K, S, slab);
-  else
-    hipLaunchKernelGGL(gemm_bf16x3_kernel<false>, dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C, G, M, N,
-                       K, S, slab);
+  const X3Epi e = epi ? *epi : X3Epi{};
+  if (epi) {
+    if (a_f32)
+      hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C,
+                         G, M, N, K, S, slab, e);
+    else
+      hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true>), dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3,
+                         C, G, M, N, K, S, slab, e);
+  } else if (a_f32) {
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C,
+                       G, M, N, K, S, slab, e);
+  } else {
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C,
+                       G, M, N, K, S, slab, e);
+  }
   KD_HIP_CHECK(hipGetLastError());
-  if (with_sum && R && S > 1) hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)(R * 32)), dim3(256), 0, s, slab, C, G, M, N, S, first);
-  KD_HIP_CHECK(hipGetLastError());
+  if (with_sum && R && S > 1) return launch_gemm_bf16x3_sum(C, G, M, N, K, ws, s, epi);
   return 0;
 }
 

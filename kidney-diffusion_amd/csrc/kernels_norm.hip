@@ -1,6 +1,7 @@
 // HBM-bound normalisation / elementwise kernels on NHWC fp32 feature maps.
 // All of them move 16 B per lane and reduce with wavefront (64-lane) shuffles.
 #include "common.h"
+#include "epilogue.h"
 
 namespace kd {
 
@@ -265,11 +266,107 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// The same with the row held in registers (C <= 256 NV floats: one wave per row, NV float4 per lane) - one read of x
+// instead of three -, an optional activation applied to x on the way in (GELU: the feed-forward's Linear -> GELU ->
+// LayerNorm, with the GEMM storing the raw product; same function on the same values as the GEMM epilogue's: bit-equal),
+// and an optional SECOND LayerNorm of the result (gain g2, output y2): the TransformerBlock's x1 = LN(proj) g + x followed
+// by h0 = LN(x1) g2 in one pass over the row.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
+                                                            const float* __restrict__ beta, const float* __restrict__ res,
+                                                            int ldres, float* __restrict__ y, int rows, int C, float eps,
+                                                            int in_act, const float* __restrict__ g2, float* __restrict__ y2) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + (int64_t)row * ldx;
+  const int C4 = C >> 2;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c4 < C4) {
+      v[i] = *(const f32x4*)(xr + c4 * 4);
+      if (in_act != ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = ep_act(v[i][e], in_act);
+      }
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  }
+  const float mean = wave_sum_f(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < C4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        ss += d * d;
+      }
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum_f(ss) / (float)C + eps);
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < C4) {
+      const f32x4 gg = *(const f32x4*)(g + c4 * 4);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gg[e];
+      if (beta) o += *(const f32x4*)(beta + c4 * 4);
+      if (res) o += *(const f32x4*)(res + (int64_t)row * ldres + c4 * 4);
+      *(f32x4*)(y + (int64_t)row * C + c4 * 4) = o;
+      v[i] = o;
+      s2 += (o[0] + o[1]) + (o[2] + o[3]);
+    }
+  }
+  if (!g2) return;
+  const float mean2 = wave_sum_f(s2) / (float)C;
+  float ss2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < C4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean2;
+        ss2 += d * d;
+      }
+    }
+  const float rstd2 = 1.0f / sqrtf(wave_sum_f(ss2) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < C4) {
+      const f32x4 gg = *(const f32x4*)(g2 + c4 * 4);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean2) * rstd2 * gg[e];
+      *(f32x4*)(y2 + (int64_t)row * C + c4 * 4) = o;
+    }
+  }
+}
+
 int launch_layernorm(const float* x, int ldx, const float* g, const float* beta, const float* res, int ldres, float* y,
-                     int rows, int C, float eps, hipStream_t s) {
+                     int rows, int C, float eps, hipStream_t s, int in_act, const float* g2, float* y2) {
   KD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && (!res || ldres % 4 == 0), "LayerNorm needs C % 4 == 0");
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, g, beta, res, ldres, y, rows, C,
-                     eps);
+  KD_REQUIRE((g2 == nullptr) == (y2 == nullptr), "LayerNorm: the second normalisation needs its gain and its output");
+  const dim3 grid((rows + 3) / 4), block(256);
+#define KD_LN(NV_)                                                                                                     \
+  hipLaunchKernelGGL(layernorm_reg_kernel<NV_>, grid, block, 0, s, x, ldx, g, beta, res, ldres, y, rows, C, eps, in_act, g2, y2)
+  if (C <= 256) KD_LN(1);
+  else if (C <= 512) KD_LN(2);
+  else if (C <= 1024) KD_LN(4);
+  else if (C <= 2048) KD_LN(8);
+  else if (C <= 4096) KD_LN(16);
+  else {
+    KD_REQUIRE(in_act == ACT_NONE && !g2, "LayerNorm rows above 4096 channels: plain form only");
+    hipLaunchKernelGGL(layernorm_kernel, grid, block, 0, s, x, ldx, g, beta, res, ldres, y, rows, C, eps);
+  }
+#undef KD_LN
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }

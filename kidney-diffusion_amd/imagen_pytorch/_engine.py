@@ -55,6 +55,7 @@ class kd_unet_config_t(C.Structure):
         ("wino_slice_mb", C.c_int),
         ("wino43_min_cin", C.c_int),
         ("gemm_bf16x3", C.c_int),
+        ("x3_linear", C.c_int),
     ]
 
 
@@ -132,10 +133,13 @@ SIGNATURES = {
     "kd_conv3x3_winograd_nhwc": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     "kd_conv3x3_winograd4_nhwc": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "kd_gemm_bf16x3": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),
+    "kd_linear_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "kd_gn_conv3x3_winograd_fused_nhwc": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "kd_init_conv_nchw": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
     "kd_groupnorm_silu_nhwc": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "kd_layernorm": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "kd_layernorm_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kd_attention": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
     "kd_quantile_abs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),

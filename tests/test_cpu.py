@@ -351,7 +351,7 @@ def test_library_loads_and_exports_every_symbol_the_header_declares():
         assert hasattr(lib, sym), f"libkd_engine.so does not export {sym}"
     assert set(E.SIGNATURES) == declared, "ctypes table and header disagree"
     assert lib.kd_version() == 2   # KD_ENGINE_ABI_VERSION of include/kd_engine.h
-    assert C.sizeof(E.kd_unet_config_t) == 4 * (2 + 4 * E.KD_MAX_LEVELS + 25)  # ints only, header order
+    assert C.sizeof(E.kd_unet_config_t) == 4 * (2 + 4 * E.KD_MAX_LEVELS + 26)  # ints only, header order
     assert lib.kd_quantile_workspace_bytes(4) == 4 * 16 + 4 * 4 * 256 * 4
 
 
@@ -382,7 +382,7 @@ def test_library_build_id_matches_the_sources_and_the_build_is_up_to_date():
 def test_makefile_tracks_header_dependencies(tmp_path):
     """Round 2 shipped a library that predated its last header edit: the Makefile listed headers by hand and
     missed epilogue.h.  Dependencies now come from the compiler (-MMD): touching epilogue.h must schedule
-    exactly its users (kernels_conv, kernels_init) + the link, and nothing when nothing changed."""
+    exactly its users (kernels_conv, kernels_init, kernels_norm) + the link, and nothing when nothing changed."""
     import os
     import shutil
     import subprocess
@@ -401,7 +401,7 @@ def test_makefile_tracks_header_dependencies(tmp_path):
     assert planned() == []
     try:
         os.utime(hdr, None)
-        assert planned() == ["kernels_conv.hip", "kernels_init.hip"]
+        assert planned() == ["kernels_conv.hip", "kernels_init.hip", "kernels_norm.hip"]
     finally:
         os.utime(hdr, ns=(st.st_atime_ns, st.st_mtime_ns))
     assert planned() == []

@@ -138,12 +138,15 @@ def test_c3_sr_unet_at_the_benchmark_batch_matches_oracle(device, c3):
     errs = {}
     # default plan (the F(4x4,3x3) position GEMMs on the bf16 matrix pipe as three-piece fp32 products), the same with the
     # fp32 MFMA GEMMs, and the plan without F(4x4,3x3)
-    for w43, x3 in ((0, 0), (0, -1), (-1, 0)):
+    nlin = {}
+    for w43, x3, lin in ((0, 0, 0), (0, 0, -1), (0, -1, 0), (-1, 0, 0)):
         pu = H.product_unet_like(ou).to(device)
         pu.wino43_min_cin = w43
         pu.gemm_bf16x3 = x3
+        pu.x3_linear = lin
         got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
-        errs[w43, x3] = H.rel_l2(got, ref)
+        key = (w43, x3) if lin == 0 else "fp32 token GEMMs"
+        errs[key] = H.rel_l2(got, ref)
         buf = C.create_string_buffer(1 << 20)
         E.check(E.load().kd_unet_profile(pu.engine(B, S, device, with_text=False), 1, buf, len(buf), E.current_stream()))
         labels = buf.value.decode()
@@ -152,7 +155,14 @@ def test_c3_sr_unet_at_the_benchmark_batch_matches_oracle(device, c3):
         assert labels.count("wino4 gemm") == n4, labels.count("wino4 gemm")
         assert labels.count("wino4 gemm bf16x3") == (n4 if x3 == 0 else 0), labels.count("wino4 gemm bf16x3")
         assert labels.count("wino fused") == 56 - n4, labels.count("wino fused")
+        # the attention projections and the feed-forward of the 16 x 16 / 32 x 32 levels (K >= 512) on the bf16x3 kernel's
+        # epilogue form - unless switched off, or the bf16x3 kernels are off altogether
+        nlin[key] = labels.count("conv k1 x3 M")
+        assert (nlin[key] >= 20) == (lin == 0 and x3 == 0), (key, nlin[key])
         del pu
+    print(f"C3 plan at batch 16: {nlin[0, 0]} token GEMMs / 1x1 convs on bf16x3; rel-L2 {errs[0, 0]:.3e} with them, "
+          f"{errs['fp32 token GEMMs']:.3e} with conv_buf_kernel (fp32 MFMA)")
+    assert errs[0, 0] < 1.5 * errs["fp32 token GEMMs"] + 1e-7, errs   # fp32-class products: nothing is lost
     print(f"C3 forward at batch 16: rel-L2 {errs[0, 0]:.3e} with F(4x4,3x3) on 40 layers (bf16x3 GEMMs), "
           f"{errs[0, -1]:.3e} with fp32 MFMA GEMMs, {errs[-1, 0]:.3e} without F(4x4,3x3)")
     assert all(e < FWD_REL_L2 for e in errs.values()), errs

@@ -285,6 +285,70 @@ def test_gemm_bf16x3_matches_fp64(lib, device, G, M, N, K, scale_b, a_planes):
     assert torch.equal(c, c2)   # the other form of the A operand: the same planes, the same bits
 
 
+# The same kernel in its token-GEMM / 1x1-conv form (kd_unet_config_t::x3_linear): every epilogue variant the plan uses -
+# bias, residual, GlobalContext gate, strided input / output rows (skip slices) - on shapes that run whole rounds, whole
+# rounds plus k-cut left-over tiles, and (fewer tiles than CUs) every tile cut in k with the epilogue in the summing launch.
+@pytest.mark.parametrize("M,N,K,bias,res,gate,ldx,ldy", [
+    (4096, 1024, 1024, False, True, False, 0, 0),     # feed-forward's second Linear + residual: 128 tiles, all cut in two
+    (4096, 2048, 1024, False, False, False, 0, 0),    # feed-forward's first Linear (GELU applied by the next LayerNorm): one round
+    (4096, 640, 1024, False, False, False, 0, 0),     # the stacked q / kv projection: 80 tiles
+    (4096, 1024, 512, True, False, False, 0, 2048),   # attention's to_out into a skip slot (row stride 2048): K = 512, parts of 16 stages
+    (4096, 1024, 2048, True, False, True, 2560, 0),   # the 1x1 skip conv of a ResnetBlock with the GlobalContext gate, strided input
+    (16384, 512, 512, False, True, False, 0, 0),      # 32 x 32 level cross-attention projections: 256 tiles
+    (768, 384, 96, True, True, False, 0, 0),          # 9 tiles, six stages: too short to cut (one tile per workgroup)
+    (73728, 128, 64, True, False, False, 0, 0),       # 288 tiles: a whole round and 32 left-over tiles that are not cut
+])
+def test_linear_bf16x3_epilogues_match_fp64(lib, device, M, N, K, bias, res, gate, ldx, ldy):
+    E = _E()
+    lda, ldo = ldx or K, ldy or N
+    hw = 256
+    xfull = (torch.randn(M, lda, generator=g(41)) * torch.logspace(-2, 2, lda)).to(device)
+    w = (torch.randn(N, K, generator=g(42)) * 0.05).to(device)
+    b = torch.randn(N, generator=g(43)).to(device) if bias else None
+    r = torch.randn(M, N, generator=g(44)).to(device) if res else None
+    gs = torch.randn(M, N, generator=g(45)).to(device) if gate else None
+    gt = torch.rand(M // hw, N, generator=g(46)).to(device) if gate else None
+    y = torch.full((M, ldo), float("nan"), device=device)
+    E.check(lib.kd_linear_bf16x3(E.ptr(xfull), lda, E.ptr(w), E.ptr(b), E.ptr(r), N, E.ptr(gs), N, E.ptr(gt), hw, E.ptr(y), ldo,
+                                 M, N, K, E.current_stream()))
+    x = xfull[:, :K]
+    ref = x.double() @ w.double().T
+    f32 = (x @ w.T).double()
+    bound = x.double().abs() @ w.double().abs().T
+    extra = torch.zeros_like(ref)
+    if bias:
+        extra = extra + b.double()
+    if gate:
+        extra = extra + gs.double() * gt.double().repeat_interleave(hw, dim=0)
+    if res:
+        extra = extra + r.double()
+    got = y[:, :N].double()
+    assert torch.isfinite(got).all()
+    if ldo > N:
+        assert torch.isnan(y[:, N:]).all()   # nothing outside the slice is written
+    # the product is held to the fp32 product's error (as test_gemm_bf16x3_matches_fp64); the added terms cost at most a few
+    # ulps of the sum
+    scale = bound + extra.abs()
+    e_x3 = ((got - (ref + extra)).abs() / scale.clamp_min(1e-300))
+    e_32 = ((f32 + extra - (ref + extra)).abs() / scale.clamp_min(1e-300))
+    print(f"linear bf16x3 M{M} N{N} K{K}: max err {float(e_x3.max()):.2e} (fp32 matmul {float(e_32.max()):.2e})")
+    assert float(e_x3.max()) <= max(2.0 * float(e_32.max()), 2.0 ** -21), float(e_x3.max())
+    rms = lambda e: float(e.pow(2).mean().sqrt())
+    assert rms(e_x3) <= max(1.5 * rms(e_32), 2.0 ** -24), (rms(e_x3), rms(e_32))
+
+
+def test_linear_bf16x3_rejects_unsupported_shapes(lib, device):
+    E = _E()
+    t = torch.zeros(16, device=device)
+    for M, N, K, hw in [(128, 128, 64, 256), (256, 64, 64, 256), (256, 128, 48, 256)]:
+        rc = lib.kd_linear_bf16x3(E.ptr(t), 0, E.ptr(t), None, None, 0, None, 0, None, hw, E.ptr(t), 0, M, N, K, E.current_stream())
+        assert rc != 0 and b"kd_linear_bf16x3" in lib.kd_last_error()
+    # a gate needs whole images per 256-row tile
+    rc = lib.kd_linear_bf16x3(E.ptr(t), 0, E.ptr(t), None, None, 0, E.ptr(t), 128, E.ptr(t), 64, E.ptr(t), 0, 256, 128, 64,
+                              E.current_stream())
+    assert rc != 0
+
+
 def test_gemm_bf16x3_two_launches_sharing_the_chip_do_not_depend_on_each_other(lib, device):
     """No workgroup of the persistent kernel waits for another (the k-parts of a left-over tile leave their accumulators in
     slabs of the launch's own workspace, a second launch adds them), so two such launches on different streams (two plans of
@@ -487,6 +551,39 @@ def test_layernorm(lib, device, rows, C, bias):
     bd = bb.to(device) if bias else None
     E.check(lib.kd_layernorm(E.ptr(xd), E.ptr(gd), E.ptr(bd), E.ptr(y), rows, C, 1e-5, E.current_stream()))
     assert torch.allclose(y.cpu().double(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("rows,C,act,res,second", [
+    (300, 1024, 0, True, True),     # attention's to_out LayerNorm + residual, then the feed-forward's first LayerNorm
+    (64, 2048, 2, False, False),    # FeedForward: GELU of the raw product on the way in
+    (5, 4096, 2, True, True), (7, 32, 1, False, True), (300, 256, 0, False, False), (33, 520, 2, True, False),
+])
+def test_layernorm_forms_of_the_transformer_block(lib, device, rows, C, act, res, second):
+    E = _E()
+    x = torch.randn(rows, C, generator=g(8)) * 3 + 1
+    gg, g2 = torch.randn(C, generator=g(9)), torch.randn(C, generator=g(14))
+    r = torch.randn(rows, C, generator=g(15)) if res else None
+    xa = x.double()
+    if act == 1:
+        xa = F.silu(xa)
+    elif act == 2:
+        xa = F.gelu(xa)
+    ref = F.layer_norm(xa, (C,), gg.double(), None, eps=1e-5)
+    if res:
+        ref = ref + r.double()
+    y = torch.empty(rows, C, device=device)
+    y2 = torch.empty(rows, C, device=device) if second else None
+    E.check(lib.kd_layernorm_ex(E.ptr(x.to(device)), E.ptr(gg.to(device)), None, E.ptr(r.to(device)) if res else None, E.ptr(y), rows,
+                                C, 1e-5, act, E.ptr(g2.to(device)) if second else None, E.ptr(y2), E.current_stream()))
+    assert torch.allclose(y.cpu().double(), ref, rtol=2e-5, atol=2e-5)
+    if second:
+        ref2 = F.layer_norm(ref, (C,), g2.double(), None, eps=1e-5)
+        assert torch.allclose(y2.cpu().double(), ref2, rtol=4e-5, atol=4e-5)
+    # the plain form is what kd_layernorm computes, bit for bit (one read of the row instead of three: same sums, same order)
+    if act == 0 and not res:
+        y0 = torch.empty(rows, C, device=device)
+        E.check(lib.kd_layernorm(E.ptr(x.to(device)), E.ptr(gg.to(device)), None, E.ptr(y0), rows, C, 1e-5, E.current_stream()))
+        assert torch.equal(y0, y)
 
 
 @pytest.mark.parametrize("B,Nq,Nk,H,Hkv", [
