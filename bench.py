@@ -675,6 +675,9 @@ def main():
                          "kernel - the A/B of profiles/README.md")
     ap.add_argument("--wino43-min-cin", type=int, default=0,
                     help="sr: Unet.wino43_min_cin (0 = the plan's default rule; 512 = the rule of the fp32 MFMA GEMMs)")
+    ap.add_argument("--x3-linear", type=int, default=0,
+                    help="sr: Unet.x3_linear (0 = the plan's default: token GEMMs / 1x1 convs with K >= 512 on the bf16x3 kernel; "
+                         "-1 = on conv_buf_kernel, fp32 MFMA; n = K >= n)")
     ap.add_argument("--no-line-grid", action="store_true",
                     help="sr: leave the nested `grid` object (8x8 grid patches/s for 1 and 3 canvases) out of the line")
     ap.add_argument("--line-grid-steps", type=int, default=8, help="timesteps per stage of the nested grid runs")
@@ -735,6 +738,7 @@ def main():
     if args.fp32_mfma_gemms:
         unet.gemm_bf16x3 = -1
     unet.wino43_min_cin = args.wino43_min_cin
+    unet.x3_linear = args.x3_linear
     handle = unet.engine(BATCH, SIZE, device, with_text=False)
     macs = lib.kd_unet_macs(handle)            # algorithmic: the direct convolutions the reference computes
     mfma_macs = lib.kd_unet_mfma_macs(handle)  # issued on the matrix cores (Winograd layers: 16/36 of theirs)

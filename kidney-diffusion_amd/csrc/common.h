@@ -154,6 +154,10 @@ struct X3Epi {
   int hw = 0;                    // rows per image (gate), a multiple of 256
   int ldy = 0;                   // row stride of y (>= N)
   int lda = 0;                   // row stride of an fp32 A (a_f32); plane-form A is always dense
+  // GroupNorm partials of y for the layer that normalises it (SegSrc): [images][seg_nseg][hw / 32][2] doubles, segment
+  // (n + seg_coff) / 16 of column n; needs hw % 32 == 0 and a launch whose tiles are not cut in k
+  double* seg = nullptr;
+  int seg_nseg = 0, seg_coff = 0;
 };
 bool gemm_bf16x3_epi_ok(int64_t M, int N, int K, const X3Epi& e);
 // a_f32: A is plain fp32 rows, split into its planes by the kernel's loader waves on the way into LDS

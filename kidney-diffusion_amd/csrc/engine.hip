@@ -508,11 +508,13 @@ struct Builder {
   bool x3_linear_ok(const T& x, int Cout, int K, int stride, int pad, const ConvOpt& o) const {
     if (cfg.gemm_bf16x3 < 0 || cfg.conv_algo != 0 || cfg.x3_linear < 0 || to_text || to_static || to_cond) return false;
     if (K != 1 || stride != 1 || pad != 0 || o.rowrun || o.wz_rows || o.out_mode != OUT_NHWC || o.out_external) return false;
-    if (o.act != ACT_NONE || (o.want_seg && seg_on) || (o.gate_src && o.res)) return false;
+    if (o.act != ACT_NONE || (o.gate_src && o.res)) return false;
     const int min_k = cfg.x3_linear > 0 ? cfg.x3_linear : 512;
     if (x.C < min_k || x.C % 32 || Cout % 128) return false;
     const int64_t M = x.rows();
     if (M % 256 || (M / 256) * (Cout / 128) < 64) return false;   // below 64 tiles the k-parts get too short
+    // a layer whose output statistics the epilogue must leave: only where no tile is cut in k (the summing launch leaves none)
+    if (o.want_seg && seg_on && gemm_bf16x3_needs_sum(1, (int)M, Cout, x.C)) return false;
     X3Epi e;
     e.lda = x.LD();
     e.ldy = o.dst ? o.dst->LD() : Cout;
@@ -559,48 +561,6 @@ struct Builder {
     size_t ro = has_res ? o.res->at() : 0, gso = has_gs ? o.gate_src->at() : 0, go = has_gs ? o.gate->off : 0;
     kd_unet* uu = u;
     const int res_coff = o.res_coff, o_yoff = o.yoff;
-    // ---- token GEMMs / 1x1 convs with K >= 512 as fp32 products on the bf16 matrix pipe (kernels_gemm_bf16x3.hip,
-    // epilogue form: bias / residual / gate, strided rows; weights split into planes once per plan, the fp32 activations by
-    // the kernel's loader waves).  Layers whose output statistics the epilogue would have to leave (want_seg) and
-    // activations stay on conv_buf_kernel; cfg.conv_algo != 0 (the direct-convolution plans of the tests) too
-    if (x3_linear_ok(x, Cout, K, stride, pad, o)) {
-      const int64_t M = (int64_t)x.B * Ho * Wo;
-      const int Cin = x.C;
-      const float* W3 = cached("x3lin:" + std::to_string((uintptr_t)w) + ":" + std::to_string(Cout) + "x" + std::to_string(Cin),
-                               ((size_t)Cout * Cin * 3 + 1) / 2,
-                               [&](float* dst) { KD_THROW_IF(launch_split3(w, dst, 1, Cout, Cin, 0)); });
-      if (!u->x3_ws) KD_HIP_THROW(hipMalloc(&u->x3_ws, gemm_bf16x3_workspace_bytes()));
-      X3Epi base;
-      base.bias = bias;
-      base.ldres = p.ldres;
-      base.ldgs = p.ldgs;
-      base.hw = Ho * Wo;
-      base.ldy = p.ldy;
-      base.lda = p.ldx;
-      const int yoff = p.yoff;
-      auto epi_of = [=]() {
-        X3Epi e = base;
-        e.res = has_res ? uu->P(ro) + res_coff : nullptr;
-        e.gate_src = has_gs ? uu->P(gso) : nullptr;
-        e.gate = has_gs ? uu->P(go) : nullptr;
-        return e;
-      };
-      const std::string shape = " M" + std::to_string(M) + " Cin" + std::to_string(Cin) + " Cout" + std::to_string(Cout);
-      const int64_t m = o.macs_override >= 0 ? o.macs_override : M * Cout * Cin;
-      emit([=](hipStream_t s) {
-        const X3Epi e = epi_of();
-        return launch_gemm_bf16x3(uu->P(xo), W3, uu->P(yo) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, true, false, &e);
-      }, "conv k1 x3" + shape, m);
-      u->macs += m;
-      u->op_mfma.back() = 6 * M * Cout * Cin;   // bf16 MACs
-      u->mfma_bf16_macs += u->op_mfma.back();
-      if (gemm_bf16x3_needs_sum(1, (int)M, Cout, Cin))   // every tile cut in k (fewer tiles than CUs): the parts are added, and the epilogue applied, here
-        emit([=](hipStream_t s) {
-          const X3Epi e = epi_of();
-          return launch_gemm_bf16x3_sum(uu->P(yo) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, &e);
-        }, "conv k1 x3 sum" + shape);
-      return y;
-    }
     // small-M layers (batch-1 patches): split-K scratch, released right after the launch is recorded
     // (one in-order stream: the next op that reuses the block runs after the reduction)
     const int ks = conv_ksplit(p);
@@ -636,6 +596,55 @@ struct Builder {
         seg_nseg = span / 16;
         sego = have ? have->off : add_seg(y, seg_c0, seg_nseg, nchunk);
       }
+    }
+    // ---- token GEMMs / 1x1 convs with K >= 512 as fp32 products on the bf16 matrix pipe (kernels_gemm_bf16x3.hip,
+    // epilogue form: bias / residual / gate, strided rows; weights split into planes once per plan, the fp32 activations by
+    // the kernel's loader waves; GroupNorm partials of the output where no tile is cut in k).  Layers with an activation
+    // stay on conv_buf_kernel; cfg.conv_algo != 0 (the direct-convolution plans of the tests) too
+    if (x3_linear_ok(x, Cout, K, stride, pad, o)) {
+      const int64_t M = (int64_t)x.B * Ho * Wo;
+      const int Cin = x.C;
+      const float* W3 = cached("x3lin:" + std::to_string((uintptr_t)w) + ":" + std::to_string(Cout) + "x" + std::to_string(Cin),
+                               ((size_t)Cout * Cin * 3 + 1) / 2,
+                               [&](float* dst) { KD_THROW_IF(launch_split3(w, dst, 1, Cout, Cin, 0)); });
+      if (!u->x3_ws) KD_HIP_THROW(hipMalloc(&u->x3_ws, gemm_bf16x3_workspace_bytes()));
+      X3Epi base;
+      base.bias = bias;
+      base.ldres = p.ldres;
+      base.ldgs = p.ldgs;
+      base.hw = Ho * Wo;
+      base.ldy = p.ldy;
+      base.lda = p.ldx;
+      const int yoff = p.yoff;
+      const int seg_coff = o_yoff - seg_c0;
+      auto epi_of = [=]() {
+        X3Epi e = base;
+        e.res = has_res ? uu->P(ro) + res_coff : nullptr;
+        e.gate_src = has_gs ? uu->P(gso) : nullptr;
+        e.gate = has_gs ? uu->P(go) : nullptr;
+        if (seg_nseg) {   // the output feeds a GroupNorm: its partials from the epilogue (no tile of such a launch is cut in k)
+          e.seg = (double*)uu->P(sego);
+          e.seg_nseg = seg_nseg;
+          e.seg_coff = seg_coff;
+        }
+        return e;
+      };
+      const std::string shape = " M" + std::to_string(M) + " Cin" + std::to_string(Cin) + " Cout" + std::to_string(Cout);
+      const int64_t m = o.macs_override >= 0 ? o.macs_override : M * Cout * Cin;
+      emit([=](hipStream_t s) {
+        const X3Epi e = epi_of();
+        return launch_gemm_bf16x3(uu->P(xo), W3, uu->P(yo) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, true, false, &e);
+      }, "conv k1 x3" + shape, m);
+      u->macs += m;
+      u->op_mfma.back() = 6 * M * Cout * Cin;   // bf16 MACs
+      u->mfma_bf16_macs += u->op_mfma.back();
+      if (gemm_bf16x3_needs_sum(1, (int)M, Cout, Cin))   // every tile cut in k (fewer tiles than CUs): the parts are added, and the epilogue applied, here
+        emit([=](hipStream_t s) {
+          const X3Epi e = epi_of();
+          return launch_gemm_bf16x3_sum(uu->P(yo) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, &e);
+        }, "conv k1 x3 sum" + shape);
+      if (ks > 1) free(part);
+      return y;
     }
     emit([=](hipStream_t s) {
       ConvParams q = p;

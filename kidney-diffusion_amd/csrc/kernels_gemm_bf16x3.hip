@@ -360,6 +360,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+          float f1 = 0.f, f2 = 0.f;
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
             float add[4] = {0.f, 0.f, 0.f, 0.f};
@@ -380,6 +381,28 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
             for (int k = 0; k < 4; ++k) {
               const float v = (acc[i][j][4 * r4 + k] + bj[j]) + add[k];
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vC, s0 + ((i * 32 + 8 * r4 + k) * Nv + j * 32) * 4, 0);
+              f1 += v;
+              f2 = fmaf(v, v, f2);
+            }
+          }
+          if (e.seg) {
+            // GroupNorm partials of the stored 32 x 32 block for the layer that reads the map (SegSrc, common.h): the lane's
+            // 16 values of one channel in fp32, fp64 from there on; the 16 lanes x 2 halves of a 16-channel segment are
+            // folded with shuffles, lanes 0 / 16 write chunk (row of the image) / 32 - as conv_buf_kernel's epilogue does
+            double d1 = (double)f1, d2 = (double)f2;
+#pragma unroll
+            for (int off = 1; off <= 8; off <<= 1) {
+              d1 += __shfl_xor(d1, off, 64);
+              d2 += __shfl_xor(d2, off, 64);
+            }
+            d1 += __shfl_xor(d1, 32, 64);
+            d2 += __shfl_xor(d2, 32, 64);
+            if ((ln & 47) == 0) {
+              const int rowb = mt * BM + wm * 64 + i * 32, b = rowb / e.hw;
+              const int seg = (col0 + j * 32 + e.seg_coff) >> 4;
+              double* o = e.seg + (((int64_t)b * e.seg_nseg + seg) * (e.hw >> 5) + ((rowb - b * e.hw) >> 5)) * 2;
+              o[0] = d1;
+              o[1] = d2;
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -590,6 +613,10 @@ bool gemm_bf16x3_epi_ok(int64_t M, int N, int K, const X3Epi& e) {
   if (M * (int64_t)e.lda * 4 >= ((int64_t)1 << 31) || M * (int64_t)e.ldy >= ((int64_t)1 << 29)) return false;
   if (e.res && (e.ldres < N || M * (int64_t)e.ldres * 4 >= ((int64_t)1 << 31))) return false;
   if (e.gate_src && (!e.gate || e.ldgs < N || e.hw <= 0 || e.hw % BM || M * (int64_t)e.ldgs * 4 >= ((int64_t)1 << 31))) return false;
+  // output statistics: whole 32-row blocks per image, segments of 16 channels, and no tile cut in k (the summing launch
+  // does not leave them)
+  if (e.seg && (e.hw <= 0 || e.hw % 32 || M % e.hw || (e.seg_coff & 15) || e.seg_nseg <= 0 || gemm_bf16x3_needs_sum(1, (int)M, N, K)))
+    return false;
   return true;
 }
 

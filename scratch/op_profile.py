@@ -16,14 +16,16 @@ w43 = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # Unet.wino43_min_cin (0 = 
 x3 = int(sys.argv[3]) if len(sys.argv) > 3 else 0    # Unet.gemm_bf16x3 (0 = default, -1 = fp32 MFMA position GEMMs)
 dev = torch.device("cuda:0")
 lib = E.load()
-unet = bench.build_unet(0)
+lin = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # Unet.x3_linear (0 = default, -1 = token GEMMs on conv_buf_kernel, n = K >= n)
+unet = bench.build_unet(0).to(dev)
 unet.wino43_min_cin = w43
 unet.gemm_bf16x3 = x3
-h = unet.engine(bench.BATCH, bench.SIZE, dev, with_text=False)
+unet.x3_linear = lin
 x, lowres, _, cond = bench.synthetic_inputs(bench.BATCH, dev)
 t = torch.zeros(bench.BATCH, device=dev)
 with torch.no_grad():
-    unet.to(dev)(x, t, lowres_cond_img=lowres, lowres_noise_times=t, cond_images=cond)
+    unet(x, t, lowres_cond_img=lowres, lowres_noise_times=t, cond_images=cond)
+h = unet.engine(bench.BATCH, bench.SIZE, dev, with_text=False)
 buf = C.create_string_buffer(1 << 20)
 E.check(lib.kd_unet_profile(h, 5, buf, len(buf), E.current_stream()))
 rows = [l.split(",") for l in buf.value.decode().strip().split("\n")[1:]]

@@ -573,8 +573,10 @@ def test_layernorm_forms_of_the_transformer_block(lib, device, rows, C, act, res
         ref = ref + r.double()
     y = torch.empty(rows, C, device=device)
     y2 = torch.empty(rows, C, device=device) if second else None
-    E.check(lib.kd_layernorm_ex(E.ptr(x.to(device)), E.ptr(gg.to(device)), None, E.ptr(r.to(device)) if res else None, E.ptr(y), rows,
-                                C, 1e-5, act, E.ptr(g2.to(device)) if second else None, E.ptr(y2), E.current_stream()))
+    xd, gd, g2d = x.to(device), gg.to(device), g2.to(device)   # (kept alive: a temporary's block would be handed to the next one)
+    rd = r.to(device) if res else None
+    E.check(lib.kd_layernorm_ex(E.ptr(xd), E.ptr(gd), None, E.ptr(rd), E.ptr(y), rows, C, 1e-5, act, E.ptr(g2d) if second else None,
+                                E.ptr(y2), E.current_stream()))
     assert torch.allclose(y.cpu().double(), ref, rtol=2e-5, atol=2e-5)
     if second:
         ref2 = F.layer_norm(ref, (C,), g2.double(), None, eps=1e-5)
@@ -582,7 +584,7 @@ def test_layernorm_forms_of_the_transformer_block(lib, device, rows, C, act, res
     # the plain form is what kd_layernorm computes, bit for bit (one read of the row instead of three: same sums, same order)
     if act == 0 and not res:
         y0 = torch.empty(rows, C, device=device)
-        E.check(lib.kd_layernorm(E.ptr(x.to(device)), E.ptr(gg.to(device)), None, E.ptr(y0), rows, C, 1e-5, E.current_stream()))
+        E.check(lib.kd_layernorm(E.ptr(xd), E.ptr(gd), None, E.ptr(y0), rows, C, 1e-5, E.current_stream()))
         assert torch.equal(y0, y)
 
 
