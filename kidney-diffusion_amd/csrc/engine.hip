@@ -509,10 +509,14 @@ struct Builder {
     if (cfg.gemm_bf16x3 < 0 || cfg.conv_algo != 0 || cfg.x3_linear < 0 || to_text || to_static || to_cond) return false;
     if (K != 1 || stride != 1 || pad != 0 || o.rowrun || o.wz_rows || o.out_mode != OUT_NHWC || o.out_external) return false;
     if (o.act != ACT_NONE || (o.gate_src && o.res)) return false;
-    const int min_k = cfg.x3_linear > 0 ? cfg.x3_linear : 512;
+    // measured per launch against conv_buf_kernel at batch 16 (profiles/README.md, round 5): K >= 256 wins wherever the
+    // launch runs whole rounds (256 -> 128 on the 256 x 256 map 748 -> 645 us); with fewer tiles than CUs every tile is cut
+    // in k and a second launch adds the parts (10-15 us): K = 512 then only draws level (45.5 against 45.7 us), K >= 1024 wins
+    const int min_k = cfg.x3_linear > 0 ? cfg.x3_linear : 256;
     if (x.C < min_k || x.C % 32 || Cout % 128) return false;
     const int64_t M = x.rows();
     if (M % 256 || (M / 256) * (Cout / 128) < 64) return false;   // below 64 tiles the k-parts get too short
+    if (cfg.x3_linear == 0 && x.C < 1024 && gemm_bf16x3_needs_sum(1, (int)M, Cout, x.C)) return false;
     // a layer whose output statistics the epilogue must leave: only where no tile is cut in k (the summing launch leaves none)
     if (o.want_seg && seg_on && gemm_bf16x3_needs_sum(1, (int)M, Cout, x.C)) return false;
     X3Epi e;
@@ -716,16 +720,20 @@ struct Builder {
   // in_act: applied to x on the way in (ACT_GELU: the feed-forward's GELU when its GEMM stores the raw product);
   // g2 / y2: a second LayerNorm of the result in the same pass (y2 = LN(y) g2)
   T layernorm(const T& x, const float* g, const float* beta, const T* res = nullptr, int in_act = ACT_NONE,
-              const float* g2 = nullptr, T* y2 = nullptr) {
+              const float* g2 = nullptr, T* y2 = nullptr, bool want_seg = false) {
     T y = alloc(x.B, x.H, x.W, x.C);
     if (g2) *y2 = alloc(x.B, x.H, x.W, x.C);
     size_t xo = x.at(), yo = y.off, ro = res ? res->at() : 0, y2o = g2 ? y2->off : 0;
     bool hr = res != nullptr;
     int rows = (int)x.rows(), C = x.C, ldx = x.LD(), ldres = res ? res->LD() : 0;
+    // the output feeds a GroupNorm (the ResnetBlock's block2 behind its cross-attention): one chunk of partials per pixel
+    const int hw = x.HW();
+    const bool sg = want_seg && seg_on && !to_cond && !to_text && !to_static && C % 16 == 0 && C <= 4096 && x.B * hw == rows;
+    const size_t sgo = sg ? add_seg(y, 0, C / 16, hw) : 0;
     kd_unet* uu = u;
     emit([=](hipStream_t s) {
       return launch_layernorm(uu->P(xo), ldx, g, beta, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), rows, C, 1e-5f, s, in_act, g2,
-                              g2 ? uu->P(y2o) : nullptr);
+                              g2 ? uu->P(y2o) : nullptr, sg ? (double*)uu->P(sgo) : nullptr, hw);
     }, std::string(g2 ? "ln x2 rows" : "ln rows") + std::to_string(rows) + " C" + std::to_string(C));
     return y;
   }
@@ -824,7 +832,7 @@ struct Builder {
     free(kv);
     T proj = linear(o, P(pre + ".to_out.0.weight", (int64_t)dim * inner), nullptr, dim);
     free(o);
-    T y = layernorm(proj, P(pre + ".to_out.1.g", dim), nullptr, &x);
+    T y = layernorm(proj, P(pre + ".to_out.1.g", dim), nullptr, &x, ACT_NONE, nullptr, nullptr, true);   // block2's GroupNorm reads it
     free(proj);
     return y;
   }

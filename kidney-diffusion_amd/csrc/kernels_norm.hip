@@ -275,7 +275,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
                                                             const float* __restrict__ beta, const float* __restrict__ res,
                                                             int ldres, float* __restrict__ y, int rows, int C, float eps,
-                                                            int in_act, const float* __restrict__ g2, float* __restrict__ y2) {
+                                                            int in_act, const float* __restrict__ g2, float* __restrict__ y2,
+                                                            double* __restrict__ seg, int seg_hw) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -323,6 +324,23 @@ __global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restr
       v[i] = o;
       s2 += (o[0] + o[1]) + (o[2] + o[3]);
     }
+    if (seg) {
+      // GroupNorm partials of y for the layer that normalises it (SegSrc, common.h): one chunk per pixel; the four lanes
+      // 4 j .. 4 j + 3 hold the 16 channels of segment j + 16 i (whole waves get here: C4 % 4 == 0, lanes past the row add zeros)
+      const bool in = c4 < C4;
+      double d1 = in ? (double)((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) : 0.0;
+      double d2 = in ? (double)fmaf(v[i][0], v[i][0], fmaf(v[i][1], v[i][1], fmaf(v[i][2], v[i][2], v[i][3] * v[i][3]))) : 0.0;
+      d1 += __shfl_xor(d1, 1, 64);
+      d2 += __shfl_xor(d2, 1, 64);
+      d1 += __shfl_xor(d1, 2, 64);
+      d2 += __shfl_xor(d2, 2, 64);
+      if (in && (lane & 3) == 0) {
+        const int b = row / seg_hw, pix = row - b * seg_hw;
+        double* o = seg + (((int64_t)b * (C >> 4) + (c4 >> 2)) * seg_hw + pix) * 2;
+        o[0] = d1;
+        o[1] = d2;
+      }
+    }
   }
   if (!g2) return;
   const float mean2 = wave_sum_f(s2) / (float)C;
@@ -351,12 +369,15 @@ __global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restr
 }
 
 int launch_layernorm(const float* x, int ldx, const float* g, const float* beta, const float* res, int ldres, float* y,
-                     int rows, int C, float eps, hipStream_t s, int in_act, const float* g2, float* y2) {
+                     int rows, int C, float eps, hipStream_t s, int in_act, const float* g2, float* y2, double* seg, int seg_hw) {
   KD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && (!res || ldres % 4 == 0), "LayerNorm needs C % 4 == 0");
   KD_REQUIRE((g2 == nullptr) == (y2 == nullptr), "LayerNorm: the second normalisation needs its gain and its output");
+  KD_REQUIRE(!seg || (C % 16 == 0 && C <= 4096 && seg_hw > 0 && rows % seg_hw == 0),
+             "LayerNorm: output statistics need C % 16 == 0, C <= 4096 and whole images");
   const dim3 grid((rows + 3) / 4), block(256);
 #define KD_LN(NV_)                                                                                                     \
-  hipLaunchKernelGGL(layernorm_reg_kernel<NV_>, grid, block, 0, s, x, ldx, g, beta, res, ldres, y, rows, C, eps, in_act, g2, y2)
+  hipLaunchKernelGGL(layernorm_reg_kernel<NV_>, grid, block, 0, s, x, ldx, g, beta, res, ldres, y, rows, C, eps, in_act, g2, y2, seg, \
+                     seg_hw)
   if (C <= 256) KD_LN(1);
   else if (C <= 512) KD_LN(2);
   else if (C <= 1024) KD_LN(4);
