@@ -287,44 +287,34 @@ __global__ __launch_bounds__(256) void gca_combine_kernel(const float* __restric
 // C <= 512: a workgroup then streams at most 0.5 + 0.5 MB of weights; above that the skinny kernels' N / 32 workgroups
 // stream them faster than 16 workgroups can.  Plain fp32 fma chains in index order.
 constexpr int GCAG_MAXC = 512;
-constexpr int GCAG_THREADS = 512;
-// Round 5: the two FCs walk the weights a wave per row - 64 lanes read 1 KB of consecutive memory and fold their products
-// with shuffles - four rows in flight per wave.  (Round 4 gave every thread a whole row: 64 lanes x 16 bytes at a stride of
-// C floats per load, and a 128-step dependent chain per thread: 45 of the 61 us of a C = 512 gate.)
-__global__ __launch_bounds__(GCAG_THREADS) void gca_gate_kernel(const float* __restrict__ part, int nchunks, int C,
-                                                                const float* __restrict__ w0, const float* __restrict__ b0,
-                                                                int hid, const float* __restrict__ w2,
-                                                                const float* __restrict__ b2, float* __restrict__ gate) {
-  constexpr int NW = GCAG_THREADS / 64;
+__global__ __launch_bounds__(256) void gca_gate_kernel(const float* __restrict__ part, int nchunks, int C,
+                                                       const float* __restrict__ w0, const float* __restrict__ b0, int hid,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       float* __restrict__ gate) {
   __shared__ float se[1024];   // exp(m_i - mg) per chunk (nchunks <= 1024)
-  __shared__ float red[2 * NW];
+  __shared__ float red[8];
   __shared__ __attribute__((aligned(16))) float pooled[GCAG_MAXC];
   __shared__ __attribute__((aligned(16))) float hidden[GCAG_MAXC / 2];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* pb = part + (int64_t)b * nchunks * (C + 2);
   float m = -INFINITY;
-  for (int i = threadIdx.x; i < nchunks; i += GCAG_THREADS) m = fmaxf(m, pb[(int64_t)i * (C + 2)]);
+  for (int i = threadIdx.x; i < nchunks; i += 256) m = fmaxf(m, pb[(int64_t)i * (C + 2)]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if (lane == 0) red[wave] = m;
   __syncthreads();
-  float mg = red[0];
-#pragma unroll
-  for (int w = 1; w < NW; ++w) mg = fmaxf(mg, red[w]);
+  const float mg = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float l = 0.f;
-  for (int i = threadIdx.x; i < nchunks; i += GCAG_THREADS) {
+  for (int i = threadIdx.x; i < nchunks; i += 256) {
     const float e = expf(pb[(int64_t)i * (C + 2)] - mg);
     se[i] = e;
     l += pb[(int64_t)i * (C + 2) + 1] * e;
   }
   l = wave_sum(l);
-  if (lane == 0) red[NW + wave] = l;
+  if (lane == 0) red[4 + wave] = l;
   __syncthreads();
-  float lsum = 0.f;
-#pragma unroll
-  for (int w = 0; w < NW; ++w) lsum += red[NW + w];
-  const float inv = 1.0f / lsum;
-  for (int c = threadIdx.x; c < C; c += GCAG_THREADS) {   // consecutive threads read consecutive channels of a chunk
+  const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+  for (int c = threadIdx.x; c < C; c += 256) {   // consecutive threads read consecutive channels of a chunk
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int i = 0;
     for (; i + 3 < nchunks; i += 4) {
@@ -338,46 +328,40 @@ __global__ __launch_bounds__(GCAG_THREADS) void gca_gate_kernel(const float* __r
   }
   __syncthreads();
   typedef float f32x4g __attribute__((ext_vector_type(4)));
-  // y[r] = sum_k w[r][k] v[k] for the rows r = first, first + NW, ... of this wave, four rows per trip; K % 4 == 0
-  auto rows_dot = [&](const float* __restrict__ w, int R, int K, const float* v, auto&& finish) {
-    const int K4 = K >> 2;
-    for (int r0 = wave * 4; r0 < R; r0 += NW * 4) {
-      float a[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int k4 = lane; k4 < K4; k4 += 64) {
-        const f32x4g vv = *(const f32x4g*)(v + 4 * k4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (r0 + q < R) {
-            const f32x4g wv = *(const f32x4g*)(w + (int64_t)(r0 + q) * K + 4 * k4);
-            a[q] = fmaf(wv[0], vv[0], fmaf(wv[1], vv[1], fmaf(wv[2], vv[2], fmaf(wv[3], vv[3], a[q]))));
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float t = wave_sum(a[q]);
-        if (lane == 0 && r0 + q < R) finish(r0 + q, t);
-      }
+  for (int h = threadIdx.x; h < hid; h += 256) {   // hidden = SiLU(W0 pooled + b0): a thread streams one weight row
+    const f32x4g* wr = (const f32x4g*)(w0 + (int64_t)h * C);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int c4 = 0; c4 < C / 4; ++c4) {
+      const f32x4g wv = wr[c4], pv = *(const f32x4g*)(pooled + 4 * c4);
+      a0 = fmaf(wv[0], pv[0], a0);
+      a1 = fmaf(wv[1], pv[1], a1);
+      a2 = fmaf(wv[2], pv[2], a2);
+      a3 = fmaf(wv[3], pv[3], a3);
     }
-  };
-  rows_dot(w0, hid, C, pooled, [&](int h, float t) {   // hidden = SiLU(W0 pooled + b0)
-    const float v = t + b0[h];
+    const float v = ((a0 + a1) + (a2 + a3)) + b0[h];
     hidden[h] = v / (1.0f + expf(-v));
-  });
+  }
   __syncthreads();
-  if ((hid & 3) == 0) {
-    rows_dot(w2, C, hid, hidden, [&](int n, float t) {   // gate = sigmoid(W2 hidden + b2)
-      const float v = t + b2[n];
-      gate[(int64_t)b * C + n] = 1.0f / (1.0f + expf(-v));
-    });
-  } else {   // (hidden widths that are not a multiple of 4: a thread per output)
-    for (int n = threadIdx.x; n < C; n += GCAG_THREADS) {
-      const float* wr = w2 + (int64_t)n * hid;
-      float a0 = 0.f;
-      for (int h = 0; h < hid; ++h) a0 = fmaf(wr[h], hidden[h], a0);
-      const float v = a0 + b2[n];
-      gate[(int64_t)b * C + n] = 1.0f / (1.0f + expf(-v));
+  for (int n = threadIdx.x; n < C; n += 256) {     // gate = sigmoid(W2 hidden + b2)
+    const float* wr = w2 + (int64_t)n * hid;
+    float a0 = 0.f, a1 = 0.f;
+    int h = 0;
+    if ((hid & 3) == 0) {
+      float a2 = 0.f, a3 = 0.f;
+      for (; h < hid; h += 4) {
+        const f32x4g wv = *(const f32x4g*)(wr + h), hv = *(const f32x4g*)(hidden + h);
+        a0 = fmaf(wv[0], hv[0], a0);
+        a1 = fmaf(wv[1], hv[1], a1);
+        a2 = fmaf(wv[2], hv[2], a2);
+        a3 = fmaf(wv[3], hv[3], a3);
+      }
+      a0 += a2;
+      a1 += a3;
+    } else {
+      for (; h < hid; ++h) a0 = fmaf(wr[h], hidden[h], a0);
     }
+    const float v = (a0 + a1) + b2[n];
+    gate[(int64_t)b * C + n] = 1.0f / (1.0f + expf(-v));
   }
 }
 
@@ -406,7 +390,7 @@ int launch_gca_gate(const float* x, const float* wk, const float* bk, float* scr
   KD_REQUIRE((((uintptr_t)w0 | (uintptr_t)w2) & 15) == 0, "fused GlobalContext gate: 16-byte aligned weights");
   const int rows = gca_rows(HW, B), chunks = (HW + rows - 1) / rows;
   if (launch_gca_partial(x, wk, bk, scratch, B, HW, C, rows, chunks, s)) return 1;
-  hipLaunchKernelGGL(gca_gate_kernel, dim3(B), dim3(GCAG_THREADS), 0, s, scratch, chunks, C, w0, b0, hid, w2, b2, gate);
+  hipLaunchKernelGGL(gca_gate_kernel, dim3(B), dim3(256), 0, s, scratch, chunks, C, w0, b0, hid, w2, b2, gate);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
