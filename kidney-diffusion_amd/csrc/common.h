@@ -114,8 +114,11 @@ int launch_wino_out(const float* D, const float* bias, const float* res, int ldr
 // Mt = B (H/4) (W/4) tiles of 4x4 outputs; arguments as launch_wino_in / launch_wino_out (one slice).  seg_partial != nullptr:
 // wino4_out also leaves the GroupNorm partials of y, layout [B][N/16][(H/4)(W/4)][2] doubles (N % 64 == 0)
 int launch_wino4_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s);
+// mul_c0 >= 0 (GroupNorm form only): channels >= mul_c0 of x hold an unscaled skip tensor that the layer sees times `mul`
+// (the statistics were taken of the scaled tensor): the factor goes into the folded affine, the map is not touched
 int launch_wino4_in(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
-                    const float* scale_shift, int ld_ss, float* V, int B, int H, int W, int C, int G, hipStream_t s);
+                    const float* scale_shift, int ld_ss, float* V, int B, int H, int W, int C, int G, hipStream_t s,
+                    int mul_c0 = -1, float mul = 1.0f);
 int launch_wino4_out(const float* D, const float* bias, const float* res, int ldres, float* y, int ldy, double* seg_partial,
                      int B, int H, int W, int C, hipStream_t s);
 
@@ -171,7 +174,8 @@ int launch_gemm_bf16x3_sum(float* C, int G, int M, int N, int K, const void* ws,
 int gemm_bf16x3_workgroups(int G, int M, int N, int K);
 // launch_wino4_in writing V as the three planes the bf16x3 GEMM reads ([3][36][C/16][Mt][16] bf16; Mt % 8 == 0, C % 16 == 0)
 int launch_wino4_in3(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
-                     const float* scale_shift, int ld_ss, void* V3, int B, int H, int W, int C, int G, hipStream_t s);
+                     const float* scale_shift, int ld_ss, void* V3, int B, int H, int W, int C, int G, hipStream_t s,
+                     int mul_c0 = -1, float mul = 1.0f);
 
 // ---- fused Winograd F(2x2,3x3) conv + GroupNorm / FiLM / SiLU (kernels_wino_fused128.hip): items of 16 x 8 pixels x 128
 // output channels, Cin <= 2048.  The kernel evaluates SiLU as u / (1 + 2^u) on u = -log2(e) (A x + B): the affine of

@@ -1016,8 +1016,10 @@ struct Builder {
       thr = 256;
     return x.C >= thr;
   }
+  // skip_c0 >= 0: channels [skip_c0, ..) of x hold an unscaled skip tensor the layer must see times skip_scale: the input
+  // transform folds the factor into its affine (the statistics come from partials that carry the scale: add_skip)
   T wino4_block(const T& x, const std::string& gn_prefix, int ss_col, const std::string& conv_prefix, int Cout,
-                const T* res) {
+                const T* res, int skip_c0 = -1, float skip_scale = 1.0f) {
     const int Cin = x.C, G = cfg.resnet_groups, Bx = x.B, H = x.H, W = x.W, HW = x.HW();
     const int64_t Mt = (int64_t)Bx * (H / 4) * (W / 4);
     const float* gamma = P(gn_prefix + ".weight", Cin);
@@ -1044,8 +1046,9 @@ struct Builder {
       const int ld = tmlp_total, ldx = x.LD();
       emit([=](hipStream_t s) {
         const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
-        if (x3_planes) return launch_wino4_in3(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s);
-        return launch_wino4_in(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s);
+        if (x3_planes)
+          return launch_wino4_in3(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s, skip_c0, skip_scale);
+        return launch_wino4_in(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s, skip_c0, skip_scale);
       }, (x3_planes ? "wino4_in3" : "wino4_in") + shape);
     }
     if (x3) {
@@ -1235,7 +1238,7 @@ struct Builder {
     int dim_in = x.C;
     T h;
     if (wino4_ok(x, dim_out)) {
-      h = wino4_block(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
+      h = wino4_block(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr, skip_c0, skip_scale);
     } else if (wino_ok(x, dim_out)) {
       h = wino_block(x, pre + ".block1.groupnorm", -1, pre + ".block1.project", dim_out, nullptr);
     } else if (fwino_gn_ok(x, dim_out)) {

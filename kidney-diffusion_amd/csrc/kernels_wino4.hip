@@ -103,7 +103,8 @@ template <bool PLANES>
 __global__ __launch_bounds__(256) void wino4_in_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ scale_shift, int ld_ss,
-                                                       float* __restrict__ V, int B, int H, int W, int C, int G, int64_t nt) {
+                                                       float* __restrict__ V, int B, int H, int W, int C, int G, int64_t nt,
+                                                       int mul_c0, float mul) {
   const int Ht = H >> 2, Wt = W >> 2, C2 = C >> 1;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nt * C2) return;   // (PLANES: whole waves, nt % 8 == 0 and C % 16 == 0)
@@ -136,7 +137,9 @@ __global__ __launch_bounds__(256) void wino4_in_kernel(const float* __restrict__
         a *= sc;
         bb = bb * sc + sh;
       }
-      A[e] = a;
+      // channels >= mul_c0 hold an UNSCALED skip tensor that the layer sees times `mul` (2^-1/2): the statistics were taken
+      // of the scaled tensor (SegSrc::scale), so ((mul x) - mean) rstd gamma = (mul a) x + bb
+      A[e] = ce >= mul_c0 ? a * mul : a;
       Bc[e] = bb;
     }
   }
@@ -203,24 +206,30 @@ __global__ __launch_bounds__(256) void wino4_in_kernel(const float* __restrict__
 // 30 of the 36 pixels each - took 1715 us per step over the 31 launches against 1369 us of this kernel: the width of the
 // accesses is not what limits it.)
 int launch_wino4_in(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
-                    const float* scale_shift, int ld_ss, float* V, int B, int H, int W, int C, int G, hipStream_t s) {
+                    const float* scale_shift, int ld_ss, float* V, int B, int H, int W, int C, int G, hipStream_t s, int mul_c0,
+                    float mul) {
+  KD_REQUIRE(mul_c0 < 0 || stats, "Winograd F(4x4,3x3) input transform: a channel scale needs the GroupNorm form");
+  if (mul_c0 < 0) mul_c0 = C;
   KD_REQUIRE(H % 4 == 0 && W % 4 == 0 && ldx >= C && C % 2 == 0 && ldx % 2 == 0 && ((uintptr_t)x & 7) == 0,
              "Winograd F(4x4,3x3) input transform needs H % 4 == 0, W % 4 == 0 and even C / row stride");
   const int64_t nt = (int64_t)B * (H / 4) * (W / 4), total = nt * (C / 2);
   hipLaunchKernelGGL(wino4_in_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, stats, gamma,
-                     beta, scale_shift, ld_ss, V, B, H, W, C, G, nt);
+                     beta, scale_shift, ld_ss, V, B, H, W, C, G, nt, mul_c0, mul);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int launch_wino4_in3(const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
-                     const float* scale_shift, int ld_ss, void* V3, int B, int H, int W, int C, int G, hipStream_t s) {
+                     const float* scale_shift, int ld_ss, void* V3, int B, int H, int W, int C, int G, hipStream_t s, int mul_c0,
+                     float mul) {
+  KD_REQUIRE(mul_c0 < 0 || stats, "Winograd F(4x4,3x3) input transform: a channel scale needs the GroupNorm form");
+  if (mul_c0 < 0) mul_c0 = C;
   const int64_t nt = (int64_t)B * (H / 4) * (W / 4), total = nt * (C / 2);
   KD_REQUIRE(H % 4 == 0 && W % 4 == 0 && ldx >= C && C % X3_BK == 0 && ldx % 2 == 0 && ((uintptr_t)x & 7) == 0 && nt % 8 == 0 &&
                  ((uintptr_t)V3 & 3) == 0,
              "Winograd F(4x4,3x3) input transform to bf16x3 planes needs H % 4 == 0, W % 4 == 0, C % 16 == 0, tiles % 8 == 0");
   hipLaunchKernelGGL(wino4_in_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, stats, gamma, beta,
-                     scale_shift, ld_ss, (float*)V3, B, H, W, C, G, nt);
+                     scale_shift, ld_ss, (float*)V3, B, H, W, C, G, nt, mul_c0, mul);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
