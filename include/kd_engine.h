@@ -318,10 +318,13 @@ int kd_gemm_bf16x3(const float* d_a, const float* d_b, float* d_c, int G, int M,
  * the skip convs with K >= 512 (kd_unet_config_t::x3_linear): y[m][n] = sum_k x[m][k] w[n][k] + bias[n]
  * (+ gate_src[m][n] gate[m / hw][n]) (+ res[m][n]), fp32 rows with strides ldx / ldres / ldgs / ldy (0 = dense), the
  * activations split into their three bf16 pieces by the kernel's loader waves, the weights once.  Optional pointers may
- * be NULL.  Replaces nn.Linear / 1x1 nn.Conv2d + the residual / GlobalContext-gate adds around them. */
+ * be NULL.  d_seg (optional): the (sum, sum of squares) partials of y the launch leaves for a GroupNorm that reads it,
+ * fp64 [M / hw][N / 16][hw / rows][2] with rows = kd_linear_bf16x3_seg_rows(M, N, K) (32, or 8 where the tiles are cut in
+ * k).  Replaces nn.Linear / 1x1 nn.Conv2d + the residual / GlobalContext-gate adds around them. */
 int kd_linear_bf16x3(const float* d_x, int ldx, const float* d_w, const float* d_bias, const float* d_res, int ldres,
                      const float* d_gate_src, int ldgs, const float* d_gate, int hw, float* d_y, int ldy, int M, int N, int K,
-                     void* stream);
+                     double* d_seg, void* stream);
+int kd_linear_bf16x3_seg_rows(int M, int N, int K);
 /* ResnetBlock `Block` in one pass over x: conv3x3(SiLU(FiLM(GroupNorm_G(x)))) + bias (+ d_res), the form the
  * plan uses for those layers: statistics, a per-(image, channel) affine fold, and the fused Winograd kernel
  * with the activation applied to the raw patch in LDS (the activated map is never written).  d_scale_shift

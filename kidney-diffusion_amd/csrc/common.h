@@ -157,10 +157,12 @@ struct X3Epi {
   int hw = 0;                    // rows per image (gate), a multiple of 256
   int ldy = 0;                   // row stride of y (>= N)
   int lda = 0;                   // row stride of an fp32 A (a_f32); plane-form A is always dense
-  // GroupNorm partials of y for the layer that normalises it (SegSrc): [images][seg_nseg][hw / 32][2] doubles, segment
-  // (n + seg_coff) / 16 of column n; needs hw % 32 == 0 and a launch whose tiles are not cut in k
+  // GroupNorm partials of y for the layer that normalises it (SegSrc): [images][seg_nseg][hw / rows][2] doubles with rows =
+  // gemm_bf16x3_seg_rows(M, N, K) (32, or 8 where the tiles are cut in k and the summing launch leaves them), segment
+  // (n + seg_coff) / 16 of column n; needs hw % 32 == 0
   double* seg = nullptr;
   int seg_nseg = 0, seg_coff = 0;
+  int seg_rows8 = 0;             // set by launch_gemm_bf16x3: chunks of 8 rows (gemm_bf16x3_seg_rows == 8)
 };
 bool gemm_bf16x3_epi_ok(int64_t M, int N, int K, const X3Epi& e);
 // a_f32: A is plain fp32 rows, split into its planes by the kernel's loader waves on the way into LDS
@@ -170,6 +172,7 @@ bool gemm_bf16x3_epi_ok(int64_t M, int N, int K, const X3Epi& e);
 int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, int N, int K, void* ws, hipStream_t s,
                        bool a_f32 = false, bool with_sum = true, const X3Epi* epi = nullptr);
 bool gemm_bf16x3_needs_sum(int G, int M, int N, int K);
+int gemm_bf16x3_seg_rows(int M, int N, int K);
 int launch_gemm_bf16x3_sum(float* C, int G, int M, int N, int K, const void* ws, hipStream_t s, const X3Epi* epi = nullptr);
 int gemm_bf16x3_workgroups(int G, int M, int N, int K);
 // launch_wino4_in writing V as the three planes the bf16x3 GEMM reads ([3][36][C/16][Mt][16] bf16; Mt % 8 == 0, C % 16 == 0)

@@ -517,8 +517,6 @@ struct Builder {
     const int64_t M = x.rows();
     if (M % 256 || (M / 256) * (Cout / 128) < 64) return false;   // below 64 tiles the k-parts get too short
     if (cfg.x3_linear == 0 && x.C < 1024 && gemm_bf16x3_needs_sum(1, (int)M, Cout, x.C)) return false;
-    // a layer whose output statistics the epilogue must leave: only where no tile is cut in k (the summing launch leaves none)
-    if (o.want_seg && seg_on && gemm_bf16x3_needs_sum(1, (int)M, Cout, x.C)) return false;
     X3Epi e;
     e.lda = x.LD();
     e.ldy = o.dst ? o.dst->LD() : Cout;
@@ -590,7 +588,10 @@ struct Builder {
       probe.gate_src = has_gs ? (const float*)16 : nullptr;
       probe.seg_c0 = y.coff + seg_c0;
       probe.partial = ks > 1 ? (float*)16 : nullptr;   // split-K: statistics from the reduction kernel, one chunk per pixel
-      const int nchunk = conv_seg_chunks(probe);
+      // (the bf16x3 form of a 1x1 conv whose tiles are cut in k leaves its partials from the summing launch, a chunk per 8 rows)
+      const bool lin3 = x3_linear_ok(x, Cout, K, stride, pad, o);
+      const int nchunk = conv_seg_chunks(probe) > 0 && lin3 ? Ho * Wo / gemm_bf16x3_seg_rows(x.B * Ho * Wo, Cout, x.C)
+                                                            : conv_seg_chunks(probe);
       if (nchunk > 0 && cw % 16 == 0 && span % 16 == 0 && o.yoff >= seg_c0 && o.yoff + cw <= seg_c0 + span) {
         SegPart* have = nullptr;
         auto it = seg_of.find(y.at());
@@ -626,7 +627,7 @@ struct Builder {
         e.res = has_res ? uu->P(ro) + res_coff : nullptr;
         e.gate_src = has_gs ? uu->P(gso) : nullptr;
         e.gate = has_gs ? uu->P(go) : nullptr;
-        if (seg_nseg) {   // the output feeds a GroupNorm: its partials from the epilogue (no tile of such a launch is cut in k)
+        if (seg_nseg) {   // the output feeds a GroupNorm: its partials from the epilogue (of the summing launch where tiles are cut in k)
           e.seg = (double*)uu->P(sego);
           e.seg_nseg = seg_nseg;
           e.seg_coff = seg_coff;

@@ -400,9 +400,18 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
             if ((ln & 47) == 0) {
               const int rowb = mt * BM + wm * 64 + i * 32, b = rowb / e.hw;
               const int seg = (col0 + j * 32 + e.seg_coff) >> 4;
-              double* o = e.seg + (((int64_t)b * e.seg_nseg + seg) * (e.hw >> 5) + ((rowb - b * e.hw) >> 5)) * 2;
-              o[0] = d1;
-              o[1] = d2;
+              if (e.seg_rows8) {   // a launch whose left-over tiles are cut in k keeps a chunk per 8 rows (the summing launch's
+                                   // granularity): this block's sum goes into the first of its four chunks, zeros into the rest
+                double* o = e.seg + (((int64_t)b * e.seg_nseg + seg) * (e.hw >> 3) + ((rowb - b * e.hw) >> 3)) * 2;
+                o[0] = d1;
+                o[1] = d2;
+#pragma unroll
+                for (int z = 2; z < 8; ++z) o[z] = 0.0;
+              } else {
+                double* o = e.seg + (((int64_t)b * e.seg_nseg + seg) * (e.hw >> 5) + ((rowb - b * e.hw) >> 5)) * 2;
+                o[0] = d1;
+                o[1] = d2;
+              }
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -528,11 +537,33 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
   if constexpr (EPI) {
     const float b = e.bias ? e.bias[col] : 0.f;
     const float gt = e.gate ? e.gate[(int64_t)(row / e.hw) * N + col] : 0.f;
+    float f1 = 0.f, f2 = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float add = e.res ? e.res[(int64_t)(row + k) * e.ldres + col] : 0.f;
       if (e.gate_src) add = fmaf(e.gate_src[(int64_t)(row + k) * e.ldgs + col], gt, add);
-      c[(int64_t)k * ldc] = (v[k] + b) + add;
+      const float o = (v[k] + b) + add;
+      c[(int64_t)k * ldc] = o;
+      f1 += o;
+      f2 = fmaf(o, o, f2);
+    }
+    if (e.seg) {
+      // GroupNorm partials (SegSrc): the two lane halves hold rows 8 r4 .. + 3 and + 4 .. + 7 of the same columns, 16 lanes a
+      // 16-channel segment - one chunk per EIGHT rows here (the 32 rows of an accumulator block sit in four workgroups)
+      double d1 = (double)f1, d2 = (double)f2;
+#pragma unroll
+      for (int off = 1; off <= 8; off <<= 1) {
+        d1 += __shfl_xor(d1, off, 64);
+        d2 += __shfl_xor(d2, off, 64);
+      }
+      d1 += __shfl_xor(d1, 32, 64);
+      d2 += __shfl_xor(d2, 32, 64);
+      if ((lane & 47) == 0) {
+        const int bi = row / e.hw;
+        double* o = e.seg + (((int64_t)bi * e.seg_nseg + ((col + e.seg_coff) >> 4)) * (e.hw >> 3) + ((row - bi * e.hw) >> 3)) * 2;
+        o[0] = d1;
+        o[1] = d2;
+      }
     }
     return;
   }
@@ -587,6 +618,8 @@ size_t gemm_bf16x3_workspace_bytes() {   // a slab per workgroup
   return (size_t)X3_MAX_WG * BM * BN * sizeof(float);
 }
 
+// rows per chunk of the GroupNorm partials a launch leaves (X3Epi::seg): 32 from the kernel's epilogue, 8 from the summing launch
+int gemm_bf16x3_seg_rows(int M, int N, int K) { return gemm_bf16x3_needs_sum(1, M, N, K) ? 8 : 32; }
 bool gemm_bf16x3_needs_sum(int G, int M, int N, int K) {
   int P, R, S, first;
   x3_shape(G, M, N, K, &P, &R, &S, &first);
@@ -613,10 +646,9 @@ bool gemm_bf16x3_epi_ok(int64_t M, int N, int K, const X3Epi& e) {
   if (M * (int64_t)e.lda * 4 >= ((int64_t)1 << 31) || M * (int64_t)e.ldy >= ((int64_t)1 << 29)) return false;
   if (e.res && (e.ldres < N || M * (int64_t)e.ldres * 4 >= ((int64_t)1 << 31))) return false;
   if (e.gate_src && (!e.gate || e.ldgs < N || e.hw <= 0 || e.hw % BM || M * (int64_t)e.ldgs * 4 >= ((int64_t)1 << 31))) return false;
-  // output statistics: whole 32-row blocks per image, segments of 16 channels, and no tile cut in k (the summing launch
-  // does not leave them)
-  if (e.seg && (e.hw <= 0 || e.hw % 32 || M % e.hw || (e.seg_coff & 15) || e.seg_nseg <= 0 || gemm_bf16x3_needs_sum(1, (int)M, N, K)))
-    return false;
+  // output statistics: whole 32-row blocks per image, segments of 16 channels (a launch whose tiles are cut in k leaves
+  // them from its summing launch, one chunk per 8 rows: gemm_bf16x3_seg_rows)
+  if (e.seg && (e.hw <= 0 || e.hw % 32 || M % e.hw || (e.seg_coff & 15) || e.seg_nseg <= 0)) return false;
   return true;
 }
 
@@ -635,7 +667,8 @@ int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, i
   x3_shape(G, M, N, K, &P, &R, &S, &first);
   KD_REQUIRE(P <= X3_MAX_WG, "bf16x3 GEMM: more workgroups than the workspace holds");
   float* slab = (float*)ws;
-  const X3Epi e = epi ? *epi : X3Epi{};
+  X3Epi e = epi ? *epi : X3Epi{};
+  e.seg_rows8 = R && S > 1;
   if (epi) {
     if (a_f32)
       hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C,

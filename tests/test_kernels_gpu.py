@@ -309,8 +309,19 @@ def test_linear_bf16x3_epilogues_match_fp64(lib, device, M, N, K, bias, res, gat
     gs = torch.randn(M, N, generator=g(45)).to(device) if gate else None
     gt = torch.rand(M // hw, N, generator=g(46)).to(device) if gate else None
     y = torch.full((M, ldo), float("nan"), device=device)
+    # the GroupNorm partials the launch leaves (the plan's want_seg layers): a chunk per 32 rows from the kernel's epilogue,
+    # per 8 rows where the tiles are cut in k and the summing launch leaves them
+    rows = lib.kd_linear_bf16x3_seg_rows(M, N, K)
+    assert rows == (8 if (M // 256) * (N // 128) < 256 and K >= 256 else 32) or (M // 256) * (N // 128) % 256
+    seg = torch.full((M // hw, N // 16, hw // rows, 2), float("nan"), device=device, dtype=torch.float64)
     E.check(lib.kd_linear_bf16x3(E.ptr(xfull), lda, E.ptr(w), E.ptr(b), E.ptr(r), N, E.ptr(gs), N, E.ptr(gt), hw, E.ptr(y), ldo,
-                                 M, N, K, E.current_stream()))
+                                 M, N, K, C.c_void_p(seg.data_ptr()), E.current_stream()))
+    yy = y[:, :N].double().reshape(M // hw, hw, N // 16, 16)
+    assert torch.isfinite(seg).all()
+    s1, s2 = seg[..., 0].sum(-1), seg[..., 1].sum(-1)
+    w1, w2 = yy.sum((1, 3)), (yy * yy).sum((1, 3))
+    assert torch.allclose(s1, w1, rtol=1e-6, atol=1e-6 * float(yy.abs().sum((1, 3)).max())), float((s1 - w1).abs().max())
+    assert torch.allclose(s2, w2, rtol=1e-5), float((s2 / w2 - 1).abs().max())
     x = xfull[:, :K]
     ref = x.double() @ w.double().T
     f32 = (x @ w.T).double()
@@ -341,10 +352,10 @@ def test_linear_bf16x3_rejects_unsupported_shapes(lib, device):
     E = _E()
     t = torch.zeros(16, device=device)
     for M, N, K, hw in [(128, 128, 64, 256), (256, 64, 64, 256), (256, 128, 48, 256)]:
-        rc = lib.kd_linear_bf16x3(E.ptr(t), 0, E.ptr(t), None, None, 0, None, 0, None, hw, E.ptr(t), 0, M, N, K, E.current_stream())
+        rc = lib.kd_linear_bf16x3(E.ptr(t), 0, E.ptr(t), None, None, 0, None, 0, None, hw, E.ptr(t), 0, M, N, K, None, E.current_stream())
         assert rc != 0 and b"kd_linear_bf16x3" in lib.kd_last_error()
     # a gate needs whole images per 256-row tile
-    rc = lib.kd_linear_bf16x3(E.ptr(t), 0, E.ptr(t), None, None, 0, E.ptr(t), 128, E.ptr(t), 64, E.ptr(t), 0, 256, 128, 64,
+    rc = lib.kd_linear_bf16x3(E.ptr(t), 0, E.ptr(t), None, None, 0, E.ptr(t), 128, E.ptr(t), 64, E.ptr(t), 0, 256, 128, 64, None,
                               E.current_stream())
     assert rc != 0
 
