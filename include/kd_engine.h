@@ -320,10 +320,14 @@ int kd_gemm_bf16x3(const float* d_a, const float* d_b, float* d_c, int G, int M,
  * activations split into their three bf16 pieces by the kernel's loader waves, the weights once.  Optional pointers may
  * be NULL.  d_seg (optional): the (sum, sum of squares) partials of y the launch leaves for a GroupNorm that reads it,
  * fp64 [M / hw][N / 16][hw / rows][2] with rows = kd_linear_bf16x3_seg_rows(M, N, K) (32, or 8 where the tiles are cut in
- * k).  Replaces nn.Linear / 1x1 nn.Conv2d + the residual / GlobalContext-gate adds around them. */
+ * k).  act (0 none, 1 SiLU, 2 GELU, 3 sigmoid) is applied to the product + bias.  pixshuf_wo > 0: the Upsample form
+ * (conv1x1 -> SiLU -> PixelShuffle(2)): the rows are the pixels of maps of width pixshuf_wo, d_w's rows are packed
+ * n' = (2 i + j) N/4 + c, y is the [4 M][ldy] map of N / 4 channels and the statistics chunks are 4 per 32 input pixels
+ * (one per sub-position).  Replaces nn.Linear / 1x1 nn.Conv2d + the residual / GlobalContext-gate adds around them and
+ * Upsample's conv + activation + rearrange. */
 int kd_linear_bf16x3(const float* d_x, int ldx, const float* d_w, const float* d_bias, const float* d_res, int ldres,
                      const float* d_gate_src, int ldgs, const float* d_gate, int hw, float* d_y, int ldy, int M, int N, int K,
-                     double* d_seg, void* stream);
+                     int act, int pixshuf_wo, double* d_seg, void* stream);
 int kd_linear_bf16x3_seg_rows(int M, int N, int K);
 /* ResnetBlock `Block` in one pass over x: conv3x3(SiLU(FiLM(GroupNorm_G(x)))) + bias (+ d_res), the form the
  * plan uses for those layers: statistics, a per-(image, channel) affine fold, and the fused Winograd kernel

@@ -507,8 +507,9 @@ struct Builder {
   // a 1x1 conv / token GEMM that runs on the bf16x3 kernel's epilogue form (kernels_gemm_bf16x3.hip)
   bool x3_linear_ok(const T& x, int Cout, int K, int stride, int pad, const ConvOpt& o) const {
     if (cfg.gemm_bf16x3 < 0 || cfg.conv_algo != 0 || cfg.x3_linear < 0 || to_text || to_static || to_cond) return false;
-    if (K != 1 || stride != 1 || pad != 0 || o.rowrun || o.wz_rows || o.out_mode != OUT_NHWC || o.out_external) return false;
-    if (o.act != ACT_NONE || (o.gate_src && o.res)) return false;
+    if (K != 1 || stride != 1 || pad != 0 || o.rowrun || o.wz_rows || o.out_external) return false;
+    if (o.out_mode != OUT_NHWC && o.out_mode != OUT_PIXSHUF) return false;
+    if (o.gate_src && o.res) return false;
     // measured per launch against conv_buf_kernel at batch 16 (profiles/README.md, round 5): K >= 256 wins wherever the
     // launch runs whole rounds (256 -> 128 on the 256 x 256 map 748 -> 645 us); with fewer tiles than CUs every tile is cut
     // in k and a second launch adds the parts (10-15 us): K = 512 then only draws level (45.5 against 45.7 us), K >= 1024 wins
@@ -516,16 +517,19 @@ struct Builder {
     if (x.C < min_k || x.C % 32 || Cout % 128) return false;
     const int64_t M = x.rows();
     if (M % 256 || (M / 256) * (Cout / 128) < 64) return false;   // below 64 tiles the k-parts get too short
-    if (cfg.x3_linear == 0 && x.C < 1024 && gemm_bf16x3_needs_sum(1, (int)M, Cout, x.C)) return false;
+    const bool cut = gemm_bf16x3_needs_sum(1, (int)M, Cout, x.C);
+    if (cfg.x3_linear == 0 && x.C < 1024 && cut) return false;
     X3Epi e;
     e.lda = x.LD();
-    e.ldy = o.dst ? o.dst->LD() : Cout;
+    e.ldy = o.dst ? o.dst->LD() : (o.out_mode == OUT_PIXSHUF ? Cout / 4 : Cout);
     e.res = o.res ? (const float*)16 : nullptr;
     e.ldres = o.res ? o.res->LD() : 0;
     e.gate_src = o.gate_src ? (const float*)16 : nullptr;
     e.gate = o.gate_src ? (const float*)16 : nullptr;
     e.ldgs = o.gate_src ? o.gate_src->LD() : 0;
     e.hw = x.H * x.W;
+    e.act = o.act;
+    e.pixshuf_wo = o.out_mode == OUT_PIXSHUF ? x.W : 0;
     return gemm_bf16x3_epi_ok(M, Cout, x.C, e);
   }
   T conv(const T& x, const float* w, const float* bias, int Cout, int K, int stride, int pad, const ConvOpt& o) {
@@ -590,8 +594,9 @@ struct Builder {
       probe.partial = ks > 1 ? (float*)16 : nullptr;   // split-K: statistics from the reduction kernel, one chunk per pixel
       // (the bf16x3 form of a 1x1 conv whose tiles are cut in k leaves its partials from the summing launch, a chunk per 8 rows)
       const bool lin3 = x3_linear_ok(x, Cout, K, stride, pad, o);
-      const int nchunk = conv_seg_chunks(probe) > 0 && lin3 ? Ho * Wo / gemm_bf16x3_seg_rows(x.B * Ho * Wo, Cout, x.C)
-                                                            : conv_seg_chunks(probe);
+      const int nchunk = conv_seg_chunks(probe) > 0 && lin3 && o.out_mode == OUT_NHWC
+                             ? Ho * Wo / gemm_bf16x3_seg_rows(x.B * Ho * Wo, Cout, x.C)
+                             : conv_seg_chunks(probe);
       if (nchunk > 0 && cw % 16 == 0 && span % 16 == 0 && o.yoff >= seg_c0 && o.yoff + cw <= seg_c0 + span) {
         SegPart* have = nullptr;
         auto it = seg_of.find(y.at());
@@ -620,6 +625,8 @@ struct Builder {
       base.hw = Ho * Wo;
       base.ldy = p.ldy;
       base.lda = p.ldx;
+      base.act = o.act;
+      base.pixshuf_wo = o.out_mode == OUT_PIXSHUF ? Wo : 0;
       const int yoff = p.yoff;
       const int seg_coff = o_yoff - seg_c0;
       auto epi_of = [=]() {

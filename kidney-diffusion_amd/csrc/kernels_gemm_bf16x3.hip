@@ -28,6 +28,7 @@
 //              PFLOP/s of bf16 (2.5 nominal); in the plan the launches run at 0.85-1.25 = 140-210 TFLOP/s of fp32-equivalent
 //              work against 120-136 of the fp32 MFMA kernel on the same GEMMs (1.37-1.63 x per launch).
 #include "common.h"
+#include "epilogue.h"
 
 namespace kd {
 
@@ -303,7 +304,8 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t rsS =
       __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, (int)((size_t)X3_MAX_WG * BM * BN * sizeof(float)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)((int64_t)G * M * ldc * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)C, 0, (int)((int64_t)G * M * ldc * 4 * ((EPI && e.pixshuf_wo) ? 4 : 1)), 0x00020000);
   // the lane's part of the offsets, recomputed where it is used (from an opaque copy of the lane id: two registers less
   // held across the stage loop)
   auto lane_offsets = [&](int& vS, int& vC) __attribute__((always_inline)) {
@@ -356,11 +358,24 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
       const __amdgpu_buffer_rsrc_t rsG =
           __builtin_amdgcn_make_buffer_rsrc((void*)e.gate_src, 0, e.gate_src ? (int)((int64_t)M * e.ldgs * 4) : 0, 0x00020000);
       const int vR = (row0 * e.ldres + col0) * 4, vG = (row0 * e.ldgs + col0) * 4;
+      // PixelShuffle(2) form (upsample convs; weight rows packed n' = q Co + c, q = 2 i' + j'): the 32 columns of a block are
+      // 32 channels of ONE sub-position q (Co % 32 == 0), its 32 rows 32 consecutive pixels of one image row (Wo % 32 == 0),
+      // so the block lands on 32 output pixels two apart: out pixel (2 R + q / 2) 2 Wo + 2 ox + q % 2 of image row R
+      const int Co = N >> 2, Wo = e.pixshuf_wo;
+      const int vP = (8 * (ln >> 5) * ldc + (ln & 31)) * 4;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           float f1 = 0.f, f2 = 0.f;
+          const int rowb = mt * BM + wm * 64 + i * 32;
+          int q = 0, sP = 0;
+          if (Wo) {
+            const int cb = nt * BN + wn * 64 + j * 32;   // first column of the block
+            q = cb / Co;
+            const int R = rowb / Wo, ox0 = rowb - R * Wo;
+            sP = (((2 * R + (q >> 1)) * (2 * Wo) + 2 * ox0 + (q & 1)) * ldc + (cb - q * Co)) * 4;
+          }
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
             float add[4] = {0.f, 0.f, 0.f, 0.f};
@@ -379,8 +394,11 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const float v = (acc[i][j][4 * r4 + k] + bj[j]) + add[k];
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vC, s0 + ((i * 32 + 8 * r4 + k) * Nv + j * 32) * 4, 0);
+              float v = acc[i][j][4 * r4 + k] + bj[j];
+              if (e.act != ACT_NONE) v = ep_act(v, e.act);
+              v += add[k];
+              if (Wo) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vP, sP + 2 * (8 * r4 + k) * Nv * 4, 0);
+              else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vC, s0 + ((i * 32 + 8 * r4 + k) * Nv + j * 32) * 4, 0);
               f1 += v;
               f2 = fmaf(v, v, f2);
             }
@@ -398,16 +416,22 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
             d1 += __shfl_xor(d1, 32, 64);
             d2 += __shfl_xor(d2, 32, 64);
             if ((ln & 47) == 0) {
-              const int rowb = mt * BM + wm * 64 + i * 32, b = rowb / e.hw;
-              const int seg = (col0 + j * 32 + e.seg_coff) >> 4;
-              if (e.seg_rows8) {   // a launch whose left-over tiles are cut in k keeps a chunk per 8 rows (the summing launch's
-                                   // granularity): this block's sum goes into the first of its four chunks, zeros into the rest
+              const int b = rowb / e.hw;
+              if (Wo) {   // four sub-positions per 32-row block: chunk 4 (block of the image) + q, channel c = column - q Co
+                const int seg = (col0 + j * 32 - q * Co + e.seg_coff) >> 4;
+                double* o = e.seg + (((int64_t)b * e.seg_nseg + seg) * ((e.hw >> 5) * 4) + ((rowb - b * e.hw) >> 5) * 4 + q) * 2;
+                o[0] = d1;
+                o[1] = d2;
+              } else if (e.seg_rows8) {   // a launch whose left-over tiles are cut in k keeps a chunk per 8 rows (the summing
+                                          // launch's granularity): this block's sum goes into the first of its four chunks
+                const int seg = (col0 + j * 32 + e.seg_coff) >> 4;
                 double* o = e.seg + (((int64_t)b * e.seg_nseg + seg) * (e.hw >> 3) + ((rowb - b * e.hw) >> 3)) * 2;
                 o[0] = d1;
                 o[1] = d2;
 #pragma unroll
                 for (int z = 2; z < 8; ++z) o[z] = 0.0;
               } else {
+                const int seg = (col0 + j * 32 + e.seg_coff) >> 4;
                 double* o = e.seg + (((int64_t)b * e.seg_nseg + seg) * (e.hw >> 5) + ((rowb - b * e.hw) >> 5)) * 2;
                 o[0] = d1;
                 o[1] = d2;
@@ -542,7 +566,9 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
     for (int k = 0; k < 4; ++k) {
       float add = e.res ? e.res[(int64_t)(row + k) * e.ldres + col] : 0.f;
       if (e.gate_src) add = fmaf(e.gate_src[(int64_t)(row + k) * e.ldgs + col], gt, add);
-      const float o = (v[k] + b) + add;
+      float o = v[k] + b;
+      if (e.act != ACT_NONE) o = ep_act(o, e.act);
+      o += add;
       c[(int64_t)k * ldc] = o;
       f1 += o;
       f2 = fmaf(o, o, f2);
@@ -642,13 +668,19 @@ int launch_gemm_bf16x3_sum(float* C, int G, int M, int N, int K, const void* ws,
 // where a per-image gate is applied, 4-byte aligned maps
 bool gemm_bf16x3_epi_ok(int64_t M, int N, int K, const X3Epi& e) {
   if (!gemm_bf16x3_ok(1, M, N, K)) return false;
-  if (e.lda < K || e.ldy < N || (e.lda & 3)) return false;
+  if (e.lda < K || (e.ldy < N && !e.pixshuf_wo) || (e.lda & 3)) return false;
   if (M * (int64_t)e.lda * 4 >= ((int64_t)1 << 31) || M * (int64_t)e.ldy >= ((int64_t)1 << 29)) return false;
   if (e.res && (e.ldres < N || M * (int64_t)e.ldres * 4 >= ((int64_t)1 << 31))) return false;
   if (e.gate_src && (!e.gate || e.ldgs < N || e.hw <= 0 || e.hw % BM || M * (int64_t)e.ldgs * 4 >= ((int64_t)1 << 31))) return false;
   // output statistics: whole 32-row blocks per image, segments of 16 channels (a launch whose tiles are cut in k leaves
   // them from its summing launch, one chunk per 8 rows: gemm_bf16x3_seg_rows)
   if (e.seg && (e.hw <= 0 || e.hw % 32 || M % e.hw || (e.seg_coff & 15) || e.seg_nseg <= 0)) return false;
+  // PixelShuffle(2) output: whole 32-pixel runs of an image row and 32-channel runs of a sub-position per accumulator block;
+  // the kernel's epilogue only (no tile cut in k), no added maps
+  if (e.pixshuf_wo && (e.pixshuf_wo % 32 || M % e.pixshuf_wo || (N & 127) || e.res || e.gate_src || gemm_bf16x3_needs_sum(1, (int)M, N, K) ||
+                       4 * M * (int64_t)e.ldy >= ((int64_t)1 << 29) || e.ldy < N / 4))
+    return false;
+  if (e.act < ACT_NONE || e.act > ACT_SIGMOID) return false;
   return true;
 }
 

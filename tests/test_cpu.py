@@ -382,7 +382,7 @@ def test_library_build_id_matches_the_sources_and_the_build_is_up_to_date():
 def test_makefile_tracks_header_dependencies(tmp_path):
     """Round 2 shipped a library that predated its last header edit: the Makefile listed headers by hand and
     missed epilogue.h.  Dependencies now come from the compiler (-MMD): touching epilogue.h must schedule
-    exactly its users (kernels_conv, kernels_init, kernels_norm) + the link, and nothing when nothing changed."""
+    exactly its users (kernels_conv, kernels_gemm_bf16x3, kernels_init, kernels_norm) + the link, and nothing when nothing changed."""
     import os
     import shutil
     import subprocess
@@ -401,7 +401,7 @@ def test_makefile_tracks_header_dependencies(tmp_path):
     assert planned() == []
     try:
         os.utime(hdr, None)
-        assert planned() == ["kernels_conv.hip", "kernels_init.hip", "kernels_norm.hip"]
+        assert planned() == ["kernels_conv.hip", "kernels_gemm_bf16x3.hip", "kernels_init.hip", "kernels_norm.hip"]
     finally:
         os.utime(hdr, ns=(st.st_atime_ns, st.st_mtime_ns))
     assert planned() == []

@@ -315,7 +315,7 @@ def test_linear_bf16x3_epilogues_match_fp64(lib, device, M, N, K, bias, res, gat
     assert rows == (8 if (M // 256) * (N // 128) < 256 and K >= 256 else 32) or (M // 256) * (N // 128) % 256
     seg = torch.full((M // hw, N // 16, hw // rows, 2), float("nan"), device=device, dtype=torch.float64)
     E.check(lib.kd_linear_bf16x3(E.ptr(xfull), lda, E.ptr(w), E.ptr(b), E.ptr(r), N, E.ptr(gs), N, E.ptr(gt), hw, E.ptr(y), ldo,
-                                 M, N, K, C.c_void_p(seg.data_ptr()), E.current_stream()))
+                                 M, N, K, 0, 0, C.c_void_p(seg.data_ptr()), E.current_stream()))
     yy = y[:, :N].double().reshape(M // hw, hw, N // 16, 16)
     assert torch.isfinite(seg).all()
     s1, s2 = seg[..., 0].sum(-1), seg[..., 1].sum(-1)
@@ -352,12 +352,57 @@ def test_linear_bf16x3_rejects_unsupported_shapes(lib, device):
     E = _E()
     t = torch.zeros(16, device=device)
     for M, N, K, hw in [(128, 128, 64, 256), (256, 64, 64, 256), (256, 128, 48, 256)]:
-        rc = lib.kd_linear_bf16x3(E.ptr(t), 0, E.ptr(t), None, None, 0, None, 0, None, hw, E.ptr(t), 0, M, N, K, None, E.current_stream())
+        rc = lib.kd_linear_bf16x3(E.ptr(t), 0, E.ptr(t), None, None, 0, None, 0, None, hw, E.ptr(t), 0, M, N, K, 0, 0, None, E.current_stream())
         assert rc != 0 and b"kd_linear_bf16x3" in lib.kd_last_error()
     # a gate needs whole images per 256-row tile
-    rc = lib.kd_linear_bf16x3(E.ptr(t), 0, E.ptr(t), None, None, 0, E.ptr(t), 128, E.ptr(t), 64, E.ptr(t), 0, 256, 128, 64, None,
+    rc = lib.kd_linear_bf16x3(E.ptr(t), 0, E.ptr(t), None, None, 0, E.ptr(t), 128, E.ptr(t), 64, E.ptr(t), 0, 256, 128, 64, 0, 0, None,
                               E.current_stream())
     assert rc != 0
+    # PixelShuffle output: maps whose width is a multiple of 32, channel runs of 32 per sub-position
+    for M, N, K, wo in [(16384, 64, 64, 64), (16384, 256, 64, 48)]:
+        rc = lib.kd_linear_bf16x3(E.ptr(t), 0, E.ptr(t), None, None, 0, None, 0, None, 256, E.ptr(t), 0, M, N, K, 1, wo, None,
+                                  E.current_stream())
+        assert rc != 0
+
+
+@pytest.mark.parametrize("B,H,W,K,Co,ldy,act", [
+    (16, 64, 64, 256, 128, 256, 1),    # the 64 x 64 level's upsample of the SR UNet into the first half of a concat buffer
+    (16, 16, 16, 1024, 512, 0, 1),     # the 16 x 16 level's: 256 tiles
+    (4, 64, 32, 64, 32, 0, 2),         # a narrow one (Co = 32: one channel run per sub-position), GELU
+])
+def test_linear_bf16x3_upsample_form_matches_fp64(lib, device, B, H, W, K, Co, ldy, act):
+    """conv1x1 -> SiLU -> PixelShuffle(2) of the library's Upsample through the bf16x3 kernel's epilogue: weight
+    rows packed n' = (2 i + j) Co + c as the plan packs them, output [B, 2H, 2W, Co] written with row stride ldy."""
+    E = _E()
+    M, N = B * H * W, 4 * Co
+    x = torch.randn(M, K, generator=g(51)).to(device)
+    wt = (torch.randn(N, K, generator=g(52)) * 0.1).to(device)        # torch layout: row c * 4 + i * 2 + j
+    bt = torch.randn(N, generator=g(53)).to(device)
+    perm = torch.tensor([(n % Co) * 4 + n // Co for n in range(N)], device=device)   # packed row n' = q Co + c <- torch row c 4 + q
+    wp, bp = wt[perm].contiguous(), bt[perm].contiguous()
+    ldo = ldy or Co
+    y = torch.full((4 * M, ldo), float("nan"), device=device)
+    seg = torch.full((B, Co // 16, (H * W // 32) * 4, 2), float("nan"), device=device, dtype=torch.float64)
+    E.check(lib.kd_linear_bf16x3(E.ptr(x), 0, E.ptr(wp), E.ptr(bp), None, 0, None, 0, None, H * W, E.ptr(y), ldo, M, N, K, act, W,
+                                 C.c_void_p(seg.data_ptr()), E.current_stream()))
+    z = x.double() @ wt.double().T + bt.double()
+    z = F.silu(z) if act == 1 else F.gelu(z)
+    ref = F.pixel_shuffle(z.reshape(B, H, W, N).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)   # [B, 2H, 2W, Co]
+    got = y[:, :Co].double().reshape(B, 2 * H, 2 * W, Co)
+    assert torch.isfinite(got).all()
+    if ldo > Co:
+        assert torch.isnan(y[:, Co:]).all()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    f32 = x @ wt.T + bt
+    f32 = (F.silu(f32) if act == 1 else F.gelu(f32)).double()
+    e32 = float((f32 - z).abs().max() / z.abs().max())
+    print(f"upsample form M{M} K{K} Co{Co}: max err / max |y| {err:.2e} (fp32 torch {e32:.2e})")
+    assert err <= max(3.0 * e32, 2e-6), (err, e32)
+    assert torch.isfinite(seg).all()
+    s1, s2 = seg[..., 0].sum(-1), seg[..., 1].sum(-1)
+    gg = got.reshape(B, 4 * H * W, Co // 16, 16)
+    assert torch.allclose(s1, gg.sum((1, 3)), rtol=1e-6, atol=1e-6 * float(gg.abs().sum((1, 3)).max()))
+    assert torch.allclose(s2, (gg * gg).sum((1, 3)), rtol=1e-5)
 
 
 def test_gemm_bf16x3_two_launches_sharing_the_chip_do_not_depend_on_each_other(lib, device):
