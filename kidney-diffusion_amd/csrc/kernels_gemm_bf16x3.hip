@@ -120,10 +120,15 @@ constexpr int X3_MAX_SPLIT = 8;
 // writes 4 instead of 6 bytes per element, and its writes are what bound it (kernels_wino4.hip)
 // EPI: the token-GEMM / 1x1-conv form (G = 1): C rows with stride e.ldy, bias, residual, per-image gate (X3Epi, common.h);
 // A rows (A_F32) with stride e.lda.  Without it the code is that of the Winograd position GEMMs, instruction for instruction.
-template <bool A_F32, bool EPI>
+// EK: 0 = none (the Winograd position GEMMs), 1 = bias / residual / gate / statistics (token GEMMs, 1x1 skip convs),
+// 2 = 1 + activation and PixelShuffle output (upsample convs) - kinds of their own so that the common one carries neither
+// the extra branches nor the scalar registers of the rare one (the loop's scalar state spills to vector lanes: 73 spilled
+// SGPRs with kind 1 alone, 133 when one kernel served both - and 791 instead of 645 us on the 256 -> 128 conv of the 256^2 map)
+template <bool A_F32, int EK>
 __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __restrict__ A3, const uint16_t* __restrict__ B3,
                                                           float* __restrict__ C, int G, int M, int N, int K, int S,
                                                           float* __restrict__ slab, X3Epi e) {
+  constexpr bool EPI = EK != 0;
   const int lda = EPI ? e.lda : K, ldc = EPI ? e.ldy : N;
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE_B];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
   const __amdgpu_buffer_rsrc_t rsS =
       __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, (int)((size_t)X3_MAX_WG * BM * BN * sizeof(float)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)C, 0, (int)((int64_t)G * M * ldc * 4 * ((EPI && e.pixshuf_wo) ? 4 : 1)), 0x00020000);
+      (void*)C, 0, (int)((int64_t)G * M * ldc * 4 * ((EK == 2 && e.pixshuf_wo) ? 4 : 1)), 0x00020000);
   // the lane's part of the offsets, recomputed where it is used (from an opaque copy of the lane id: two registers less
   // held across the stage loop)
   auto lane_offsets = [&](int& vS, int& vC) __attribute__((always_inline)) {
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
       // PixelShuffle(2) form (upsample convs; weight rows packed n' = q Co + c, q = 2 i' + j'): the 32 columns of a block are
       // 32 channels of ONE sub-position q (Co % 32 == 0), its 32 rows 32 consecutive pixels of one image row (Wo % 32 == 0),
       // so the block lands on 32 output pixels two apart: out pixel (2 R + q / 2) 2 Wo + 2 ox + q % 2 of image row R
-      const int Co = N >> 2, Wo = e.pixshuf_wo;
+      const int Co = N >> 2, Wo = EK == 2 ? e.pixshuf_wo : 0;
       const int vP = (8 * (ln >> 5) * ldc + (ln & 31)) * 4;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
           float f1 = 0.f, f2 = 0.f;
           const int rowb = mt * BM + wm * 64 + i * 32;
           int q = 0, sP = 0;
-          if (Wo) {
+          if (EK == 2 && Wo) {
             const int cb = nt * BN + wn * 64 + j * 32;   // first column of the block
             q = cb / Co;
             const int R = rowb / Wo, ox0 = rowb - R * Wo;
@@ -395,9 +400,9 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               float v = acc[i][j][4 * r4 + k] + bj[j];
-              if (e.act != ACT_NONE) v = ep_act(v, e.act);
+              if (EK == 2 && e.act != ACT_NONE) v = ep_act(v, e.act);
               v += add[k];
-              if (Wo) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vP, sP + 2 * (8 * r4 + k) * Nv * 4, 0);
+              if (EK == 2 && Wo) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vP, sP + 2 * (8 * r4 + k) * Nv * 4, 0);
               else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vC, s0 + ((i * 32 + 8 * r4 + k) * Nv + j * 32) * 4, 0);
               f1 += v;
               f2 = fmaf(v, v, f2);
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
             d2 += __shfl_xor(d2, 32, 64);
             if ((ln & 47) == 0) {
               const int b = rowb / e.hw;
-              if (Wo) {   // four sub-positions per 32-row block: chunk 4 (block of the image) + q, channel c = column - q Co
+              if (EK == 2 && Wo) {   // four sub-positions per 32-row block: chunk 4 (block of the image) + q, channel c = column - q Co
                 const int seg = (col0 + j * 32 - q * Co + e.seg_coff) >> 4;
                 double* o = e.seg + (((int64_t)b * e.seg_nseg + seg) * ((e.hw >> 5) * 4) + ((rowb - b * e.hw) >> 5) * 4 + q) * 2;
                 o[0] = d1;
@@ -701,20 +706,18 @@ int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, i
   float* slab = (float*)ws;
   X3Epi e = epi ? *epi : X3Epi{};
   e.seg_rows8 = R && S > 1;
-  if (epi) {
-    if (a_f32)
-      hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C,
-                         G, M, N, K, S, slab, e);
-    else
-      hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true>), dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3,
-                         C, G, M, N, K, S, slab, e);
-  } else if (a_f32) {
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C,
-                       G, M, N, K, S, slab, e);
+  const dim3 grid((unsigned)P), block(768);
+  const uint16_t *a = (const uint16_t*)A3, *b = (const uint16_t*)B3;
+  const int kind = !epi ? 0 : (e.act != ACT_NONE || e.pixshuf_wo) ? 2 : 1;
+#define KD_X3(AF, EKIND) hipLaunchKernelGGL((gemm_bf16x3_kernel<AF, EKIND>), grid, block, 0, s, a, b, C, G, M, N, K, S, slab, e)
+  if (kind == 0) {
+    if (a_f32) KD_X3(true, 0); else KD_X3(false, 0);
+  } else if (kind == 1) {
+    if (a_f32) KD_X3(true, 1); else KD_X3(false, 1);
   } else {
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), dim3((unsigned)P), dim3(768), 0, s, (const uint16_t*)A3, (const uint16_t*)B3, C,
-                       G, M, N, K, S, slab, e);
+    if (a_f32) KD_X3(true, 2); else KD_X3(false, 2);
   }
+#undef KD_X3
   KD_HIP_CHECK(hipGetLastError());
   if (with_sum && R && S > 1) return launch_gemm_bf16x3_sum(C, G, M, N, K, ws, s, epi);
   return 0;
