@@ -3,9 +3,10 @@
 #   unet1c  train.py:30-41            base 64x64 seg-cond (text dim 3, 4 cond channels)  (configs[1])
 #   unet2   train_ultra_res.py:39-48  SR 64->256                           (configs[2], the headline)
 #   unet3   train_ultra_res.py:51-60  SR 256->1024                         (configs[3] stage 3)
-# usage: python scratch/fwd_configs.py <name> <batch> [size] [wino43_min_cin] [gemm_bf16x3]
+# usage: python scratch/fwd_configs.py <name> <batch> [size] [wino43_min_cin] [gemm_bf16x3] [x3_linear]
 import sys, time, ctypes as C, torch
-sys.path.insert(0, 'kidney-diffusion_amd')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / 'kidney-diffusion_amd'))
 import imagen_pytorch as ip
 from imagen_pytorch import _engine as E
 
@@ -39,6 +40,8 @@ if len(sys.argv) > 4:
     u.wino43_min_cin = int(sys.argv[4])
 if len(sys.argv) > 5:
     u.gemm_bf16x3 = int(sys.argv[5])
+if len(sys.argv) > 6:
+    u.x3_linear = int(sys.argv[6])
 with_text = bool(kw.get('cond_on_text'))
 t0 = time.time(); h = u.engine(B, S, dev, with_text=with_text)
 print(name, 'B', B, 'S', S, 'plan %.1f s' % (time.time() - t0), 'hbm GB %.1f' % (lib.kd_unet_hbm_bytes(h) / 1e9),
