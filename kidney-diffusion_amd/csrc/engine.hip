@@ -1020,7 +1020,11 @@ struct Builder {
     // 129 + 82 + 48 (GEMM + transforms), nine layers, -0.64 ms per forward; the larger maps stay: 256 -> 128 at 128 x 128
     // 688 against 256 + 378 + ~100, at 256 x 256 2618 against 934 + 1514 + ~400 (the transforms write 3.4 x the map)
     int thr = cfg.wino43_min_cin > 0 ? cfg.wino43_min_cin : 512;
-    if (cfg.wino43_min_cin == 0 && cfg.gemm_bf16x3 >= 0 && gemm_bf16x3_ok(36, Mt, cout, x.C) && (int64_t)x.B * x.H * x.W <= 65536)
+    // (round 5: 256 -> 256 on larger maps as well - unet3's 256 x 256 level at batch 8, 524288 pixels: 2.62 ms fused against
+    // 8 x (117 + 78 + 49 + 12) us for the same pixels at batch 1; what loses above 65536 pixels is Cout = 128, whose GEMMs
+    // are half as wide for the same transform traffic)
+    if (cfg.wino43_min_cin == 0 && cfg.gemm_bf16x3 >= 0 && gemm_bf16x3_ok(36, Mt, cout, x.C) &&
+        ((int64_t)x.B * x.H * x.W <= 65536 || cout >= 256))
       thr = 256;
     return x.C >= thr;
   }
