@@ -163,6 +163,7 @@ struct X3Epi {
   double* seg = nullptr;
   int seg_nseg = 0, seg_coff = 0;
   int seg_rows8 = 0;             // set by launch_gemm_bf16x3: chunks of 8 rows (gemm_bf16x3_seg_rows == 8)
+  int wide = 0;                  // set by launch_gemm_bf16x3: 16-byte epilogue accesses (every row 16-byte aligned)
   int act = ACT_NONE;            // applied to acc + bias, before the added maps
   // > 0: PixelShuffle(2) output (upsample convs, weight rows packed n' = q N/4 + c): the width Wo of the INPUT map; y is
   // [4 M][ldy] rows of N / 4 channels; statistics chunks as conv_buf_kernel's: 4 (32-row block of the image) + q

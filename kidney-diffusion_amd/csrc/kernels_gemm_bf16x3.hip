@@ -120,8 +120,8 @@ constexpr int X3_MAX_SPLIT = 8;
 // writes 4 instead of 6 bytes per element, and its writes are what bound it (kernels_wino4.hip)
 // EPI: the token-GEMM / 1x1-conv form (G = 1): C rows with stride e.ldy, bias, residual, per-image gate (X3Epi, common.h);
 // A rows (A_F32) with stride e.lda.  Without it the code is that of the Winograd position GEMMs, instruction for instruction.
-// EK: 0 = none (the Winograd position GEMMs), 1 = bias / residual / gate / statistics (token GEMMs, 1x1 skip convs),
-// 2 = 1 + activation and PixelShuffle output (upsample convs) - kinds of their own so that the common one carries neither
+// EK: 0 = none (the Winograd position GEMMs), 1 = bias / residual / gate / statistics with 16-byte accesses (token GEMMs,
+// 1x1 skip convs: rows 16-byte aligned), 2 = the general form: 4-byte accesses, activation, PixelShuffle output (upsample convs) - kinds of their own so that the common one carries neither
 // the extra branches nor the scalar registers of the rare one (the loop's scalar state spills to vector lanes: 73 spilled
 // SGPRs with kind 1 alone, 133 when one kernel served both - and 791 instead of 645 us on the 256 -> 128 conv of the 256^2 map)
 template <bool A_F32, int EK>
@@ -130,7 +130,10 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
                                                           float* __restrict__ slab, X3Epi e) {
   constexpr bool EPI = EK != 0;
   const int lda = EPI ? e.lda : K, ldc = EPI ? e.ldy : N;
-  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE_B];
+  // kind 1 turns its accumulator blocks through 2 KB of LDS per computing wave behind the ring (16-byte epilogue accesses):
+  // 147456 + 16384 = 160 KB, the whole LDS of a CU
+  constexpr int EPI_LDS = EK == 1 ? 8 * 2048 : 0;
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE_B + EPI_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mtiles = M / BM, ntiles = N / BN;
@@ -344,7 +347,95 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     int Nv = ldc;
     asm volatile("" : "+s"(Nv));   // (opaque: the 64 scalar offsets below are not to be hoisted out of the loop)
     const int s0 = ((g * M + mt * BM) * Nv + nt * BN) * 4;   // (G M ldc floats < 2^29: gemm_bf16x3_ok)
-    if constexpr (EPI) {
+    if constexpr (EK == 1) {
+      // 16-byte epilogue (MI355X guide T21; epilogue.h does the same for conv_buf_kernel): every 32 x 32 accumulator block
+      // goes through the wave's private 2 KB of LDS in two halves of 16 rows - 8 ds_write_b32, 2 ds_read_b128, no barrier -
+      // and leaves as two 16-byte stores per half (+ two loads per added map): 16 vector-memory instructions per lane and
+      // block instead of 64.  The short-K launches on the big maps (16 stages per tile) spent a third of a tile there.
+      // Buffer accesses with the lane's part in one VGPR per map (no 64-bit address registers across the loop).
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      float* sc = (float*)(lds + NST * STAGE_B) + wave * 512;
+      const int rr = ln >> 3, c4 = (ln & 7) * 4;              // read side: row rr (+ 8), columns c4 .. c4 + 3 of the half
+      const int wcol = ln & 31, wrow = 4 * (ln >> 5);         // write side: column, first row of the lane's four
+      const int colb = nt * BN + wn * 64, rowb0 = mt * BM + wm * 64;
+      const __amdgpu_buffer_rsrc_t rsR =
+          __builtin_amdgcn_make_buffer_rsrc((void*)e.res, 0, e.res ? (int)((int64_t)M * e.ldres * 4) : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsG =
+          __builtin_amdgcn_make_buffer_rsrc((void*)e.gate_src, 0, e.gate_src ? (int)((int64_t)M * e.ldgs * 4) : 0, 0x00020000);
+      const int vY = (rr * Nv + c4) * 4, vRw = (rr * e.ldres + c4) * 4, vGw = (rr * e.ldgs + c4) * 4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = colb + j * 32;   // first column of the block (the lane's: + c4)
+        const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const f4 b4 = e.bias ? *(const f4*)(e.bias + col + c4) : z4;
+        const f4 g4 = e.gate ? *(const f4*)(e.gate + (int64_t)((mt * BM) / e.hw) * N + col + c4) : z4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float f1 = 0.f, f2 = 0.f;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) sc[(8 * q + wrow + k) * 32 + wcol] = acc[i][j][4 * (2 * h + q) + k];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own writes have landed (nobody else reads them)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int row = rowb0 + i * 32 + 16 * h + 8 * t;   // (the lane's: + rr)
+              f4 v = *(const f4*)(sc + (rr + 8 * t) * 32 + c4) + b4;
+              if (e.gate_src) {
+                const u32x4 gq = __builtin_amdgcn_raw_buffer_load_b128(rsG, vGw, (row * e.ldgs + col) * 4, 0);
+                v += f4{__uint_as_float(gq[0]), __uint_as_float(gq[1]), __uint_as_float(gq[2]), __uint_as_float(gq[3])} * g4;
+              }
+              if (e.res) {
+                const u32x4 rq = __builtin_amdgcn_raw_buffer_load_b128(rsR, vRw, (row * e.ldres + col) * 4, 0);
+                v += f4{__uint_as_float(rq[0]), __uint_as_float(rq[1]), __uint_as_float(rq[2]), __uint_as_float(rq[3])};
+              }
+              const u32x4 o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+              __builtin_amdgcn_raw_buffer_store_b128(o, rsC, vY, (row * Nv + col) * 4, 0);
+              f1 += (v[0] + v[1]) + (v[2] + v[3]);
+              f2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], f2))));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next half's writes
+          }
+          if (e.seg) {
+            // the lane's 16 values of 4 channels in fp32, fp64 from there on: lanes with equal (ln & 7) >> 2 hold the same
+            // 16-channel segment - folded over the rows (lane bits 3-5) and the segment's four lanes (bits 0-1)
+            double d1 = (double)f1, d2 = (double)f2;
+#pragma unroll
+            for (int off = 8; off <= 32; off <<= 1) {
+              d1 += __shfl_xor(d1, off, 64);
+              d2 += __shfl_xor(d2, off, 64);
+            }
+#pragma unroll
+            for (int off = 1; off <= 2; off <<= 1) {
+              d1 += __shfl_xor(d1, off, 64);
+              d2 += __shfl_xor(d2, off, 64);
+            }
+            if ((ln & ~4) == 0) {   // lanes 0 and 4: columns 0-15 and 16-31 of the block
+              const int rowb = rowb0 + i * 32, b = rowb / e.hw;
+              const int seg = (col + 4 * (ln & 4) + e.seg_coff) >> 4;
+              if (e.seg_rows8) {   // (a launch whose left-over tiles are cut in k: chunks of 8 rows, this block's sum in the first of its four)
+                double* o = e.seg + (((int64_t)b * e.seg_nseg + seg) * (e.hw >> 3) + ((rowb - b * e.hw) >> 3)) * 2;
+                o[0] = d1;
+                o[1] = d2;
+#pragma unroll
+                for (int zz = 2; zz < 8; ++zz) o[zz] = 0.0;
+              } else {
+                double* o = e.seg + (((int64_t)b * e.seg_nseg + seg) * (e.hw >> 5) + ((rowb - b * e.hw) >> 5)) * 2;
+                o[0] = d1;
+                o[1] = d2;
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
+    if constexpr (EK == 2) {
       // y = acc + bias[col] (+ gate_src[row][col] gate[image][col]) (+ res[row][col]): a lane owns one column of each of its
       // two 32-column blocks, so bias and the gate are two scalars per lane; the added maps come in as 4-byte loads, four
       // per map in flight (the registers of the next tile's first fragments stay live across the epilogue)
@@ -706,9 +797,13 @@ int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, i
   float* slab = (float*)ws;
   X3Epi e = epi ? *epi : X3Epi{};
   e.seg_rows8 = R && S > 1;
+  // 16-byte epilogue accesses: every row of y and of the added maps 16-byte aligned
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  e.wide = epi && al16(C) && e.ldy % 4 == 0 && al16(e.bias) && (!e.res || (al16(e.res) && e.ldres % 4 == 0)) &&
+           (!e.gate_src || (al16(e.gate_src) && al16(e.gate) && e.ldgs % 4 == 0));
   const dim3 grid((unsigned)P), block(768);
   const uint16_t *a = (const uint16_t*)A3, *b = (const uint16_t*)B3;
-  const int kind = !epi ? 0 : (e.act != ACT_NONE || e.pixshuf_wo) ? 2 : 1;
+  const int kind = !epi ? 0 : (e.act != ACT_NONE || e.pixshuf_wo || !e.wide) ? 2 : 1;
 #define KD_X3(AF, EKIND) hipLaunchKernelGGL((gemm_bf16x3_kernel<AF, EKIND>), grid, block, 0, s, a, b, C, G, M, N, K, S, slab, e)
   if (kind == 0) {
     if (a_f32) KD_X3(true, 0); else KD_X3(false, 0);
