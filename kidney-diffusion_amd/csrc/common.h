@@ -282,9 +282,7 @@ int launch_linear_skinny_valu(const float* x, int ldx, const float* w, const flo
 int launch_gca_pool(const float* x, const float* wk, const float* bk, float* logits, float* pooled,
                     float* scratch, int B, int HW, int C, hipStream_t s);
 size_t gca_scratch_floats(int B, int HW, int C);
-// the whole gate of a GlobalContext block with C <= 512 in two launches (pooling partials; merge + FC + SiLU + FC + sigmoid);
-// w0 / w2 are the TRANSPOSED FC weights ([C][hid] and [hid][C]: launch_transpose of the torch tensors, once per plan)
-int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);   // dst [cols][rows] = src [rows][cols]^T
+// the whole gate of a GlobalContext block with C <= 512 in two launches (pooling partials; merge + FC + SiLU + FC + sigmoid)
 bool gca_gate_fused_ok(int C, int hid);
 int launch_gca_gate(const float* x, const float* wk, const float* bk, float* scratch, const float* w0, const float* b0, int hid,
                     const float* w2, const float* b2, float* gate, int B, int HW, int C, hipStream_t s);

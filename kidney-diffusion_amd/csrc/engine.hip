@@ -953,11 +953,8 @@ struct Builder {
       T scratch = alloc_bytes(gca_scratch_floats(h.B, h.HW(), C) * sizeof(float));
       T gate = alloc(h.B, 1, 1, C);
       size_t ho = h.off, so = scratch.off, go = gate.off;
-      // the gate kernel walks the FC weights by columns: transposed copies, made once per UNet
-      const float* w0t = cached("gca_w0t:" + pre, (size_t)hid * C, [&](float* dst) { KD_THROW_IF(launch_transpose(w0, dst, hid, C, 0)); });
-      const float* w2t = cached("gca_w2t:" + pre, (size_t)hid * C, [&](float* dst) { KD_THROW_IF(launch_transpose(w2, dst, C, hid, 0)); });
       emit([=](hipStream_t s) {
-        return launch_gca_gate(uu->P(ho), wk, bk, uu->P(so), w0t, b0, hid, w2t, b2, uu->P(go), Bx, HW, C, s);
+        return launch_gca_gate(uu->P(ho), wk, bk, uu->P(so), w0, b0, hid, w2, b2, uu->P(go), Bx, HW, C, s);
       }, "gca_gate HW" + std::to_string(HW) + " C" + std::to_string(C));
       u->macs += (int64_t)Bx * HW * C * 2 + (int64_t)Bx * C * hid * 2;
       free(scratch);

@@ -327,56 +327,42 @@ __global__ __launch_bounds__(256) void gca_gate_kernel(const float* __restrict__
     pooled[c] = ((s0 + s1) + (s2 + s3)) * inv;
   }
   __syncthreads();
-  // The FCs read TRANSPOSED weights (w0t [C][hid], w2t [hid][C], made once per plan: launch_transpose): thread h walks
-  // column h, so a wave reads 256 consecutive bytes per step and every weight byte crosses into the CU once.  (Round 4
-  // gave every thread a row of the torch layout: 64 lanes x 16 bytes a row stride apart per load - each 128-byte line came
-  // from L2 eight times; 45 of the 61 us of a C = 512 gate.)  Same products, same four interleaved sums per output as
-  // before: bit-identical results.
-  for (int h = threadIdx.x; h < hid; h += 256) {   // hidden = SiLU(W0 pooled + b0)
+  typedef float f32x4g __attribute__((ext_vector_type(4)));
+  for (int h = threadIdx.x; h < hid; h += 256) {   // hidden = SiLU(W0 pooled + b0): a thread streams one weight row
+    const f32x4g* wr = (const f32x4g*)(w0 + (int64_t)h * C);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int c = 0; c < C; c += 4) {
-      a0 = fmaf(w0[(int64_t)c * hid + h], pooled[c], a0);
-      a1 = fmaf(w0[(int64_t)(c + 1) * hid + h], pooled[c + 1], a1);
-      a2 = fmaf(w0[(int64_t)(c + 2) * hid + h], pooled[c + 2], a2);
-      a3 = fmaf(w0[(int64_t)(c + 3) * hid + h], pooled[c + 3], a3);
+    for (int c4 = 0; c4 < C / 4; ++c4) {
+      const f32x4g wv = wr[c4], pv = *(const f32x4g*)(pooled + 4 * c4);
+      a0 = fmaf(wv[0], pv[0], a0);
+      a1 = fmaf(wv[1], pv[1], a1);
+      a2 = fmaf(wv[2], pv[2], a2);
+      a3 = fmaf(wv[3], pv[3], a3);
     }
     const float v = ((a0 + a1) + (a2 + a3)) + b0[h];
     hidden[h] = v / (1.0f + expf(-v));
   }
   __syncthreads();
   for (int n = threadIdx.x; n < C; n += 256) {     // gate = sigmoid(W2 hidden + b2)
+    const float* wr = w2 + (int64_t)n * hid;
     float a0 = 0.f, a1 = 0.f;
     int h = 0;
     if ((hid & 3) == 0) {
       float a2 = 0.f, a3 = 0.f;
       for (; h < hid; h += 4) {
-        a0 = fmaf(w2[(int64_t)h * C + n], hidden[h], a0);
-        a1 = fmaf(w2[(int64_t)(h + 1) * C + n], hidden[h + 1], a1);
-        a2 = fmaf(w2[(int64_t)(h + 2) * C + n], hidden[h + 2], a2);
-        a3 = fmaf(w2[(int64_t)(h + 3) * C + n], hidden[h + 3], a3);
+        const f32x4g wv = *(const f32x4g*)(wr + h), hv = *(const f32x4g*)(hidden + h);
+        a0 = fmaf(wv[0], hv[0], a0);
+        a1 = fmaf(wv[1], hv[1], a1);
+        a2 = fmaf(wv[2], hv[2], a2);
+        a3 = fmaf(wv[3], hv[3], a3);
       }
       a0 += a2;
       a1 += a3;
     } else {
-      for (; h < hid; ++h) a0 = fmaf(w2[(int64_t)h * C + n], hidden[h], a0);
+      for (; h < hid; ++h) a0 = fmaf(wr[h], hidden[h], a0);
     }
     const float v = (a0 + a1) + b2[n];
     gate[(int64_t)b * C + n] = 1.0f / (1.0f + expf(-v));
   }
-}
-
-// dst [cols][rows] = src [rows][cols]^T (plan build)
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)rows * cols) return;
-  const int r = (int)(i / cols), c = (int)(i % cols);
-  dst[(int64_t)c * rows + r] = src[i];
-}
-int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s) {
-  const int64_t n = (int64_t)rows * cols;
-  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, cols);
-  KD_HIP_CHECK(hipGetLastError());
-  return 0;
 }
 
 bool gca_gate_fused_ok(int C, int hid) {
@@ -397,8 +383,7 @@ static int launch_gca_partial(const float* x, const float* wk, const float* bk, 
   return 0;
 }
 
-// pooling partials + the gate in two launches: gate[b][c] = sigmoid(W2 SiLU(W0 pooled_b + b0) + b2); w0t [C][hid] and
-// w2t [hid][C] are the TRANSPOSES of the torch weights (launch_transpose)
+// pooling partials + the gate in two launches: gate[b][c] = sigmoid(W2 SiLU(W0 pooled_b + b0) + b2)
 int launch_gca_gate(const float* x, const float* wk, const float* bk, float* scratch, const float* w0, const float* b0, int hid,
                     const float* w2, const float* b2, float* gate, int B, int HW, int C, hipStream_t s) {
   KD_REQUIRE(gca_gate_fused_ok(C, hid), "fused GlobalContext gate needs C % 4 == 0, C <= 512, hidden <= 256");

@@ -23,10 +23,6 @@
 // transform passes: Cin >= 512 (Builder::wino4_ok).
 #include "common.h"
 
-#ifndef KD_W4IN_WAVES
-#define KD_W4IN_WAVES 4   // waves per SIMD the input transform is compiled for (104 VGPRs; 5 = 96 VGPRs + 13 spilled: measured below)
-#endif
-
 namespace kd {
 
 namespace {
@@ -104,7 +100,7 @@ int launch_wino4_pack(const float* w_oihw, float* U, int O, int I, hipStream_t s
 // consecutive tiles x the 16 channels of one k-chunk (it writes 256 consecutive bytes per position and plane, and reads
 // 64 bytes per pixel and tile - the four waves of a workgroup take four consecutive chunks, 256 bytes per pixel)
 template <bool PLANES>
-__global__ __launch_bounds__(256, KD_W4IN_WAVES) void wino4_in_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void wino4_in_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ scale_shift, int ld_ss,
                                                        float* __restrict__ V, int B, int H, int W, int C, int G, int64_t nt,
