@@ -40,11 +40,12 @@ DOMINANT = ("wino_fused_gn128_kernel: fused Winograd F(2x2,3x3) 3x3 convs of the
             "in the kernel (sixteen waves, persistent workgroups, items of 16x8 pixels x 128 output channels)")
 WINO4 = ("conv_buf_kernel: the 36 position GEMMs of Winograd F(4x4,3x3) - the ResnetBlock 3x3 convs with Cin >= 512 "
          "(buffer-DMA implicit-GEMM kernel, batched over the positions)")
-WINO4_X3 = ("gemm_bf16x3_kernel: the 36 position GEMMs of Winograd F(4x4,3x3) - the ResnetBlock 3x3 convs with Cin >= 512 - as "
-            "fp32 products on the bf16 matrix pipe (three bf16 pieces per fp32 operand, six exact products per k-step, fp32 "
-            "accumulation; LDS-DMA ring fed by loader waves)")
-LIN_X3 = ("gemm_bf16x3_kernel, epilogue form: attention projections, feed-forward and 1x1 convs with K >= 512 as fp32 products "
-          "on the bf16 matrix pipe (fp32 activations split by the kernel's loader waves; bias / residual / gate epilogue)")
+WINO4_X3 = ("gemm_bf16x3_kernel: the 36 position GEMMs of Winograd F(4x4,3x3) - the ResnetBlock 3x3 convs with Cin >= 512, and "
+            "Cin >= 256 on the 64 x 64 level - as fp32 products on the bf16 matrix pipe (three bf16 pieces per fp32 operand, six "
+            "exact products per k-step, fp32 accumulation; LDS-DMA ring fed by loader waves)")
+LIN_X3 = ("gemm_bf16x3_kernel, epilogue form: attention projections, feed-forward, 1x1 skip convs, upsample and 2x2-s2 "
+          "downsample convs with K >= 256 as fp32 products on the bf16 matrix pipe (fp32 activations split by the kernel's loader waves; bias / "
+          "residual / GlobalContext gate / SiLU + PixelShuffle epilogue, GroupNorm partials of the output)")
 CONV_CLASS = "conv_buf_kernel / conv_igemm_kernel / init_conv_kernel: 1x1, 2x2-s2, init and final convs, token GEMMs"
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix = vector peak (v_mfma_f32_32x32x2_f32, exact fp32)
 # dense bf16 matrix peak (MI355X_MICROARCH.md "~2.5 PF dense": v_mfma_f32_32x32x16_bf16 at 32 cycles per SIMD, 1024 CU-SIMDs,
@@ -116,6 +117,8 @@ def kernel_classes(lib, handle, iters=3):
         if v: return 2 * 4.0 * BATCH * v[0] * v[1]
         v = g(r"ln rows(\d+) C(\d+)")
         if v: return 2 * 4.0 * v[0] * v[1]
+        v = g(r"ln x2 rows(\d+) C(\d+)")
+        if v: return 4 * 4.0 * v[0] * v[1]                         # x and the residual in; both LayerNorms' rows out
         v = g(r"(?:scale slice|skip copy|concat head|concat tail|concat) rows(\d+) C(\d+)")
         if v: return 2 * 4.0 * v[0] * v[1]
         v = g(r"attn N(\d+)")
@@ -130,9 +133,9 @@ def kernel_classes(lib, handle, iters=3):
         us, macs, mfma = float(us), int(macs), int(mfma)
         total_us += us
         m = re.match(r"(wino_in|wino_out|wino gemm|wino4_in3|wino4_in|wino4_out|wino4 gemm bf16x3|wino4 gemm) M(\d+) Cin(\d+) Cout(\d+)", label)
-        if label.startswith("conv k1 x3 sum"):   # the k-parts of the tiles added and the epilogue applied: time of the same GEMMs
+        if re.match(r"conv k[12] x3 sum", label):   # the k-parts of the tiles added and the epilogue applied: time of the same GEMMs
             cls[LIN_X3][1] += us
-        elif label.startswith("conv k1 x3"):     # `mfma` = bf16 MACs (6 per fp32 MAC)
+        elif re.match(r"conv k[12] x3", label):     # `mfma` = bf16 MACs (6 per fp32 MAC)
             add(LIN_X3, us, 2.0 * macs, 2.0 * mfma)
         elif label.startswith("conv k3"):
             add("conv_buf_kernel: direct 3x3 convs", us, 2.0 * macs, 2.0 * mfma)
@@ -431,7 +434,7 @@ def grid_workload(args, world, rank, device, distributed, barrier, canvases_list
     slab_dev = device if (not distributed or dist.get_backend() == "nccl") else torch.device("cpu")
 
     # deal order inside a generalised wave: batch-1 step times per stage (profiles/README.md) x this run's timesteps
-    stage_cost = {1: 6.9 * T, 2: 5.7 * T, 3: 46.4 * T}
+    stage_cost = {1: 6.9 * T, 2: 5.7 * T, 3: 43.0 * T}
 
     xstats = {}
 

@@ -37,7 +37,7 @@ const char* kd_last_error(void);
  * caller built against an older header can refuse the library instead of passing short structs.  History:
  *   1  rounds 1-3
  *   2  round 4/5: kd_conv3x3_winograd4_nhwc gained `gemm_bf16x3` (before `stream`); kd_unet_config_t gained
- *      `gemm_bf16x3` and `x3_linear`, kd_sample_args_t `cond_table_max_mb`; kd_unet_cond_table_refused_bytes, kd_linear_bf16x3 and kd_layernorm_ex added;
+ *      `gemm_bf16x3` and `x3_linear`, kd_sample_args_t `cond_table_max_mb`; kd_unet_cond_table_refused_bytes, kd_linear_bf16x3 (+ _seg_rows), kd_downsample_bf16x3 and kd_layernorm_ex added;
  *      kd_unet_cond_table_build_ms takes a non-const handle (it reads the build's events on demand) */
 #define KD_ENGINE_ABI_VERSION 2
 int kd_version(void);
@@ -329,6 +329,12 @@ int kd_linear_bf16x3(const float* d_x, int ldx, const float* d_w, const float* d
                      const float* d_gate_src, int ldgs, const float* d_gate, int hw, float* d_y, int ldy, int M, int N, int K,
                      int act, int pixshuf_wo, double* d_seg, void* stream);
 int kd_linear_bf16x3_seg_rows(int M, int N, int K);
+/* The library's Downsample (Rearrange 'b c (h s1) (w s2) -> b (c s1 s2) h w' + Conv2d(4 C, O, 1): a 2 x 2 / stride-2 conv,
+ * SURVEY A.1) on the same kernel: x NHWC [B][H][W][ldx] (C channels used), d_w the torch weight [O][4 C], y NHWC
+ * [B][H/2][W/2][O]; the kernel's loader waves gather the four input pixels of an output pixel.  d_seg as above with
+ * hw = (H/2) (W/2) and rows = kd_linear_bf16x3_seg_rows(B hw, O, 4 C). */
+int kd_downsample_bf16x3(const float* d_x, int ldx, const float* d_w, const float* d_bias, float* d_y, int B, int H, int W, int C,
+                         int O, double* d_seg, void* stream);
 /* ResnetBlock `Block` in one pass over x: conv3x3(SiLU(FiLM(GroupNorm_G(x)))) + bias (+ d_res), the form the
  * plan uses for those layers: statistics, a per-(image, channel) affine fold, and the fused Winograd kernel
  * with the activation applied to the raw patch in LDS (the activated map is never written).  d_scale_shift

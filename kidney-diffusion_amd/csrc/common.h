@@ -157,6 +157,9 @@ struct X3Epi {
   int hw = 0;                    // rows per image (gate), a multiple of 256
   int ldy = 0;                   // row stride of y (>= N)
   int lda = 0;                   // row stride of an fp32 A (a_f32); plane-form A is always dense
+  // > 0 (a_f32 only): the 2 x 2 / stride-2 conv form - A is a [B][a_hi][a_wi][lda] map of a_tap_c channels, row m an OUTPUT
+  // pixel, k = tap a_tap_c + c the channel c of its input pixel (2 oy + tap / 2, 2 ox + tap % 2); K = 4 a_tap_c
+  int a_tap_c = 0, a_wi = 0, a_hi = 0;
   // GroupNorm partials of y for the layer that normalises it (SegSrc): [images][seg_nseg][hw / rows][2] doubles with rows =
   // gemm_bf16x3_seg_rows(M, N, K) (32, or 8 where the tiles are cut in k and the summing launch leaves them), segment
   // (n + seg_coff) / 16 of column n; needs hw % 32 == 0

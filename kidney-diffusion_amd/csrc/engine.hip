@@ -1343,6 +1343,77 @@ struct Builder {
     return out;
   }
 
+  // the Downsample (pixel-unshuffle + conv1x1 = a 2 x 2 / stride-2 conv) on the bf16x3 kernel: its fp32-A loader gathers the
+  // four input pixels of an output pixel (X3Epi::a_tap_c), K = 4 C
+  X3Epi downsample_x3_epi(const T& x, int Cout) const {
+    X3Epi e;
+    e.lda = x.LD();
+    e.ldy = Cout;
+    e.a_tap_c = x.C;
+    e.a_wi = x.W;
+    e.a_hi = x.H;
+    e.hw = (x.H / 2) * (x.W / 2);
+    return e;
+  }
+  bool downsample_x3_ok(const T& x, int Cout) const {
+    if (cfg.gemm_bf16x3 < 0 || cfg.conv_algo != 0 || cfg.x3_linear < 0 || to_text || to_static || to_cond) return false;
+    if ((x.H & 1) || (x.W & 1) || x.C % 16 || Cout % 128) return false;
+    const int K = 4 * x.C;
+    const int64_t M = (int64_t)x.B * (x.H / 2) * (x.W / 2);
+    if (K < (cfg.x3_linear > 0 ? cfg.x3_linear : 256) || M % 256 || (M / 256) * (Cout / 128) < 64) return false;
+    if (cfg.x3_linear == 0 && K < 1024 && gemm_bf16x3_needs_sum(1, (int)M, Cout, K)) return false;
+    return gemm_bf16x3_epi_ok(M, Cout, K, downsample_x3_epi(x, Cout));
+  }
+  T downsample_x3(const T& x, const std::string& pre, const float* w_taps /*[tap][O][C]*/, const float* bias, int Cout) {
+    const int C = x.C, K = 4 * C, Ho = x.H / 2, Wo = x.W / 2;
+    const int64_t M = (int64_t)x.B * Ho * Wo;
+    // B operand [O][K] with k = tap C + c, then its three planes
+    const float* W3 = cached("x3down:" + pre, ((size_t)Cout * K * 3 + 1) / 2, [&](float* dst) {
+      float* wk = nullptr;
+      KD_HIP_THROW(hipMalloc((void**)&wk, (size_t)Cout * K * sizeof(float)));
+      int rc = 0;
+      for (int t = 0; t < 4 && !rc; ++t)
+        rc = launch_copy_scale_rows(w_taps + (size_t)t * Cout * C, C, wk + (size_t)t * C, K, C, 1.0f, Cout, 0);
+      if (!rc) rc = launch_split3(wk, dst, 1, Cout, K, 0);
+      hipError_t er = hipDeviceSynchronize();
+      (void)hipFree(wk);
+      KD_THROW_IF(rc);
+      KD_HIP_THROW(er);
+    });
+    if (!u->x3_ws) KD_HIP_THROW(hipMalloc(&u->x3_ws, gemm_bf16x3_workspace_bytes()));
+    T y = alloc(x.B, Ho, Wo, Cout);
+    const X3Epi base = downsample_x3_epi(x, Cout);
+    // the output feeds the GroupNorm of the level's first ResnetBlock: partials from the epilogue
+    const bool sg = seg_on && Cout % 16 == 0 && (Ho * Wo) % 32 == 0;
+    const int seg_rows = gemm_bf16x3_seg_rows((int)M, Cout, K);
+    const size_t sgo = sg ? add_seg(y, 0, Cout / 16, Ho * Wo / seg_rows) : 0;
+    const size_t xo = x.at(), yo = y.off;
+    kd_unet* uu = u;
+    auto epi_of = [=]() {
+      X3Epi e = base;
+      e.bias = bias;
+      if (sg) {
+        e.seg = (double*)uu->P(sgo);
+        e.seg_nseg = Cout / 16;
+      }
+      return e;
+    };
+    const std::string shape = " M" + std::to_string(M) + " Cin" + std::to_string(C) + " Cout" + std::to_string(Cout);
+    const int64_t m = M * Cout * K;
+    emit([=](hipStream_t s) {
+      const X3Epi e = epi_of();
+      return launch_gemm_bf16x3(uu->P(xo), W3, uu->P(yo), 1, (int)M, Cout, K, uu->x3_ws, s, true, false, &e);
+    }, "conv k2 x3" + shape, m);
+    u->macs += m;
+    u->op_mfma.back() = 6 * m;   // bf16 MACs
+    u->mfma_bf16_macs += 6 * m;
+    if (gemm_bf16x3_needs_sum(1, (int)M, Cout, K))
+      emit([=](hipStream_t s) {
+        const X3Epi e = epi_of();
+        return launch_gemm_bf16x3_sum(uu->P(yo), 1, (int)M, Cout, K, uu->x3_ws, s, &e);
+      }, "conv k2 x3 sum" + shape);
+    return y;
+  }
   T downsample(const T& x, const std::string& pre, int dim_out) {  // pixel-unshuffle + conv1x1 == 2x2/s2 conv
     if (cfg.downsample_conv4) {   // earlier library versions: Conv2d(dim, dim_out, 4, stride 2, pad 1)
       ConvOpt o4;
@@ -1353,6 +1424,7 @@ struct Builder {
     const int C = x.C;
     float* w = cached("unshuffle:" + pre, (size_t)dim_out * 4 * C,
                       [&](float* dst) { KD_THROW_IF(launch_pack_unshuffle(src, dst, dim_out, C, 0)); });
+    if (downsample_x3_ok(x, dim_out)) return downsample_x3(x, pre, w, P(pre + ".1.bias", dim_out), dim_out);
     ConvOpt o;
     o.want_seg = true;   // feeds the GroupNorm of the level's first ResnetBlock
     return conv(x, w, P(pre + ".1.bias", dim_out), dim_out, 2, 2, 0, o);

@@ -158,14 +158,25 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     const int l = wave - 8;
     const uint32_t planeB = (uint32_t)((int64_t)G * N * K * 2);
     const i32x4 rsB = make_rsrc(B3, 3u * planeB);
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A3, 0, (int)((int64_t)G * M * lda * 4), 0x00020000);
+    // (gather form: the resource spans the input map, 4 M pixels)
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)A3, 0, (int)(uint32_t)((int64_t)G * M * lda * 4 * ((EPI && e.a_tap_c > 0) ? 4 : 1)), 0x00020000);
     const uint32_t voffB = (uint32_t)((lane >> 1) * ROWB + (((lane & 1) ^ ((lane >> 4) & 1)) * 16));
     const uint32_t chunkB = (uint32_t)(N * ROWB);
     const int arow = l * 16 + (lane >> 2), aq = lane & 3;
-    const uint32_t voffA = (uint32_t)((arow * lda + aq * 4) * 4);
+    // the lane's four rows of a tile (arow + 64 j): byte offsets of their first value.  Plain rows: fixed, the tile's base
+    // goes into the scalar offset.  GATHER (X3Epi::a_tap_c = C > 0; kinds 1 / 2): the rows are the OUTPUT pixels of a 2 x 2 /
+    // stride-2 conv (the Downsample's pixel-unshuffle + 1x1 conv) over a [B][Hi][Wi][lda] map and k = tap C + c
+    // walks the four input pixels (tap = 2 dy + dx) of a row: the lane keeps the offset of pixel (2 oy, 2 ox) per row - set
+    // per tile - and the tap's displacement (dy Wi + dx) lda is wave-uniform, so it joins the scalar offset.
+    const bool gather = EPI && e.a_tap_c > 0;
+    const int cpt = gather ? e.a_tap_c / BK : nk;   // stage units per tap
+    uint32_t voffAj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) voffAj[j] = (uint32_t)(((arow + 64 * j) * lda + aq * 4) * 4);
     // LDS position of the lane's 8 bytes of a plane row: 16-byte slot (aq >> 1) ^ ((row >> 3) & 1), half aq & 1
     const int ldsA = arow * ROWB + ((((aq >> 1) ^ ((arow >> 3) & 1)) * 16) + (aq & 1) * 8);
-    int ic = 0, iseg = 0, ik = 0, ik1 = 0;
+    int ic = 0, iseg = 0, ik = 0, ik1 = 0, kc = 0, tap = 0;
     uint32_t baseA = 0, baseB = 0;
     auto locate = [&]() __attribute__((always_inline)) {
       const int it = seg_tile(iseg);
@@ -174,6 +185,18 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
       baseB = (uint32_t)((int64_t)g * N * K * 2) + (uint32_t)(nt * BN * ROWB);
       ik = iseg < rounds ? 0 : tail_k0;
       ik1 = iseg < rounds ? nk : tail_k1;
+      if (gather) {
+        const int Wo = e.a_wi >> 1, how = (e.a_hi >> 1) * Wo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = mt * BM + arow + 64 * j;
+          const int b = m / how, rem = m - b * how, oy = rem / Wo, ox = rem - oy * Wo;
+          voffAj[j] = (uint32_t)((((b * e.a_hi + 2 * oy) * e.a_wi + 2 * ox) * lda + aq * 4) * 4);
+        }
+        baseA = 0;
+        tap = ik / cpt;
+        kc = ik - tap * cpt;
+      }
     };
     locate();
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -182,9 +205,10 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     auto issue_next = [&](auto SET) __attribute__((always_inline)) {
       constexpr int set = decltype(SET)::value;
       const int st = ic & (NST - 1);
+      // plain: the tile's base + stage ik of the row; gather: the tap's pixel displacement + stage kc of the tap's channels
+      const uint32_t soA = gather ? (uint32_t)((((tap >> 1) * e.a_wi + (tap & 1)) * lda + kc * BK) * 4) : baseA + (uint32_t)(ik * (BK * 4));
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        ra[set][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA, baseA + (uint32_t)(ik * (BK * 4)) + (uint32_t)(j * 64 * lda * 4), 0);
+      for (int j = 0; j < 4; ++j) ra[set][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voffAj[j], soA, 0);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int id = l * 3 + j, pl = id >> 2, pr = id & 3;
@@ -192,6 +216,10 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
         dma16(rsB, dst, voffB, (uint32_t)pl * planeB + baseB + (uint32_t)ik * chunkB + (uint32_t)(pr * 32 * ROWB));
       }
       ++ic;
+      if (++kc == cpt) {
+        kc = 0;
+        ++tap;
+      }
       if (++ik == ik1 && ++iseg < nseg) locate();
     };
     auto write_unit = [&](int u, auto SET) __attribute__((always_inline)) {   // split + store the A planes of unit u
@@ -764,7 +792,11 @@ int launch_gemm_bf16x3_sum(float* C, int G, int M, int N, int K, const void* ws,
 // where a per-image gate is applied, 4-byte aligned maps
 bool gemm_bf16x3_epi_ok(int64_t M, int N, int K, const X3Epi& e) {
   if (!gemm_bf16x3_ok(1, M, N, K)) return false;
-  if (e.lda < K || (e.ldy < N && !e.pixshuf_wo) || (e.lda & 3)) return false;
+  if ((e.a_tap_c ? e.lda < e.a_tap_c : e.lda < K) || (e.ldy < N && !e.pixshuf_wo) || (e.lda & 3)) return false;
+  // gather form (2 x 2 / stride-2 conv): four taps of C channels, whole stage units per tap, even map sides, whole images
+  if (e.a_tap_c && (K != 4 * e.a_tap_c || e.a_tap_c % BK || (e.a_wi & 1) || (e.a_hi & 1) || e.a_wi <= 0 || e.a_hi <= 0 ||
+                    M % ((e.a_wi >> 1) * (int64_t)(e.a_hi >> 1)) || 4 * M * (int64_t)e.lda * 4 >= ((int64_t)1 << 32)))
+    return false;
   if (M * (int64_t)e.lda * 4 >= ((int64_t)1 << 31) || M * (int64_t)e.ldy >= ((int64_t)1 << 29)) return false;
   if (e.res && (e.ldres < N || M * (int64_t)e.ldres * 4 >= ((int64_t)1 << 31))) return false;
   if (e.gate_src && (!e.gate || e.ldgs < N || e.hw <= 0 || e.hw % BM || M * (int64_t)e.ldgs * 4 >= ((int64_t)1 << 31))) return false;
@@ -789,7 +821,7 @@ int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, i
                        bool with_sum, const X3Epi* epi) {
   KD_REQUIRE(gemm_bf16x3_ok(G, M, N, K), "bf16x3 GEMM needs M % 256 == 0, N % 128 == 0, K % 32 == 0 and operand planes < 4 GB");
   KD_REQUIRE((((uintptr_t)A3 | (uintptr_t)B3 | (uintptr_t)ws) & 15) == 0 && ws, "bf16x3 GEMM needs 16-byte aligned operand planes and a workspace");
-  KD_REQUIRE(!epi || (G == 1 && gemm_bf16x3_epi_ok(M, N, K, *epi) && (a_f32 || epi->lda == K)),
+  KD_REQUIRE(!epi || (G == 1 && gemm_bf16x3_epi_ok(M, N, K, *epi) && (a_f32 || (epi->lda == K && !epi->a_tap_c))),
              "bf16x3 GEMM, epilogue form: G = 1, row strides >= the row, byte offsets < 2^31, one image per 256-row tile under a gate");
   int P, R, S, first;
   x3_shape(G, M, N, K, &P, &R, &S, &first);

@@ -137,6 +137,7 @@ SIGNATURES = {
                                    C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p]),
     "kd_linear_bf16x3_seg_rows": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "kd_downsample_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]),
     "kd_gn_conv3x3_winograd_fused_nhwc": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "kd_init_conv_nchw": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
     "kd_groupnorm_silu_nhwc": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),

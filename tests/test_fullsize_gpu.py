@@ -157,7 +157,7 @@ def test_c3_sr_unet_at_the_benchmark_batch_matches_oracle(device, c3):
         assert labels.count("wino fused") == 56 - n4, labels.count("wino fused")
         # the attention projections and the feed-forward of the 16 x 16 / 32 x 32 levels (K >= 512) on the bf16x3 kernel's
         # epilogue form - unless switched off, or the bf16x3 kernels are off altogether
-        nlin[key] = labels.count("conv k1 x3 M")
+        nlin[key] = labels.count("conv k1 x3 M") + labels.count("conv k2 x3 M")
         assert (nlin[key] >= 20) == (lin == 0 and x3 == 0), (key, nlin[key])
         del pu
     print(f"C3 plan at batch 16: {nlin[0, 0]} token GEMMs / 1x1 convs on bf16x3; rel-L2 {errs[0, 0]:.3e} with them, "

@@ -405,6 +405,42 @@ def test_linear_bf16x3_upsample_form_matches_fp64(lib, device, B, H, W, K, Co, l
     assert torch.allclose(s2, (gg * gg).sum((1, 3)), rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,O,ldx", [
+    (16, 64, 64, 128, 256, 0),     # the SR UNet's 128 x 128 -> 64 x 64 downsample at a quarter of the size: K = 512, 128 tiles cut in k
+    (4, 128, 64, 256, 128, 384),   # K = 1024, input a channel slice of a wider buffer (row stride 384), 32 x ... 8192 rows: 32 tiles
+    (16, 32, 32, 64, 384, 0),      # K = 256
+])
+def test_downsample_bf16x3_matches_fp64(lib, device, B, H, W, Cin, O, ldx):
+    """Downsample of the library (pixel-unshuffle + conv1x1) through the bf16x3 kernel whose loader gathers the 2 x 2 input
+    pixels: against the same op in fp64 from the torch weight layout [O][4 C] (k = c 4 + 2 s1 + s2)."""
+    E = _E()
+    ld = ldx or Cin
+    xf = torch.randn(B, H, W, ld, generator=g(61)).to(device)
+    wt = (torch.randn(O, 4 * Cin, generator=g(62)) * 0.05).to(device)
+    bt = torch.randn(O, generator=g(63)).to(device)
+    M, hw = B * (H // 2) * (W // 2), (H // 2) * (W // 2)
+    if M % 256 or (M // 256) * (O // 128) < 1:
+        pytest.skip("shape outside the kernel's tiles")
+    y = torch.full((M, O), float("nan"), device=device)
+    rows = lib.kd_linear_bf16x3_seg_rows(M, O, 4 * Cin)
+    seg = torch.full((B, O // 16, hw // rows, 2), float("nan"), device=device, dtype=torch.float64)
+    E.check(lib.kd_downsample_bf16x3(E.ptr(xf), ld, E.ptr(wt), E.ptr(bt), E.ptr(y), B, H, W, Cin, O, C.c_void_p(seg.data_ptr()),
+                                     E.current_stream()))
+    x = xf[..., :Cin].double().permute(0, 3, 1, 2)                       # NCHW
+    xu = F.pixel_unshuffle(x, 2)                                          # channel c 4 + 2 s1 + s2
+    ref = F.conv2d(xu, wt.double().reshape(O, 4 * Cin, 1, 1), bt.double()).permute(0, 2, 3, 1).reshape(M, O)
+    f32 = F.conv2d(xu.float(), wt.reshape(O, 4 * Cin, 1, 1), bt).permute(0, 2, 3, 1).reshape(M, O).double()
+    got = y.double()
+    assert torch.isfinite(got).all()
+    e_x3, e_32 = float((got - ref).abs().max() / ref.abs().max()), float((f32 - ref).abs().max() / ref.abs().max())
+    print(f"downsample bf16x3 B{B} {H}x{W} C{Cin}->{O}: max err / max |y| {e_x3:.2e} (fp32 torch {e_32:.2e})")
+    assert e_x3 <= max(2.0 * e_32, 1e-6), (e_x3, e_32)
+    yy = got.reshape(B, hw, O // 16, 16)
+    s1, s2 = seg[..., 0].sum(-1), seg[..., 1].sum(-1)
+    assert torch.allclose(s1, yy.sum((1, 3)), rtol=1e-6, atol=1e-6 * float(yy.abs().sum((1, 3)).max()))
+    assert torch.allclose(s2, (yy * yy).sum((1, 3)), rtol=1e-5)
+
+
 def test_gemm_bf16x3_two_launches_sharing_the_chip_do_not_depend_on_each_other(lib, device):
     """No workgroup of the persistent kernel waits for another (the k-parts of a left-over tile leave their accumulators in
     slabs of the launch's own workspace, a second launch adds them), so two such launches on different streams (two plans of
