@@ -513,11 +513,13 @@ struct Builder {
     // measured per launch against conv_buf_kernel at batch 16 (profiles/README.md, round 5): K >= 256 wins wherever the
     // launch runs whole rounds (256 -> 128 on the 256 x 256 map 748 -> 645 us); with fewer tiles than CUs every tile is cut
     // in k and a second launch adds the parts (10-15 us): K = 512 then only draws level (45.5 against 45.7 us), K >= 1024 wins
-    const int min_k = cfg.x3_linear > 0 ? cfg.x3_linear : 256;
-    if (x.C < min_k || x.C % 32 || Cout % 128) return false;
+    // (K = 128 where the launch runs whole rounds: the 128 -> 512 upsample conv of the 128 x 128 map 455 -> 388 us)
+    if (x.C % 32 || Cout % 128) return false;
     const int64_t M = x.rows();
     if (M % 256 || (M / 256) * (Cout / 128) < 64) return false;   // below 64 tiles the k-parts get too short
     const bool cut = gemm_bf16x3_needs_sum(1, (int)M, Cout, x.C);
+    const int min_k = cfg.x3_linear > 0 ? cfg.x3_linear : cut ? 256 : 128;
+    if (x.C < min_k) return false;
     if (cfg.x3_linear == 0 && x.C < 1024 && cut) return false;
     X3Epi e;
     e.lda = x.LD();
