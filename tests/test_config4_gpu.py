@@ -39,7 +39,7 @@ def cascade(device):
     Imagen (device) holding the same weights."""
     import imagen_pytorch as ip
 
-    ous = [H.randomize_(R.Unet(**ULTRA_KW[s], lowres_cond=s > 1, cond_on_text=False, text_embed_dim=None), 300 + s).eval()
+    ous = [H.fast_oracle(H.randomize_(R.Unet(**ULTRA_KW[s], lowres_cond=s > 1, cond_on_text=False, text_embed_dim=None), 300 + s).eval())
            for s in (1, 2, 3)]
 
     def make(T):

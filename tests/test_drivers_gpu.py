@@ -31,7 +31,7 @@ def _pair(device, cond_channels, timesteps, seed):
     ous = []
     for s, name in ((1, "ultra1"), (2, "ultra2"), (3, "ultra3")):
         kw = dict(H.UNET_KW[name], cond_images_channels=cond_channels)
-        ous.append(H.randomize_(R.Unet(**kw, lowres_cond=s > 1, cond_on_text=False, text_embed_dim=None), seed + s).eval())
+        ous.append(H.fast_oracle(H.randomize_(R.Unet(**kw, lowres_cond=s > 1, cond_on_text=False, text_embed_dim=None), seed + s).eval()))
     oim = RS.Imagen(ous, timesteps=timesteps, **IMAGEN_KW)
     pim = ip.Imagen([ip.Unet(**u._locals) for u in oim.unets], timesteps=timesteps, random_crop_sizes=(None, None, 256),
                     **IMAGEN_KW)

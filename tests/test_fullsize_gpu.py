@@ -55,7 +55,7 @@ def _oracle(name, lowres, seed, text=False):
         u = R.Unet(**kw, lowres_cond=lowres, cond_on_text=False, text_embed_dim=None)
     else:
         u = R.Unet(**kw, lowres_cond=lowres, cond_on_text=True)
-    return H.randomize_(u, seed).eval()
+    return H.fast_oracle(H.randomize_(u, seed).eval())
 
 
 def _fwd_inputs(B, S, lowres, cc, seed):
@@ -273,7 +273,7 @@ def test_ultra_unet1_at_batch_16_matches_oracle(device):
     8x8 middle (dim 2048) switch to F(4x4,3x3) from batch 8 on; one forward against the oracle (5.5 TFLOP on the host)."""
     u1 = dict(dim=256, dim_mults=(1, 2, 4, 8), num_resnet_blocks=3, layer_attns=(F_, T_, T_, T_),
               layer_cross_attns=(F_, T_, T_, T_), cond_images_channels=3)
-    ou = H.randomize_(R.Unet(**u1, cond_on_text=False, text_embed_dim=None), 84).eval()
+    ou = H.fast_oracle(H.randomize_(R.Unet(**u1, cond_on_text=False, text_embed_dim=None), 84).eval())
     B, S = 16, 64
     x, _, cond, t, _ = _fwd_inputs(B, S, False, 3, seed=19)
     with torch.no_grad():
@@ -333,7 +333,7 @@ def test_kumar_two_stage_unets_forward_match_oracle(device):
               cond_images_channels=1)                                                                       # :41-51
     oim = RS.Imagen([R.Unet(**k1), R.Unet(**k2)], image_sizes=(64, 256), timesteps=1000, text_embed_dim=3)
     for n, u in enumerate(oim.unets):
-        H.randomize_(u, 91 + n).eval()
+        H.fast_oracle(H.randomize_(u, 91 + n).eval())
     pim = ip.Imagen([ip.Unet(**k1), ip.Unet(**k2)], image_sizes=(64, 256), timesteps=1000, text_embed_dim=3,
                     random_crop_sizes=(None, None))
     pim.load_state_dict(oim.state_dict(), strict=True)   # same key set after the re-cast (text modules of the SR UNet)
@@ -364,7 +364,7 @@ def test_segcond_unet3_blocks_2444_text_forward_matches_oracle(device):
     kw = dict(dim=128, cond_dim=512, dim_mults=(1, 2, 4, 8), num_resnet_blocks=(2, 4, 4, 4), memory_efficient=True,
               layer_attns=False, layer_cross_attns=(F_, F_, F_, T_), init_conv_to_final_conv_residual=True,
               cond_images_channels=4)
-    ou = H.randomize_(R.Unet(**kw, lowres_cond=True, cond_on_text=True, text_embed_dim=3), 95).eval()
+    ou = H.fast_oracle(H.randomize_(R.Unet(**kw, lowres_cond=True, cond_on_text=True, text_embed_dim=3), 95).eval())
     pu = H.product_unet_like(ou).to(device)
     B, S = 1, 256
     g = torch.Generator().manual_seed(18)
@@ -410,7 +410,7 @@ def test_c4_full_size_cascade_64_256_1024_matches_oracle(device):
 
     u1 = dict(dim=256, dim_mults=(1, 2, 4, 8), num_resnet_blocks=3, layer_attns=(F_, T_, T_, T_),
               layer_cross_attns=(F_, T_, T_, T_), cond_images_channels=3)   # train_ultra_res.py:29-36
-    ous = [H.randomize_(R.Unet(**u1, cond_on_text=False, text_embed_dim=None), 81).eval(), _oracle("ultra2", True, 82),
+    ous = [H.fast_oracle(H.randomize_(R.Unet(**u1, cond_on_text=False, text_embed_dim=None), 81).eval()), _oracle("ultra2", True, 82),
            _oracle("ultra3", True, 83)]
     kw = dict(image_sizes=(64, 256, 1024), timesteps=(2, 2, 2), pred_objectives=("noise", "noise", "noise"),
               condition_on_text=False)
