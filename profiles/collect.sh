@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # --no-cond-table: the table of the time conditioning is built once per schedule (250 x 21 small launches + 28 GB of weight
 # reads); in a 4-7 step trace that one-off work would be booked as per-step time and traffic
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-kernel-classes --no-line-grid --no-cond-table"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-kernel-classes --no-line-grid --no-other-configs --no-cond-table"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH --steps 5 --warmup 2 > $OUT/stats_bench.json 2> $OUT/stats.err || exit 1
 echo "stats pass done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- $BENCH --steps 3 --warmup 1 --no-graph > $OUT/fetch_bench.json 2> $OUT/fetch.err || exit 1

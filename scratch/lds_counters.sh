@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_lds
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/raw -o lds -- python3 $ROOT/bench.py --no-cpu-baseline --no-kernel-classes --no-line-grid --no-cond-table --steps 2 --warmup 1 --no-graph > $OUT/bench.json 2> $OUT/err.log
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/raw -o lds -- python3 $ROOT/bench.py --no-cpu-baseline --no-kernel-classes --no-line-grid --no-other-configs --no-cond-table --steps 2 --warmup 1 --no-graph > $OUT/bench.json 2> $OUT/err.log
 f=$(find $OUT/raw -name "*counter_collection.csv" | head -1)
 python3 - "$f" > $OUT/summary.txt <<PY
 import csv,sys,collections
