@@ -143,23 +143,48 @@ __global__ __launch_bounds__(256) void wino4_in_kernel(const float* __restrict__
       Bc[e] = bb;
     }
   }
-  f32x2 u[6][6];   // B^T d: column by column
+  // The 36 patch values first, unconditionally (coordinates clamped into the image; what lies outside is zeroed below, after
+  // the activation - the conv pads the ACTIVATED map): 36 independent loads in flight per thread.  (Until round 5 every load
+  // sat in its own bounds branch and hipcc waited for each before the next - `s_waitcnt vmcnt(0)` 36 times per thread; with
+  // the loads batched the 65536-pixel x 512-channel transform went from 181 us to the ~140 its traffic takes, see
+  // profiles/README.md.)
+  f32x2 u[6][6];
+  bool rok[6], cok[6];
+  uint32_t rowp[6], colp[6];   // byte offsets (the map is below 4 GB: launch_wino4_in): one 32-bit register per load address
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const int iy = 4 * ty - 1 + r;
+    rok[r] = iy >= 0 && iy < H;
+    rowp[r] = (uint32_t)((b * H + (iy < 0 ? 0 : iy >= H ? H - 1 : iy)) * W) * (uint32_t)(ldx * 4) + (uint32_t)(c * 4);
+  }
 #pragma unroll
   for (int s = 0; s < 6; ++s) {
     const int ix = 4 * tx - 1 + s;
+    cok[s] = ix >= 0 && ix < W;
+    colp[s] = (uint32_t)(ix < 0 ? 0 : ix >= W ? W - 1 : ix) * (uint32_t)(ldx * 4);
+  }
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(uint32_t)((int64_t)B * H * W * ldx * 4), 0x00020000);
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rsX, rowp[r] + colp[s], 0, 0);
+      u[r][s] = f32x2{__uint_as_float(q[0]), __uint_as_float(q[1])};
+    }
+  // B^T d: column by column, in place
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
     f32x2 d[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      const int iy = 4 * ty - 1 + r;
-      f32x2 v = {0.0f, 0.0f};
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-        v = *(const f32x2*)(x + (((int64_t)b * H + iy) * W + ix) * ldx + c);
-        if (norm) {
-          v[0] = w4_silu(v[0] * A[0] + Bc[0]);
-          v[1] = w4_silu(v[1] * A[1] + Bc[1]);
-        }
+      f32x2 v = u[r][s];
+      if (norm) {
+        v[0] = w4_silu(v[0] * A[0] + Bc[0]);
+        v[1] = w4_silu(v[1] * A[1] + Bc[1]);
       }
-      d[r] = v;
+      const f32x2 z = {0.0f, 0.0f};
+      d[r] = (rok[r] && cok[s]) ? v : z;
     }
     f32x2 tcol[6];
     w4_bt(d, tcol);
@@ -212,6 +237,7 @@ int launch_wino4_in(const float* x, int ldx, const float* stats, const float* ga
   if (mul_c0 < 0) mul_c0 = C;
   KD_REQUIRE(H % 4 == 0 && W % 4 == 0 && ldx >= C && C % 2 == 0 && ldx % 2 == 0 && ((uintptr_t)x & 7) == 0,
              "Winograd F(4x4,3x3) input transform needs H % 4 == 0, W % 4 == 0 and even C / row stride");
+  KD_REQUIRE((int64_t)B * H * W * ldx * 4 < ((int64_t)1 << 32), "Winograd F(4x4,3x3) input transform: maps below 4 GB");
   const int64_t nt = (int64_t)B * (H / 4) * (W / 4), total = nt * (C / 2);
   hipLaunchKernelGGL(wino4_in_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, stats, gamma,
                      beta, scale_shift, ld_ss, V, B, H, W, C, G, nt, mul_c0, mul);
@@ -225,6 +251,7 @@ int launch_wino4_in3(const float* x, int ldx, const float* stats, const float* g
   KD_REQUIRE(mul_c0 < 0 || stats, "Winograd F(4x4,3x3) input transform: a channel scale needs the GroupNorm form");
   if (mul_c0 < 0) mul_c0 = C;
   const int64_t nt = (int64_t)B * (H / 4) * (W / 4), total = nt * (C / 2);
+  KD_REQUIRE((int64_t)B * H * W * ldx * 4 < ((int64_t)1 << 32), "Winograd F(4x4,3x3) input transform: maps below 4 GB");
   KD_REQUIRE(H % 4 == 0 && W % 4 == 0 && ldx >= C && C % X3_BK == 0 && ldx % 2 == 0 && ((uintptr_t)x & 7) == 0 && nt % 8 == 0 &&
                  ((uintptr_t)V3 & 3) == 0,
              "Winograd F(4x4,3x3) input transform to bf16x3 planes needs H % 4 == 0, W % 4 == 0, C % 16 == 0, tiles % 8 == 0");

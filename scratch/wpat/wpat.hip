@@ -11,6 +11,60 @@
 #include <stdint.h>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+// OCC4: at most four waves per SIMD (what wino4_in_kernel<true>'s 104 VGPRs allow); VALU: ~the kernel's vector work per thread
+// (72 SiLUs through exp2 / rcp, ~700 plain operations), results folded into the stored value
+template <int MODE, bool READ, bool VALU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void wk4(uint32_t* __restrict__ V, const float* __restrict__ x, int64_t nt, int C) {
+  const int C2 = C >> 1;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nt * C2) return;
+  const int64_t w = idx >> 6;
+  const int lane = (int)(idx & 63), nkc = C / 16;
+  const int c = (int)(w % nkc) * 16 + (lane & 7) * 2;
+  const int64_t t = (w / nkc) * 8 + (lane >> 3);
+  float2 d[36];
+  {
+    const int Wt = 64, Ht = 64;
+    const int tx = (int)(t % Wt), ty = (int)((t / Wt) % Ht);
+    const int64_t b = t / (Wt * Ht);
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        int iy = 4 * ty - 1 + r, ix = 4 * tx - 1 + s;
+        iy = iy < 0 ? 0 : (iy > 4 * Ht - 1 ? 4 * Ht - 1 : iy);
+        ix = ix < 0 ? 0 : (ix > 4 * Wt - 1 ? 4 * Wt - 1 : ix);
+        d[r * 6 + s] = *(const float2*)(x + (((b * 4 * Ht + iy) * 4 * Wt + ix) * (int64_t)C + c));
+      }
+  }
+  if (VALU) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+      float a = d[i].x * 1.01f + 0.5f, bq = d[i].y * 0.99f - 0.5f;
+      a = a * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44f * a));
+      bq = bq * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44f * bq));
+      d[i] = make_float2(a, bq);
+    }
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+      for (int i = 0; i < 30; ++i) {
+        d[i].x = fmaf(d[i + 6].x, 4.0f, d[i].x) - 5.0f * d[i + 3].x;
+        d[i].y = fmaf(d[i + 6].y, 4.0f, d[i].y) - 5.0f * d[i + 3].y;
+      }
+  }
+  const int64_t pstride = nt * C2, plane = 36 * pstride;
+  uint32_t* out = V + ((int64_t)(c / 16) * nt + t) * 8 + (c % 16) / 2;
+#pragma unroll
+  for (int p = 0; p < 36; ++p) {
+    uint32_t* o = out + (int64_t)p * pstride;
+    const uint32_t v0 = __float_as_uint(d[p].x), v1 = __float_as_uint(d[p].y);
+    o[0] = v0;
+    o[plane] = v1;
+    o[2 * plane] = v0 ^ v1;
+  }
+}
+
 template <int MODE, bool READ>
 __global__ __launch_bounds__(256) void wk(uint32_t* __restrict__ V, const float* __restrict__ x, int64_t nt, int C) {
   const int C2 = C >> 1;
@@ -88,6 +142,22 @@ float run(uint32_t* V, const float* x, int64_t nt, int C, int iters) {
   return ms / iters * 1e3f;
 }
 
+template <bool VALU>
+float run4(uint32_t* V, const float* x, int64_t nt, int C, int iters) {
+  const int64_t total = nt * (C / 2);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((wk4<0, true, VALU>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, V, x, nt, C);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((wk4<0, true, VALU>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, V, x, nt, C);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / iters * 1e3f;
+}
+
 int main(int argc, char** argv) {
   const int64_t nt = argc > 1 ? atoll(argv[1]) : 4096 * 16;   // tiles (16 images of 64 x 64 tiles = 256 x 256 pixels... scaled)
   const int C = argc > 2 ? atoi(argv[2]) : 512;
@@ -108,5 +178,7 @@ int main(int argc, char** argv) {
   t = run<0, true>(V, x, nt, C, iters);  printf("  read+write  %-48s %8.1f us  %6.2f TB/s (writes)\n", names[0], t, vbytes / t / 1e6);
   t = run<1, true>(V, x, nt, C, iters);  printf("  read+write  %-48s %8.1f us  %6.2f TB/s (writes)\n", names[1], t, vbytes / t / 1e6);
   t = run<2, true>(V, x, nt, C, iters);  printf("  read+write  %-48s %8.1f us  %6.2f TB/s (writes)\n", names[2], t, vbytes / t / 1e6);
+  t = run4<false>(V, x, nt, C, iters);   printf("  read+write, 36 values held, <= 4 waves / SIMD       %-20s %8.1f us  %6.2f TB/s (writes)\n", "kernel layout", t, vbytes / t / 1e6);
+  t = run4<true>(V, x, nt, C, iters);    printf("  the same + the kernel's vector work (72 SiLU, ~700 ops) %-16s %8.1f us  %6.2f TB/s (writes)\n", "kernel layout", t, vbytes / t / 1e6);
   return 0;
 }
