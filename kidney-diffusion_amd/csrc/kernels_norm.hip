@@ -271,7 +271,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // LayerNorm, with the GEMM storing the raw product; same function on the same values as the GEMM epilogue's: bit-equal),
 // and an optional SECOND LayerNorm of the result (gain g2, output y2): the TransformerBlock's x1 = LN(proj) g + x followed
 // by h0 = LN(x1) g2 in one pass over the row.
-template <int NV>
+// FULL: C == 256 NV - no lane is past the row, so the loads carry no bounds branch and hipcc issues them together (with the
+// branch every load got a full wait behind it: 85 waits for 17 loads at C = 1024).  Gains / added maps come in groups of four
+// float4 per lane.
+template <int NV, bool FULL>
 __global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
                                                             const float* __restrict__ beta, const float* __restrict__ res,
                                                             int ldres, float* __restrict__ y, int rows, int C, float eps,
@@ -282,26 +285,28 @@ __global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restr
   const int lane = threadIdx.x & 63;
   const float* xr = x + (int64_t)row * ldx;
   const int C4 = C >> 2;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  auto in = [&](int i) { return FULL || lane + 64 * i < C4; };
+  // a lane past the row reads the row's first float4 instead (valid memory) and is masked wherever it would count
+  auto ld4 = [&](const float* p, int i) { return *(const f32x4*)(p + (in(i) ? lane + 64 * i : 0) * 4); };
   f32x4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = ld4(xr, i);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c4 = lane + 64 * i;
-    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (c4 < C4) {
-      v[i] = *(const f32x4*)(xr + c4 * 4);
-      if (in_act != ACT_NONE) {
+    if (in_act != ACT_NONE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[i][e] = ep_act(v[i][e], in_act);
-      }
-      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      for (int e = 0; e < 4; ++e) v[i][e] = ep_act(v[i][e], in_act);
     }
+    if (!in(i)) v[i] = z4;
+    if (in(i)) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   }
   const float mean = wave_sum_f(s) / (float)C;
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i)
-    if (lane + 64 * i < C4) {
+    if (in(i)) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float d = v[i][e] - mean;
@@ -310,35 +315,48 @@ __global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restr
     }
   const float rstd = 1.0f / sqrtf(wave_sum_f(ss) / (float)C + eps);
   float s2 = 0.f;
+  constexpr int GRP = NV < 4 ? NV : 4;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c4 = lane + 64 * i;
-    if (c4 < C4) {
-      const f32x4 gg = *(const f32x4*)(g + c4 * 4);
+  for (int i0 = 0; i0 < NV; i0 += GRP) {
+    f32x4 gg[GRP], bb[GRP], rr[GRP];
+#pragma unroll
+    for (int k = 0; k < GRP; ++k) gg[k] = ld4(g, i0 + k);
+    if (beta) {
+#pragma unroll
+      for (int k = 0; k < GRP; ++k) bb[k] = ld4(beta, i0 + k);
+    }
+    if (res) {
+#pragma unroll
+      for (int k = 0; k < GRP; ++k) rr[k] = ld4(res + (int64_t)row * ldres, i0 + k);
+    }
+#pragma unroll
+    for (int k = 0; k < GRP; ++k) {
+      const int i = i0 + k, c4 = lane + 64 * i;
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gg[e];
-      if (beta) o += *(const f32x4*)(beta + c4 * 4);
-      if (res) o += *(const f32x4*)(res + (int64_t)row * ldres + c4 * 4);
-      *(f32x4*)(y + (int64_t)row * C + c4 * 4) = o;
-      v[i] = o;
-      s2 += (o[0] + o[1]) + (o[2] + o[3]);
-    }
-    if (seg) {
-      // GroupNorm partials of y for the layer that normalises it (SegSrc, common.h): one chunk per pixel; the four lanes
-      // 4 j .. 4 j + 3 hold the 16 channels of segment j + 16 i (whole waves get here: C4 % 4 == 0, lanes past the row add zeros)
-      const bool in = c4 < C4;
-      double d1 = in ? (double)((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) : 0.0;
-      double d2 = in ? (double)fmaf(v[i][0], v[i][0], fmaf(v[i][1], v[i][1], fmaf(v[i][2], v[i][2], v[i][3] * v[i][3]))) : 0.0;
-      d1 += __shfl_xor(d1, 1, 64);
-      d2 += __shfl_xor(d2, 1, 64);
-      d1 += __shfl_xor(d1, 2, 64);
-      d2 += __shfl_xor(d2, 2, 64);
-      if (in && (lane & 3) == 0) {
-        const int b = row / seg_hw, pix = row - b * seg_hw;
-        double* o = seg + (((int64_t)b * (C >> 4) + (c4 >> 2)) * seg_hw + pix) * 2;
-        o[0] = d1;
-        o[1] = d2;
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gg[k][e];
+      if (beta) o += bb[k];
+      if (res) o += rr[k];
+      if (in(i)) {
+        *(f32x4*)(y + (int64_t)row * C + c4 * 4) = o;
+        v[i] = o;
+        s2 += (o[0] + o[1]) + (o[2] + o[3]);
+      }
+      if (seg) {
+        // GroupNorm partials of y for the layer that normalises it (SegSrc, common.h): one chunk per pixel; the four lanes
+        // 4 j .. 4 j + 3 hold the 16 channels of segment j + 16 i (whole waves get here: C4 % 4 == 0, lanes past the row add zeros)
+        double d1 = in(i) ? (double)((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) : 0.0;
+        double d2 = in(i) ? (double)fmaf(v[i][0], v[i][0], fmaf(v[i][1], v[i][1], fmaf(v[i][2], v[i][2], v[i][3] * v[i][3]))) : 0.0;
+        d1 += __shfl_xor(d1, 1, 64);
+        d2 += __shfl_xor(d2, 1, 64);
+        d1 += __shfl_xor(d1, 2, 64);
+        d2 += __shfl_xor(d2, 2, 64);
+        if (in(i) && (lane & 3) == 0) {
+          const int b = row / seg_hw, pix = row - b * seg_hw;
+          double* o2 = seg + (((int64_t)b * (C >> 4) + (c4 >> 2)) * seg_hw + pix) * 2;
+          o2[0] = d1;
+          o2[1] = d2;
+        }
       }
     }
   }
@@ -347,7 +365,7 @@ __global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restr
   float ss2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i)
-    if (lane + 64 * i < C4) {
+    if (in(i)) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float d = v[i][e] - mean2;
@@ -356,14 +374,17 @@ __global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restr
     }
   const float rstd2 = 1.0f / sqrtf(wave_sum_f(ss2) / (float)C + eps);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c4 = lane + 64 * i;
-    if (c4 < C4) {
-      const f32x4 gg = *(const f32x4*)(g2 + c4 * 4);
+  for (int i0 = 0; i0 < NV; i0 += GRP) {
+    f32x4 gg[GRP];
+#pragma unroll
+    for (int k = 0; k < GRP; ++k) gg[k] = ld4(g2, i0 + k);
+#pragma unroll
+    for (int k = 0; k < GRP; ++k) {
+      const int i = i0 + k;
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean2) * rstd2 * gg[e];
-      *(f32x4*)(y2 + (int64_t)row * C + c4 * 4) = o;
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean2) * rstd2 * gg[k][e];
+      if (in(i)) *(f32x4*)(y2 + (int64_t)row * C + (lane + 64 * i) * 4) = o;
     }
   }
 }
@@ -375,9 +396,15 @@ int launch_layernorm(const float* x, int ldx, const float* g, const float* beta,
   KD_REQUIRE(!seg || (C % 16 == 0 && C <= 4096 && seg_hw > 0 && rows % seg_hw == 0),
              "LayerNorm: output statistics need C % 16 == 0, C <= 4096 and whole images");
   const dim3 grid((rows + 3) / 4), block(256);
-#define KD_LN(NV_)                                                                                                     \
-  hipLaunchKernelGGL(layernorm_reg_kernel<NV_>, grid, block, 0, s, x, ldx, g, beta, res, ldres, y, rows, C, eps, in_act, g2, y2, seg, \
-                     seg_hw)
+#define KD_LN(NV_)                                                                                                              \
+  do {                                                                                                                          \
+    if (C == 256 * NV_)                                                                                                         \
+      hipLaunchKernelGGL((layernorm_reg_kernel<NV_, true>), grid, block, 0, s, x, ldx, g, beta, res, ldres, y, rows, C, eps, in_act, \
+                         g2, y2, seg, seg_hw);                                                                                  \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((layernorm_reg_kernel<NV_, false>), grid, block, 0, s, x, ldx, g, beta, res, ldres, y, rows, C, eps,     \
+                         in_act, g2, y2, seg, seg_hw);                                                                          \
+  } while (0)
   if (C <= 256) KD_LN(1);
   else if (C <= 512) KD_LN(2);
   else if (C <= 1024) KD_LN(4);

@@ -264,6 +264,7 @@ int launch_wino4_in3(const float* x, int ldx, const float* stats, const float* g
 // One thread: one tile x TWO channels -> 4x4 outputs (8-byte accesses); a wave = one tile x 128 consecutive channels
 // (C % 128 == 0) or a narrower run.  seg != nullptr: fp64 (sum, sum of squares) of the 16 outputs x 16 channels of every
 // 16-channel segment, entry [b][c / 16][tile of the image][2] (one chunk per tile: nchunk = (H/4)(W/4))
+template <bool RES>   // (its own kernel: the residual's registers cost the plain form a wave per SIMD)
 __global__ __launch_bounds__(256) void wino4_out_kernel(const float* __restrict__ D, const float* __restrict__ bias,
                                                         const float* __restrict__ res, int ldres, float* __restrict__ y,
                                                         int ldy, double* __restrict__ seg, int B, int H, int W, int C,
@@ -291,16 +292,34 @@ __global__ __launch_bounds__(256) void wino4_out_kernel(const float* __restrict_
   }
   f32x2 bv = {0.0f, 0.0f};
   if (bias) bv = *(const f32x2*)(bias + c);
+  // the residual a ROW of four pixels at a time, row i + 1's loads in flight under row i's transform and stores (round 5: as
+  // `if (res) v += ...` inside the loop each of the 16 loads had a full wait behind it; all 16 together with the 36 D values
+  // cost a wave per SIMD)
+  f32x2 rnext[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rnext[j] = f32x2{0.0f, 0.0f};
+  const int64_t pix0 = ((int64_t)b * H + 4 * ty) * W + 4 * tx;
+  if (RES) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rnext[j] = *(const f32x2*)(res + (pix0 + j) * ldres + c);
+  }
   float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    f32x2 rcur[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rcur[j] = rnext[j];
+    if (RES && i < 3) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rnext[j] = *(const f32x2*)(res + (pix0 + (int64_t)(i + 1) * W + j) * ldres + c);
+    }
     f32x2 o[4];
     w4_at(u[i], o);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t pix = ((int64_t)b * H + 4 * ty + i) * W + 4 * tx + j;
+      const int64_t pix = pix0 + (int64_t)i * W + j;
       f32x2 v = o[j] + bv;
-      if (res) v += *(const f32x2*)(res + pix * ldres + c);
+      v += rcur[j];
       *(f32x2*)(y + pix * ldy + c) = v;
       s1 += v[0] + v[1];
       s2 = fmaf(v[0], v[0], fmaf(v[1], v[1], s2));
@@ -330,8 +349,12 @@ int launch_wino4_out(const float* D, const float* bias, const float* res, int ld
   KD_REQUIRE(!seg_partial || C % 128 == 0 || (C % 16 == 0 && ((int64_t)B * (H / 4) * (W / 4) * (C / 2)) % 64 == 0),
              "output statistics need whole waves of 16-channel segments");
   const int64_t nt = (int64_t)B * (H / 4) * (W / 4), total = nt * (C / 2);
-  hipLaunchKernelGGL(wino4_out_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, D, bias, res, ldres, y, ldy,
-                     seg_partial, B, H, W, C, nt);
+  if (res)
+    hipLaunchKernelGGL(wino4_out_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, D, bias, res, ldres, y, ldy,
+                       seg_partial, B, H, W, C, nt);
+  else
+    hipLaunchKernelGGL(wino4_out_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, D, bias, res, ldres, y, ldy,
+                       seg_partial, B, H, W, C, nt);
   KD_HIP_CHECK(hipGetLastError());
   return 0;
 }
