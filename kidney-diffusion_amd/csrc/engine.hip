@@ -1025,9 +1025,10 @@ struct Builder {
     // (round 5: 256 -> 256 on larger maps as well - unet3's 256 x 256 level at batch 8, 524288 pixels: 2.62 ms fused against
     // 8 x (117 + 78 + 49 + 12) us for the same pixels at batch 1; what loses above 65536 pixels is Cout = 128, whose GEMMs
     // are half as wide for the same transform traffic)
-    if (cfg.wino43_min_cin == 0 && cfg.gemm_bf16x3 >= 0 && gemm_bf16x3_ok(36, Mt, cout, x.C) &&
-        ((int64_t)x.B * x.H * x.W <= 65536 || cout >= 256))
-      thr = 256;
+    // (later in round 5, with the input transform's loads issued together - 185 -> 121 us at 65536 pixels x 512 channels -
+    // Cout = 128 wins as well: 256 -> 128 at 128 x 128 698 us fused against 241 + 258 + 80, at 256 x 256 2639 against 1031 + 934
+    // + 299; same-box bench 27.81 / 27.89 -> 27.56 / 27.62 ms: the rule is Cin >= 256 wherever the bf16x3 GEMM takes the shape)
+    if (cfg.wino43_min_cin == 0 && cfg.gemm_bf16x3 >= 0 && gemm_bf16x3_ok(36, Mt, cout, x.C)) thr = 256;
     return x.C >= thr;
   }
   // skip_c0 >= 0: channels [skip_c0, ..) of x hold an unscaled skip tensor the layer must see times skip_scale: the input
