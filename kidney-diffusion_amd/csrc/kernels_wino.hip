@@ -99,24 +99,41 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
     }
   }
 
+  // the 16 patch values first, unconditionally (coordinates clamped into the image; what lies outside is zeroed after the
+  // activation - the conv pads the ACTIVATED map): with every load in its own bounds branch hipcc waited for each before the
+  // next (round 5, as in wino4_in_kernel)
   f32x4 d[4][4];
+  bool rok[4], cok[4];
+  int64_t rowp[4];
+  int colp[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int iy = 2 * ty - 1 + r;
+    rok[r] = iy >= 0 && iy < H;
+    rowp[r] = ((int64_t)b * H + (iy < 0 ? 0 : iy >= H ? H - 1 : iy)) * W;
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int ix = 2 * tx - 1 + s;
+    cok[s] = ix >= 0 && ix < W;
+    colp[s] = ix < 0 ? 0 : ix >= W ? W - 1 : ix;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) d[r][s] = *(const f32x4*)(x + (rowp[r] + colp[s]) * ldx + c4 * 4);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int ix = 2 * tx - 1 + s;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-        v = *(const f32x4*)(x + (((int64_t)b * H + iy) * W + ix) * ldx + c4 * 4);
-        if (norm) {
+      f32x4 v = d[r][s];
+      if (norm) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = wino_silu(v[e] * A[e] + Bc[e]);
-        }
+        for (int e = 0; e < 4; ++e) v[e] = wino_silu(v[e] * A[e] + Bc[e]);
       }
-      d[r][s] = v;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      d[r][s] = (rok[r] && cok[s]) ? v : z;
     }
-  }
   // B^T d
   f32x4 u[4][4];
 #pragma unroll

@@ -48,14 +48,17 @@ FULL_KW = {
 }
 
 
-def _oracle(name, lowres, seed, text=False):
+def _oracle(name, lowres, seed, text=False, fast=True):
     kw = dict(FULL_KW[name])
     if not text:
         kw.pop("text_embed_dim", None)
         u = R.Unet(**kw, lowres_cond=lowres, cond_on_text=False, text_embed_dim=None)
     else:
         u = R.Unet(**kw, lowres_cond=lowres, cond_on_text=True)
-    return H.fast_oracle(H.randomize_(u, seed).eval())
+    u = H.randomize_(u, seed).eval()
+    # fast: the convolutions in channels_last (a third less host time; its other fp32 summation order moves the result by
+    # ~1-3e-6 rel-L2, so the C3 fixture - whose errors DESIGN.md quotes - keeps the default layout)
+    return H.fast_oracle(u) if fast else u
 
 
 def _fwd_inputs(B, S, lowres, cc, seed):
@@ -76,7 +79,7 @@ def _dv(device):
 @pytest.fixture(scope="module")
 def c3():
     """Oracle results of the headline UNet, computed once for both plans (Winograd / direct)."""
-    ou = _oracle("ultra2", True, seed=21)
+    ou = _oracle("ultra2", True, seed=21, fast=False)
     B, S = 2, 256
     inp = _fwd_inputs(B, S, True, 3, seed=5)
     x, lr, cond, t, tl = inp
