@@ -387,7 +387,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
       float* sc = (float*)(lds + NST * STAGE_B) + wave * 512;
       const int rr = ln >> 3, c4 = (ln & 7) * 4;              // read side: row rr (+ 8), columns c4 .. c4 + 3 of the half
       const int wcol = ln & 31, wrow = 4 * (ln >> 5);         // write side: column, first row of the lane's four
-      const int colb = nt * BN + wn * 64, rowb0 = mt * BM + wm * 64;
+      const int colb = nt * BN + wn * 64, rowb0 = g * M + mt * BM + wm * 64;   // (g > 0: the Winograd position GEMMs, no added maps)
       const __amdgpu_buffer_rsrc_t rsR =
           __builtin_amdgcn_make_buffer_rsrc((void*)e.res, 0, e.res ? (int)((int64_t)M * e.ldres * 4) : 0, 0x00020000);
       const __amdgpu_buffer_rsrc_t rsG =
@@ -831,11 +831,19 @@ int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, i
   e.seg_rows8 = R && S > 1;
   // 16-byte epilogue accesses: every row of y and of the added maps 16-byte aligned
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-  e.wide = epi && al16(C) && e.ldy % 4 == 0 && al16(e.bias) && (!e.res || (al16(e.res) && e.ldres % 4 == 0)) &&
+  // The plain form (Winograd position GEMMs, G > 1) stores its tiles through kind 1's 16-byte path too - nothing added, rows
+  // of N floats: 16 store instructions per lane and tile instead of 64, what the K = 256 launches (16 stages per tile) gain
+  // most from.  (`epi` stays null for the summing launch: sum_slabs_kernel<false>.)
+  const bool plain_wide = !epi && !a_f32 && al16(C) && kd_switch("KD_X3_WIDE_STORE", 1) != 0;
+  if (plain_wide) {
+    e.ldy = N;
+    e.lda = K;
+  }
+  e.wide = (epi || plain_wide) && al16(C) && e.ldy % 4 == 0 && al16(e.bias) && (!e.res || (al16(e.res) && e.ldres % 4 == 0)) &&
            (!e.gate_src || (al16(e.gate_src) && al16(e.gate) && e.ldgs % 4 == 0));
   const dim3 grid((unsigned)P), block(768);
   const uint16_t *a = (const uint16_t*)A3, *b = (const uint16_t*)B3;
-  const int kind = !epi ? 0 : (e.act != ACT_NONE || e.pixshuf_wo || !e.wide) ? 2 : 1;
+  const int kind = plain_wide && e.wide ? 1 : !epi ? 0 : (e.act != ACT_NONE || e.pixshuf_wo || !e.wide) ? 2 : 1;
 #define KD_X3(AF, EKIND) hipLaunchKernelGGL((gemm_bf16x3_kernel<AF, EKIND>), grid, block, 0, s, a, b, C, G, M, N, K, S, slab, e)
   if (kind == 0) {
     if (a_f32) KD_X3(true, 0); else KD_X3(false, 0);
