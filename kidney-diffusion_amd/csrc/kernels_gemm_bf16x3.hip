@@ -673,8 +673,14 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int t = blockIdx.x >> 5, el = (blockIdx.x & 31) * 256 + threadIdx.x;   // left-over tile, float4 of its slab
   const f32x4* s = (const f32x4*)(slab + (size_t)t * S * (BM * BN)) + el;
-  f32x4 v = s[0];
-  for (int p = 1; p < S; ++p) v += s[(size_t)p * (BM * BN / 4)];
+  // all parts in flight together, added in part order (as a run-time loop hipcc waited for every load before the next: S - 1
+  // dependent round trips - most of the 10-16 us of these launches); parts past S re-read the last one and are not added
+  f32x4 part[X3_MAX_SPLIT];
+#pragma unroll
+  for (int p = 0; p < X3_MAX_SPLIT; ++p) part[p] = s[(size_t)(p < S ? p : S - 1) * (BM * BN / 4)];
+  f32x4 v = part[0];
+#pragma unroll
+  for (int p = 1; p < X3_MAX_SPLIT; ++p) v = p < S ? v + part[p] : v;
   const int lane = el & 63, wave = (el >> 6) & 7, r4 = (el >> 9) & 3, ij = el >> 11;
   const int mtiles = M / BM, ntiles = N / BN, tile = first_tile + t;
   const int nt = tile % ntiles, mt = (tile / ntiles) % mtiles, g = tile / (ntiles * mtiles);
@@ -686,10 +692,19 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
     const float b = e.bias ? e.bias[col] : 0.f;
     const float gt = e.gate ? e.gate[(int64_t)(row / e.hw) * N + col] : 0.f;
     float f1 = 0.f, f2 = 0.f;
+    float radd[4] = {0.f, 0.f, 0.f, 0.f}, gsrc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e.res) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) radd[k] = e.res[(int64_t)(row + k) * e.ldres + col];
+    }
+    if (e.gate_src) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gsrc[k] = e.gate_src[(int64_t)(row + k) * e.ldgs + col];
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float add = e.res ? e.res[(int64_t)(row + k) * e.ldres + col] : 0.f;
-      if (e.gate_src) add = fmaf(e.gate_src[(int64_t)(row + k) * e.ldgs + col], gt, add);
+      float add = radd[k];
+      if (e.gate_src) add = fmaf(gsrc[k], gt, add);
       float o = v[k] + b;
       if (e.act != ACT_NONE) o = ep_act(o, e.act);
       o += add;
