@@ -596,9 +596,13 @@ struct Builder {
       probe.partial = ks > 1 ? (float*)16 : nullptr;   // split-K: statistics from the reduction kernel, one chunk per pixel
       // (the bf16x3 form of a 1x1 conv whose tiles are cut in k leaves its partials from the summing launch, a chunk per 8 rows)
       const bool lin3 = x3_linear_ok(x, Cout, K, stride, pad, o);
-      const int nchunk = conv_seg_chunks(probe) > 0 && lin3 && o.out_mode == OUT_NHWC
-                             ? Ho * Wo / gemm_bf16x3_seg_rows(x.B * Ho * Wo, Cout, x.C)
-                             : conv_seg_chunks(probe);
+      int nchunk = conv_seg_chunks(probe) > 0 && lin3 && o.out_mode == OUT_NHWC
+                       ? Ho * Wo / gemm_bf16x3_seg_rows(x.B * Ho * Wo, Cout, x.C)
+                       : conv_seg_chunks(probe);
+      // (the bf16x3 PixelShuffle epilogue takes maps 16 pixels wide - conv_buf_kernel's wants 32 - with the same chunks: four
+      // sub-positions per 32 input pixels)
+      if (lin3 && o.out_mode == OUT_PIXSHUF && nchunk == 0 && (Ho * Wo) % 32 == 0 && ((Cout >> 2) & 31) == 0)
+        nchunk = (Ho * Wo / 32) * 4;
       if (nchunk > 0 && cw % 16 == 0 && span % 16 == 0 && o.yoff >= seg_c0 && o.yoff + cw <= seg_c0 + span) {
         SegPart* have = nullptr;
         auto it = seg_of.find(y.at());

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
           __builtin_amdgcn_make_buffer_rsrc((void*)e.gate_src, 0, e.gate_src ? (int)((int64_t)M * e.ldgs * 4) : 0, 0x00020000);
       const int vR = (row0 * e.ldres + col0) * 4, vG = (row0 * e.ldgs + col0) * 4;
       // PixelShuffle(2) form (upsample convs; weight rows packed n' = q Co + c, q = 2 i' + j'): the 32 columns of a block are
-      // 32 channels of ONE sub-position q (Co % 32 == 0), its 32 rows 32 consecutive pixels of one image row (Wo % 32 == 0),
+      // 32 channels of ONE sub-position q (Co % 32 == 0), its 32 rows 16-pixel runs of image rows (Wo % 16 == 0),
       // so the block lands on 32 output pixels two apart: out pixel (2 R + q / 2) 2 Wo + 2 ox + q % 2 of image row R
       const int Co = N >> 2, Wo = EK == 2 ? e.pixshuf_wo : 0;
       const int vP = (8 * (ln >> 5) * ldc + (ln & 31)) * 4;
@@ -493,12 +493,16 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
         for (int j = 0; j < 2; ++j) {
           float f1 = 0.f, f2 = 0.f;
           const int rowb = mt * BM + wm * 64 + i * 32;
-          int q = 0, sP = 0;
+          // (the block's rows 0-15 and 16-31 are located separately: maps 16 pixels wide put them in two image rows)
+          int q = 0, sPh[2] = {0, 0};
           if (EK == 2 && Wo) {
             const int cb = nt * BN + wn * 64 + j * 32;   // first column of the block
             q = cb / Co;
-            const int R = rowb / Wo, ox0 = rowb - R * Wo;
-            sP = (((2 * R + (q >> 1)) * (2 * Wo) + 2 * ox0 + (q & 1)) * ldc + (cb - q * Co)) * 4;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+              const int rowh = rowb + 16 * hf, R = rowh / Wo, ox0 = rowh - R * Wo;
+              sPh[hf] = (((2 * R + (q >> 1)) * (2 * Wo) + 2 * ox0 + (q & 1)) * ldc + (cb - q * Co)) * 4;
+            }
           }
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
               float v = acc[i][j][4 * r4 + k] + bj[j];
               if (EK == 2 && e.act != ACT_NONE) v = ep_act(v, e.act);
               v += add[k];
-              if (EK == 2 && Wo) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vP, sP + 2 * (8 * r4 + k) * Nv * 4, 0);
+              if (EK == 2 && Wo) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vP, sPh[r4 >> 1] + 2 * (8 * (r4 & 1) + k) * Nv * 4, 0);
               else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vC, s0 + ((i * 32 + 8 * r4 + k) * Nv + j * 32) * 4, 0);
               f1 += v;
               f2 = fmaf(v, v, f2);
@@ -818,9 +822,9 @@ bool gemm_bf16x3_epi_ok(int64_t M, int N, int K, const X3Epi& e) {
   // output statistics: whole 32-row blocks per image, segments of 16 channels (a launch whose tiles are cut in k leaves
   // them from its summing launch, one chunk per 8 rows: gemm_bf16x3_seg_rows)
   if (e.seg && (e.hw <= 0 || e.hw % 32 || M % e.hw || (e.seg_coff & 15) || e.seg_nseg <= 0)) return false;
-  // PixelShuffle(2) output: whole 32-pixel runs of an image row and 32-channel runs of a sub-position per accumulator block;
+  // PixelShuffle(2) output: whole 16-pixel runs of an image row and 32-channel runs of a sub-position per accumulator block;
   // the kernel's epilogue only (no tile cut in k), no added maps
-  if (e.pixshuf_wo && (e.pixshuf_wo % 32 || M % e.pixshuf_wo || (N & 127) || e.res || e.gate_src || gemm_bf16x3_needs_sum(1, (int)M, N, K) ||
+  if (e.pixshuf_wo && (e.pixshuf_wo % 16 || M % e.pixshuf_wo || (N & 127) || e.res || e.gate_src || gemm_bf16x3_needs_sum(1, (int)M, N, K) ||
                        4 * M * (int64_t)e.ldy >= ((int64_t)1 << 29) || e.ldy < N / 4))
     return false;
   if (e.act < ACT_NONE || e.act > ACT_SIGMOID) return false;

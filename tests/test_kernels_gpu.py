@@ -358,8 +358,8 @@ def test_linear_bf16x3_rejects_unsupported_shapes(lib, device):
     rc = lib.kd_linear_bf16x3(E.ptr(t), 0, E.ptr(t), None, None, 0, E.ptr(t), 128, E.ptr(t), 64, E.ptr(t), 0, 256, 128, 64, 0, 0, None,
                               E.current_stream())
     assert rc != 0
-    # PixelShuffle output: maps whose width is a multiple of 32, channel runs of 32 per sub-position
-    for M, N, K, wo in [(16384, 64, 64, 64), (16384, 256, 64, 48)]:
+    # PixelShuffle output: maps whose width is a multiple of 16, channel runs of 32 per sub-position
+    for M, N, K, wo in [(16384, 64, 64, 64), (16384, 256, 64, 40)]:
         rc = lib.kd_linear_bf16x3(E.ptr(t), 0, E.ptr(t), None, None, 0, None, 0, None, 256, E.ptr(t), 0, M, N, K, 1, wo, None,
                                   E.current_stream())
         assert rc != 0
@@ -367,7 +367,8 @@ def test_linear_bf16x3_rejects_unsupported_shapes(lib, device):
 
 @pytest.mark.parametrize("B,H,W,K,Co,ldy,act", [
     (16, 64, 64, 256, 128, 256, 1),    # the 64 x 64 level's upsample of the SR UNet into the first half of a concat buffer
-    (4, 32, 32, 1024, 512, 0, 1),      # the 32 x 32 level's shape at batch 4: 256 tiles (maps narrower than 32 pixels stay on conv_buf_kernel)
+    (4, 32, 32, 1024, 512, 0, 1),      # the 32 x 32 level's shape at batch 4: 256 tiles
+    (16, 16, 16, 1024, 512, 0, 1),     # the 16 x 16 level's: an accumulator block's 32 rows are two image rows
     (4, 64, 32, 64, 32, 0, 2),         # a narrow one (Co = 32: one channel run per sub-position), GELU
 ])
 def test_linear_bf16x3_upsample_form_matches_fp64(lib, device, B, H, W, K, Co, ldy, act):
