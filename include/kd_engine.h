@@ -37,7 +37,7 @@ const char* kd_last_error(void);
  * caller built against an older header can refuse the library instead of passing short structs.  History:
  *   1  rounds 1-3
  *   2  round 4/5: kd_conv3x3_winograd4_nhwc gained `gemm_bf16x3` (before `stream`); kd_unet_config_t gained
- *      `gemm_bf16x3` and `x3_linear`, kd_sample_args_t `cond_table_max_mb`; kd_unet_cond_table_refused_bytes, kd_linear_bf16x3 (+ _seg_rows), kd_downsample_bf16x3 and kd_layernorm_ex added;
+ *      `gemm_bf16x3` and `x3_linear`, kd_sample_args_t `cond_table_max_mb`; kd_unet_cond_table_refused_bytes, kd_linear_bf16x3 (+ _seg_rows), kd_downsample_bf16x3, kd_layernorm_ex and kd_layernorm_linear_bf16x3 added;
  *      kd_unet_cond_table_build_ms takes a non-const handle (it reads the build's events on demand) */
 #define KD_ENGINE_ABI_VERSION 2
 int kd_version(void);
@@ -370,6 +370,14 @@ int kd_layernorm(const float* d_x, const float* d_g, const float* d_beta, float*
  * y2 = LN(y) g2 in the same pass (attention's to_out LayerNorm + residual followed by the feed-forward's first). */
 int kd_layernorm_ex(const float* d_x, const float* d_g, const float* d_beta, const float* d_res, float* d_y, int rows, int C,
                     float eps, int in_act, const float* d_g2, float* d_y2, void* stream);
+/* LayerNorm -> Linear as the TransformerBlock's plan runs them where the GEMM is a bf16x3 one: the LayerNorm leaves
+ * y = LN(f(x)) g (+ beta) as the GEMM's three bf16 planes ([3][C / 16][rows][16] bf16 in d_planes, 6 rows C bytes; the
+ * planes of a value add up to it exactly), the GEMM reads them with its DMA loaders: d_y [rows, N] (row stride ldy) =
+ * y @ w[N, C]^T + bias + res.  rows % 256 == 0, N % 128 == 0, C % 32 == 0, C <= 4096.  Same products in the same order as
+ * kd_layernorm_ex followed by kd_linear_bf16x3: bit-identical results. */
+int kd_layernorm_linear_bf16x3(const float* d_x, const float* d_g, const float* d_beta, int rows, int C, float eps, int in_act,
+                               const float* d_w, const float* d_bias, const float* d_res, int ldres, float* d_y, int ldy,
+                               int N, void* d_planes, void* stream);
 /* Attention with fp32 softmax.  q [B,Nq,H,D] (already scaled), k/v [B,Nk,Hkv,D] with
  * Hkv in {1,H}; out [B,Nq,H,D].  D must be 64. */
 int kd_attention(const float* d_q, const float* d_k, const float* d_v, float* d_out,

@@ -224,7 +224,9 @@ int launch_gn_apply_silu(const float* x, int ldx, const float* stats, const floa
 // the raw product); g2 / y2 != nullptr: also y2 = LN(y)*g2 (the TransformerBlock's two LayerNorms around its residual)
 int launch_layernorm(const float* x, int ldx, const float* g, const float* beta, const float* res, int ldres, float* y,
                      int rows, int C, float eps, hipStream_t s, int in_act = ACT_NONE, const float* g2 = nullptr,
-                     float* y2 = nullptr, double* seg = nullptr, int seg_hw = 0);
+                     float* y2 = nullptr, double* seg = nullptr, int seg_hw = 0, int planes = 0);
+// (planes & 1 / & 2: y / y2 are written as the three bf16 planes of the bf16x3 GEMM's A operand, [3][C / 16][rows][16] bf16 -
+// 6 rows C bytes - instead of fp32 rows: the GEMM that reads them needs no split by its loader waves)
 // (seg != nullptr: also the GroupNorm partials of y, [rows / seg_hw][C / 16][seg_hw][2] doubles - one chunk per pixel)
 // dst[row][0..C) = src[row][0..C) * scale, row strides ld_src / ld_dst (dst may be src)
 int launch_copy_scale_rows(const float* src, int ld_src, float* dst, int ld_dst, int C, float scale, int64_t rows,

@@ -125,6 +125,7 @@ struct T {  // NHWC tensor in the workspace, or a channel slice of one (a skip t
   int B = 0, H = 0, W = 0, C = 0;
   int ld = 0;      // row stride in floats; 0 = dense (C)
   int coff = 0;    // first channel inside the block's rows
+  bool x3p = false;  // not fp32 rows: the three bf16 planes [3][C / 16][rows][16] a LayerNorm left for the bf16x3 GEMM that reads it
   int64_t rows() const { return (int64_t)B * H * W; }
   int HW() const { return H * W; }
   int LD() const { return ld ? ld : C; }
@@ -373,6 +374,7 @@ struct Builder {
   };
   std::unordered_map<size_t, SegList> seg_of;   // key: T::at() - a slice and its buffer have different keys
   const bool seg_on = kd_switch("KD_SEG_STATS", 1) != 0;
+  const bool x3_planes_on = kd_switch("KD_X3_PLANES", 1) != 0;   // LayerNorm outputs read by one bf16x3 GEMM: in plane form
   void drop_seg_block(size_t block) {
     for (auto it = seg_of.begin(); it != seg_of.end();) {
       if (it->second.block == block) {
@@ -523,6 +525,7 @@ struct Builder {
     if (cfg.x3_linear == 0 && x.C < 1024 && cut) return false;
     X3Epi e;
     e.lda = x.LD();
+    if (x.x3p && (!x.dense() || x.coff)) return false;
     e.ldy = o.dst ? o.dst->LD() : (o.out_mode == OUT_PIXSHUF ? Cout / 4 : Cout);
     e.res = o.res ? (const float*)16 : nullptr;
     e.ldres = o.res ? o.res->LD() : 0;
@@ -535,6 +538,8 @@ struct Builder {
     return gemm_bf16x3_epi_ok(M, Cout, x.C, e);
   }
   T conv(const T& x, const float* w, const float* bias, int Cout, int K, int stride, int pad, const ConvOpt& o) {
+    if (x.x3p && !x3_linear_ok(x, Cout, K, stride, pad, o))
+      throw std::runtime_error("plan: a tensor in plane form reached a layer that is not a bf16x3 GEMM");
     int Ho = (x.H + 2 * pad - K) / stride + 1, Wo = (x.W + 2 * pad - K) / stride + 1;
     T y;
     if (o.dst) {
@@ -649,9 +654,10 @@ struct Builder {
       };
       const std::string shape = " M" + std::to_string(M) + " Cin" + std::to_string(Cin) + " Cout" + std::to_string(Cout);
       const int64_t m = o.macs_override >= 0 ? o.macs_override : M * Cout * Cin;
+      const bool a_f32 = !x.x3p;   // (planes: written by the LayerNorm in front, the loader waves only move them)
       emit([=](hipStream_t s) {
         const X3Epi e = epi_of();
-        return launch_gemm_bf16x3(uu->P(xo), W3, uu->P(yo) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, true, false, &e);
+        return launch_gemm_bf16x3(uu->P(xo), W3, uu->P(yo) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, a_f32, false, &e);
       }, "conv k1 x3" + shape, m);
       u->macs += m;
       u->op_mfma.back() = 6 * M * Cout * Cin;   // bf16 MACs
@@ -733,10 +739,20 @@ struct Builder {
 
   // in_act: applied to x on the way in (ACT_GELU: the feed-forward's GELU when its GEMM stores the raw product);
   // g2 / y2: a second LayerNorm of the result in the same pass (y2 = LN(y) g2)
+  // planes & 1 / & 2: y / y2 is read by one bf16x3 GEMM and nothing else - left as that kernel's three bf16 planes
   T layernorm(const T& x, const float* g, const float* beta, const T* res = nullptr, int in_act = ACT_NONE,
-              const float* g2 = nullptr, T* y2 = nullptr, bool want_seg = false) {
-    T y = alloc(x.B, x.H, x.W, x.C);
-    if (g2) *y2 = alloc(x.B, x.H, x.W, x.C);
+              const float* g2 = nullptr, T* y2 = nullptr, bool want_seg = false, int planes = 0) {
+    if (!x3_planes_on || x.C % 16 || x.C > 4096 || to_cond || to_text || to_static) planes = 0;
+    auto alloc_out = [&](bool pl) {
+      if (!pl) return alloc(x.B, x.H, x.W, x.C);
+      T t = alloc_bytes((size_t)x.rows() * x.C * 6);
+      t.B = x.B; t.H = x.H; t.W = x.W; t.C = x.C;
+      t.x3p = true;
+      return t;
+    };
+    if ((planes & 1) && want_seg) throw std::runtime_error("plan: GroupNorm partials of a LayerNorm output in plane form");
+    T y = alloc_out(planes & 1);
+    if (g2) *y2 = alloc_out(planes & 2);
     size_t xo = x.at(), yo = y.off, ro = res ? res->at() : 0, y2o = g2 ? y2->off : 0;
     bool hr = res != nullptr;
     int rows = (int)x.rows(), C = x.C, ldx = x.LD(), ldres = res ? res->LD() : 0;
@@ -747,14 +763,16 @@ struct Builder {
     kd_unet* uu = u;
     emit([=](hipStream_t s) {
       return launch_layernorm(uu->P(xo), ldx, g, beta, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), rows, C, 1e-5f, s, in_act, g2,
-                              g2 ? uu->P(y2o) : nullptr, sg ? (double*)uu->P(sgo) : nullptr, hw);
-    }, std::string(g2 ? "ln x2 rows" : "ln rows") + std::to_string(rows) + " C" + std::to_string(C));
+                              g2 ? uu->P(y2o) : nullptr, sg ? (double*)uu->P(sgo) : nullptr, hw, planes);
+    }, std::string(g2 ? "ln x2 rows" : "ln rows") + std::to_string(rows) + " C" + std::to_string(C) + (planes ? " planes" : ""));
     return y;
   }
   // would linear(x, .., N) run on the bf16x3 kernel (x3_linear_ok on the flattened rows)?
+  // (x stands for a dense tensor of its shape: the LayerNorm output the GEMM will read)
   bool linear_is_x3(const T& x, int N, const T* res = nullptr, const T* dst = nullptr) const {
     T xf = x;
     xf.B = 1; xf.H = 1; xf.W = (int)x.rows();
+    xf.ld = 0; xf.coff = 0;
     ConvOpt o;
     T rf, df;
     if (res) {
@@ -857,12 +875,14 @@ struct Builder {
   T transformer(const T& x, const std::string& pre, const T* ctx, const T* dst = nullptr, bool plain = false) {
     int H = cfg.attn_heads, D = cfg.attn_dim_head, inner = H * D, dim = x.C;
     std::string a = plain ? pre + ".fn.fn" : pre + ".layers.0.0", f = pre + ".layers.0.1";
-    T xn = layernorm(x, P(a + ".norm.g", dim), nullptr);
+    const bool qkv1 = cfg.conv_algo == 0 && kd_switch("KD_QKV_FUSED", 1) != 0;
+    // (one reader - the fused q / k / v GEMM: where that runs on the bf16x3 kernel the LayerNorm leaves its planes)
+    T xn = layernorm(x, P(a + ".norm.g", dim), nullptr, nullptr, ACT_NONE, nullptr, nullptr, false,
+                     qkv1 && linear_is_x3(x, inner + 2 * D) ? 1 : 0);
     // to_q and to_kv read the same rows: one GEMM over the stacked weights [inner + 2 D][dim], q and k / v are column
     // slices of its output (the attention kernel takes row strides) - one launch less and fuller tiles
     const float* wq = P(a + ".to_q.weight", (int64_t)inner * dim);
     const float* wkv = P(a + ".to_kv.weight", (int64_t)2 * D * dim);
-    const bool qkv1 = cfg.conv_algo == 0 && kd_switch("KD_QKV_FUSED", 1) != 0;
     T q, kv, qkv;
     if (qkv1) {
       const float* wqkv = cached("qkv:" + a, (size_t)(inner + 2 * D) * dim, [&](float* dst) {
@@ -927,16 +947,17 @@ struct Builder {
     }
     // x1 = LN(proj) g + x and the feed-forward's first LayerNorm h0 = LN(x1) g' in one pass over the rows
     T h0;
-    T x1 = layernorm(proj, P(a + ".to_out.1.g", dim), nullptr, &x, ACT_NONE, P(f + ".0.g", dim), &h0);
+    int hidden = dim * cfg.ff_mult_x2 / 2;
+    const bool gelu_late = linear_is_x3(proj, hidden);   // (h0 has proj's shape)
+    T x1 = layernorm(proj, P(a + ".to_out.1.g", dim), nullptr, &x, ACT_NONE, P(f + ".0.g", dim), &h0, false, gelu_late ? 2 : 0);
     free(proj);
     // feed forward: Linear -> GELU -> LayerNorm -> Linear.  Where the first GEMM runs on the bf16x3 kernel (no activation
     // in its epilogue) it stores the raw product and the LayerNorm applies the GELU on the way in: the same function on the
     // same values
-    int hidden = dim * cfg.ff_mult_x2 / 2;
-    const bool gelu_late = linear_is_x3(h0, hidden);
     T h1 = linear(h0, P(f + ".1.weight", (int64_t)hidden * dim), nullptr, hidden, gelu_late ? ACT_NONE : ACT_GELU);
     free(h0);
-    T h2 = layernorm(h1, P(f + ".3.g", hidden), nullptr, nullptr, gelu_late ? ACT_GELU : ACT_NONE);
+    T h2 = layernorm(h1, P(f + ".3.g", hidden), nullptr, nullptr, gelu_late ? ACT_GELU : ACT_NONE, nullptr, nullptr, false,
+                     linear_is_x3(h1, dim, &x1, dst) ? 1 : 0);
     free(h1);
     T y = linear(h2, P(f + ".4.weight", (int64_t)dim * hidden), nullptr, dim, ACT_NONE, &x1, dst);
     free(h2);

@@ -271,6 +271,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // LayerNorm, with the GEMM storing the raw product; same function on the same values as the GEMM epilogue's: bit-equal),
 // and an optional SECOND LayerNorm of the result (gain g2, output y2): the TransformerBlock's x1 = LN(proj) g + x followed
 // by h0 = LN(x1) g2 in one pass over the row.
+typedef float f32x2n __attribute__((ext_vector_type(2)));
+
 // FULL: C == 256 NV - no lane is past the row, so the loads carry no bounds branch and hipcc issues them together (with the
 // branch every load got a full wait behind it: 85 waits for 17 loads at C = 1024).  Gains / added maps come in groups of four
 // float4 per lane.
@@ -279,13 +281,26 @@ __global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restr
                                                             const float* __restrict__ beta, const float* __restrict__ res,
                                                             int ldres, float* __restrict__ y, int rows, int C, float eps,
                                                             int in_act, const float* __restrict__ g2, float* __restrict__ y2,
-                                                            double* __restrict__ seg, int seg_hw) {
+                                                            double* __restrict__ seg, int seg_hw, int planes) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   const float* xr = x + (int64_t)row * ldx;
   const int C4 = C >> 2;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  // planes & 1: y, & 2: y2 leave as the three bf16 planes of the bf16x3 GEMM's A operand, [3][C / 16][rows][16]
+  // (kernels_gemm_bf16x3.hip): the lane's four values are a quarter of a 32-byte plane row - 8 bytes per plane
+  auto put_planes = [&](float* dst, int c4, const f32x4& o) {
+    uint32_t h0, m0, l0, h1, m1, l1;
+    x3_split(f32x2n{o[0], o[1]}, h0, m0, l0);
+    x3_split(f32x2n{o[2], o[3]}, h1, m1, l1);
+    typedef unsigned int u32x2n __attribute__((ext_vector_type(2)));
+    const int64_t plane = (int64_t)rows * C / 2;   // dwords per plane
+    uint32_t* q = (uint32_t*)dst + (((int64_t)(c4 >> 2) * rows + row) * 8 + (c4 & 3) * 2);
+    *(u32x2n*)q = u32x2n{h0, h1};
+    *(u32x2n*)(q + plane) = u32x2n{m0, m1};
+    *(u32x2n*)(q + 2 * plane) = u32x2n{l0, l1};
+  };
   auto in = [&](int i) { return FULL || lane + 64 * i < C4; };
   // a lane past the row reads the row's first float4 instead (valid memory) and is masked wherever it would count
   auto ld4 = [&](const float* p, int i) { return *(const f32x4*)(p + (in(i) ? lane + 64 * i : 0) * 4); };
@@ -338,7 +353,8 @@ __global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restr
       if (beta) o += bb[k];
       if (res) o += rr[k];
       if (in(i)) {
-        *(f32x4*)(y + (int64_t)row * C + c4 * 4) = o;
+        if (planes & 1) put_planes(y, c4, o);
+        else *(f32x4*)(y + (int64_t)row * C + c4 * 4) = o;
         v[i] = o;
         s2 += (o[0] + o[1]) + (o[2] + o[3]);
       }
@@ -384,13 +400,19 @@ __global__ __launch_bounds__(256) void layernorm_reg_kernel(const float* __restr
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean2) * rstd2 * gg[k][e];
-      if (in(i)) *(f32x4*)(y2 + (int64_t)row * C + (lane + 64 * i) * 4) = o;
+      if (in(i)) {
+        if (planes & 2) put_planes(y2, lane + 64 * i, o);
+        else *(f32x4*)(y2 + (int64_t)row * C + (lane + 64 * i) * 4) = o;
+      }
     }
   }
 }
 
 int launch_layernorm(const float* x, int ldx, const float* g, const float* beta, const float* res, int ldres, float* y,
-                     int rows, int C, float eps, hipStream_t s, int in_act, const float* g2, float* y2, double* seg, int seg_hw) {
+                     int rows, int C, float eps, hipStream_t s, int in_act, const float* g2, float* y2, double* seg, int seg_hw,
+                     int planes) {
+  KD_REQUIRE(!planes || (C % 16 == 0 && C <= 4096 && (planes & ~3) == 0 && (!(planes & 2) || g2)),
+             "LayerNorm: plane-form output needs C % 16 == 0, C <= 4096");
   KD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && (!res || ldres % 4 == 0), "LayerNorm needs C % 4 == 0");
   KD_REQUIRE((g2 == nullptr) == (y2 == nullptr), "LayerNorm: the second normalisation needs its gain and its output");
   KD_REQUIRE(!seg || (C % 16 == 0 && C <= 4096 && seg_hw > 0 && rows % seg_hw == 0),
@@ -400,10 +422,10 @@ int launch_layernorm(const float* x, int ldx, const float* g, const float* beta,
   do {                                                                                                                          \
     if (C == 256 * NV_)                                                                                                         \
       hipLaunchKernelGGL((layernorm_reg_kernel<NV_, true>), grid, block, 0, s, x, ldx, g, beta, res, ldres, y, rows, C, eps, in_act, \
-                         g2, y2, seg, seg_hw);                                                                                  \
+                         g2, y2, seg, seg_hw, planes);                                                                          \
     else                                                                                                                        \
       hipLaunchKernelGGL((layernorm_reg_kernel<NV_, false>), grid, block, 0, s, x, ldx, g, beta, res, ldres, y, rows, C, eps,     \
-                         in_act, g2, y2, seg, seg_hw);                                                                          \
+                         in_act, g2, y2, seg, seg_hw, planes);                                                                  \
   } while (0)
   if (C <= 256) KD_LN(1);
   else if (C <= 512) KD_LN(2);
@@ -411,7 +433,7 @@ int launch_layernorm(const float* x, int ldx, const float* g, const float* beta,
   else if (C <= 2048) KD_LN(8);
   else if (C <= 4096) KD_LN(16);
   else {
-    KD_REQUIRE(in_act == ACT_NONE && !g2, "LayerNorm rows above 4096 channels: plain form only");
+    KD_REQUIRE(in_act == ACT_NONE && !g2 && !planes, "LayerNorm rows above 4096 channels: plain form only");
     hipLaunchKernelGGL(layernorm_kernel, grid, block, 0, s, x, ldx, g, beta, res, ldres, y, rows, C, eps);
   }
 #undef KD_LN

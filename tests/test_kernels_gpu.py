@@ -681,6 +681,41 @@ def test_layernorm_forms_of_the_transformer_block(lib, device, rows, C, act, res
         assert torch.equal(y0, y)
 
 
+@pytest.mark.parametrize("rows,C,N,act,res", [(4096, 512, 1664, 0, False), (4096, 512, 1024, 0, False), (4096, 1024, 512, 2, True),
+                                               (16384, 256, 768, 0, True), (4096, 2048, 1024, 2, False)])
+def test_layernorm_planes_feed_the_bf16x3_linear(lib, device, rows, C, N, act, res):
+    """The plan's LayerNorm -> Linear pairs (engine.hip transformer): the LayerNorm leaves the GEMM's A operand as three bf16
+    planes.  The planes of a value add up to the fp32 LayerNorm output exactly, and the GEMM over them is bit-identical to
+    the GEMM over the fp32 rows (same products, same order; only the loader differs)."""
+    E = _E()
+    x = torch.randn(rows, C, generator=g(21)) * 2 + 0.5
+    gg = torch.randn(C, generator=g(22))
+    w = torch.randn(N, C, generator=g(23)) / C ** 0.5
+    b = torch.randn(N, generator=g(24))
+    r = torch.randn(rows, N, generator=g(25)) if res else None
+    xd, gd, wd, bd = x.to(device), gg.to(device), w.to(device), b.to(device)
+    rd = r.to(device) if res else None
+    ln = torch.empty(rows, C, device=device)
+    E.check(lib.kd_layernorm_ex(E.ptr(xd), E.ptr(gd), None, None, E.ptr(ln), rows, C, 1e-5, act, None, None, E.current_stream()))
+    y_rows = torch.empty(rows, N, device=device)
+    E.check(lib.kd_linear_bf16x3(E.ptr(ln), C, E.ptr(wd), E.ptr(bd), E.ptr(rd), N if res else 0, None, 0, None, rows, E.ptr(y_rows),
+                                 N, rows, N, C, 0, 0, None, E.current_stream()))
+    planes = torch.zeros(3, C // 16, rows, 16, dtype=torch.bfloat16, device=device)
+    y = torch.empty(rows, N, device=device)
+    E.check(lib.kd_layernorm_linear_bf16x3(E.ptr(xd), E.ptr(gd), None, rows, C, 1e-5, act, E.ptr(wd), E.ptr(bd), E.ptr(rd),
+                                           N if res else 0, E.ptr(y), N, N, planes.data_ptr(), E.current_stream()))
+    back = planes.double().sum(0).permute(1, 0, 2).reshape(rows, C)
+    assert torch.equal(back, ln.double())
+    assert torch.equal(y, y_rows)
+    xa = x.double()
+    if act == 2:
+        xa = F.gelu(xa)
+    ref = F.layer_norm(xa, (C,), gg.double(), None, eps=1e-5) @ w.double().t() + b.double()
+    if res:
+        ref = ref + r.double()
+    assert (y.cpu().double() - ref).norm() / ref.norm() < 3e-6
+
+
 @pytest.mark.parametrize("B,Nq,Nk,H,Hkv", [
     (2, 64, 69, 8, 1), (1, 300, 5, 8, 8), (2, 256, 261, 8, 1), (1, 1000, 1029, 4, 1),   # small grids: 4 lanes per query
     (1, 70, 3, 8, 1),                      # fewer keys than key splits (one split sees no key at all)
