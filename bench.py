@@ -40,9 +40,10 @@ DOMINANT = ("wino_fused_gn128_kernel: fused Winograd F(2x2,3x3) 3x3 convs of the
             "in the kernel (sixteen waves, persistent workgroups, items of 16x8 pixels x 128 output channels)")
 WINO4 = ("conv_buf_kernel: the 36 position GEMMs of Winograd F(4x4,3x3) - the ResnetBlock 3x3 convs with Cin >= 512 "
          "(buffer-DMA implicit-GEMM kernel, batched over the positions)")
-WINO4_X3 = ("gemm_bf16x3_kernel: the 36 position GEMMs of Winograd F(4x4,3x3) - the ResnetBlock 3x3 convs with Cin >= 512, and "
-            "Cin >= 256 on the 64 x 64 level - as fp32 products on the bf16 matrix pipe (three bf16 pieces per fp32 operand, six "
-            "exact products per k-step, fp32 accumulation; LDS-DMA ring fed by loader waves)")
+WINO4_X3 = ("gemm_bf16x3_kernel: the 36 position GEMMs of Winograd F(4x4,3x3) - the ResnetBlock 3x3 convs, Cin >= 128 - as fp32 "
+            "products on the bf16 matrix pipe (three bf16 pieces per fp32 operand, six exact products per k-step, fp32 "
+            "accumulation; persistent 256 x 128 tiles, LDS-DMA ring fed by loader waves; V as planes, or as fp32 split by the "
+            "loader waves where the GEMM waits for HBM: the Cout = 128 layers)")
 LIN_X3 = ("gemm_bf16x3_kernel, epilogue form: attention projections, feed-forward, 1x1 skip convs, upsample and 2x2-s2 "
           "downsample convs with K >= 256 as fp32 products on the bf16 matrix pipe (fp32 activations split by the kernel's loader waves; bias / "
           "residual / GlobalContext gate / SiLU + PixelShuffle epilogue, GroupNorm partials of the output)")
@@ -129,6 +130,7 @@ def kernel_classes(lib, handle, iters=3):
         return 0.0   # GroupNorm folds, tiny element-wise launches: latency, not bytes
 
     total_us = 0.0
+    sums_us = {}   # time of sum_slabs_kernel launches booked to a GEMM class
     for _, label, macs, us, mfma in rows:
         us, macs, mfma = float(us), int(macs), int(mfma)
         total_us += us
@@ -147,6 +149,7 @@ def kernel_classes(lib, handle, iters=3):
             add(WINO4_X3, us, 2.0 * macs, 2.0 * mfma)
         elif label.startswith("wino4 x3 sum"):   # the left-over tiles' k-parts added up: time of the same GEMMs (not a launch of the class's count)
             cls[WINO4_X3][1] += us
+            sums_us[WINO4_X3] = sums_us.get(WINO4_X3, 0.0) + us
         elif m and m.group(1) == "wino4 gemm":
             add(WINO4, us, 2.0 * macs, 2.0 * mfma)
         elif m and m.group(1).startswith("wino4"):
@@ -171,6 +174,10 @@ def kernel_classes(lib, handle, iters=3):
     out = []
     for key, (n, us, flop, issued, nbytes) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
         e = {"kernel": key, "launches": n, "ms": us / 1e3, "avg_us": us / n, "share": us / total_us}
+        if key in sums_us:   # the GEMM kernel's own launches, without the launches that add the k-parts
+            ko = us - sums_us[key]
+            e.update(kernel_only_ms=ko / 1e3, kernel_only_avg_us=ko / n, kernel_only_achieved=issued / ko / 1e6,
+                     kernel_only_frac=issued / ko / 1e6 / BF16_PEAK_TFLOPS)
         if flop and key in (WINO4_X3, LIN_X3):
             e.update(bound="mfma", achieved=issued / us / 1e6, unit="TFLOP/s (bf16 MFMA)", peak=BF16_PEAK_TFLOPS,
                      frac=issued / us / 1e6 / BF16_PEAK_TFLOPS, achieved_fp32_equiv=issued / 6.0 / us / 1e6,
@@ -826,7 +833,9 @@ def main():
         step_pipe_frac = step_issued / FP32_PEAK_TFLOPS + step_issued_bf16 / BF16_PEAK_TFLOPS
         step_direct = flop_per_step / (dev_ms_per_step * 1e-3) / 1e12
         kernels = kernel_classes(lib, handle) if world == 1 and not args.no_kernel_classes else None
-        dom = next((k for k in (kernels or []) if k["kernel"] == DOMINANT), None)
+        # the dominant kernel: whichever of the ResnetBlock 3x3-conv kernels takes most of the step in this plan (since the end
+        # of round 5 the bf16x3 position GEMMs of F(4x4,3x3); the fused F(2x2,3x3) kernel where the plan keeps layers on it)
+        dom = max((k for k in (kernels or []) if k["kernel"] in (DOMINANT, WINO4_X3)), key=lambda k: k["ms"], default=None)
         # committed profile artefacts of the same command (profiles/): rocprofv3's average launch duration of the
         # dominant kernel and the PMC traffic.  They are NOT measured in this run and are labelled as such.
         prof = {}
@@ -836,20 +845,38 @@ def main():
         roof = {"bound": "mfma", "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s"}
         if dom:
             n = dom["launches"]
+            x3 = dom["kernel"] == WINO4_X3
+            same = ("gemm_bf16x3" in prof.get("dominant_kernel", "")) == x3   # the profile set is of this plan's dominant kernel
+            if x3:
+                work = (f"achieved = FLOPs the kernel ISSUES on the bf16 MFMA pipe per launch ({dom['issued_tflop_per_step'] / n * 1e3:.1f} "
+                        f"GFLOP average over its {n} launches per step = 2 x 6 bf16 products x 36 Winograd positions x tiles x Cout x "
+                        "Cin: six bf16 MACs per fp32 MAC, 36/144 of the direct 3x3 convolution's fp32 MACs) / average launch "
+                        "duration measured live with HIP events around each launch (kd_unet_profile, on the launch stream; the "
+                        "sum_slabs_kernel launches that add the k-parts of left-over tiles are counted in share_of_step and the "
+                        "class_* fields, not in avg_launch_us / achieved / frac, which are the GEMM kernel's own); peak = the dense bf16 MFMA "
+                        "rate at 2.4 GHz - under this load the chip sustains 1.9-2.1 GHz, a bare six-product loop issues "
+                        "1.24-1.37 PFLOP/s (profiles/README.md) - and the sixteen launches with Cout = 128 wait for HBM, not "
+                        "for the pipe (V + D = 2.4 GB per launch at 256 x 256); achieved_fp32_equiv = the same work as fp32 "
+                        "TFLOP/s (a sixth), achieved_direct_equiv prices the time against the direct-convolution FLOPs of SURVEY "
+                        "§8d - neither is a utilisation")
+                roof.update(peak=BF16_PEAK_TFLOPS, peak_dtype="bf16 (dense MFMA)", achieved_fp32_equiv=dom["achieved_fp32_equiv"])
+            else:
+                work = (f"achieved = FLOPs the kernel ISSUES on the fp32 MFMA pipe per launch ({dom['issued_tflop_per_step'] / n * 1e3:.1f} "
+                        f"GFLOP average over its {n} launches per step = 2 x 16 Winograd positions x tiles x Cout x Cin, i.e. "
+                        "16/36 of the direct 3x3 convolution the reference computes) / average launch duration measured "
+                        "live with HIP events around each launch (kd_unet_profile, on the launch stream); "
+                        "achieved_direct_equiv prices the same time against the direct-convolution FLOPs of SURVEY §8d "
+                        "and can exceed the peak - it is not a utilisation")
             roof.update(
-                kernel=DOMINANT,
-                achieved=dom["achieved"], frac=dom["frac"],
+                kernel=dom["kernel"],
+                achieved=dom.get("kernel_only_achieved", dom["achieved"]), frac=dom.get("kernel_only_frac", dom["frac"]),
                 achieved_direct_equiv=dom["achieved_direct_equiv"],
-                launches_per_step=n, avg_launch_us=dom["avg_us"], share_of_step=dom["share"],
-                work=f"achieved = FLOPs the kernel ISSUES on the fp32 MFMA pipe per launch ({dom['issued_tflop_per_step'] / n * 1e3:.1f} "
-                     f"GFLOP average over its {n} launches per step = 2 x 16 Winograd positions x tiles x Cout x Cin, i.e. "
-                     "16/36 of the direct 3x3 convolution the reference computes) / average launch duration measured "
-                     "live with HIP events around each launch (kd_unet_profile, on the launch stream); "
-                     "achieved_direct_equiv prices the same time against the direct-convolution FLOPs of SURVEY §8d "
-                     "and can exceed the peak - it is not a utilisation",
-                rocprof_avg_launch_us=prof.get("dominant_avg_us"),
-                traffic=prof.get("dominant_bytes_per_launch"),
-                traffic_source=("profile-derived, not measured in this run: " + prof["source"]) if prof.get("source") else None)
+                launches_per_step=n, avg_launch_us=dom.get("kernel_only_avg_us", dom["avg_us"]), share_of_step=dom["share"],
+                class_avg_us_with_sum_launches=dom["avg_us"], class_frac_with_sum_launches=dom["frac"],
+                work=work,
+                rocprof_avg_launch_us=prof.get("dominant_avg_us") if same else None,
+                traffic=prof.get("dominant_bytes_per_launch") if same else None,
+                traffic_source=("profile-derived, not measured in this run: " + prof["source"]) if prof.get("source") and same else None)
         else:  # multi-GPU runs / --no-kernel-classes: no per-launch profile, whole-step pipe utilisation instead
             roof.update(kernel="whole denoising step (per-launch profile skipped)", achieved=step_issued,
                         frac=step_pipe_frac, achieved_direct_equiv=step_direct, traffic=None)

@@ -100,15 +100,18 @@ typedef struct kd_unet_config {
    * slices, bit-identical results); 0 = one slice (default: fastest, largest workspace). */
   int wino_slice_mb;
   /* Winograd F(4x4,3x3) (36 batched GEMMs over tiles of 4x4 outputs) for the ResnetBlock 3x3 convs with at least this
-   * many input channels whose GEMMs fill the chip; 0 = default (512), < 0 = never.  fp32 throughout; per-conv relative
+   * many input channels whose GEMMs fill the chip; 0 = default (512; 128 where the GEMMs run on bf16x3), < 0 = never.  fp32 throughout; per-conv relative
    * L2 against fp64 3-4e-6 (F(2x2,3x3): 5e-7) - inside the 2e-5 the UNet forward is held to. */
   int wino43_min_cin;
   /* The position GEMMs of those F(4x4,3x3) layers on the bf16 matrix pipe, every fp32 operand carried as three bf16
    * pieces (a = ah + am + al exactly) and six exact products accumulated in fp32 per k-step (kernels_gemm_bf16x3.hip):
    * fp32-class results - error against fp64 not above the fp32 MFMA path's - at 3/8 of its matrix cycles.
-   * 0 = default (where tiles % 256 == 0, Cout % 128 == 0; the input transform writes V as the three planes), < 0 = never
-   * (fp32 MFMA); 2 = as 0 with V written as fp32 and split by the GEMM's loader waves on the way into LDS (the form a GEMM
-   * whose activation comes from another kernel would use; here the transform gains less than the GEMMs lose). */
+   * 0 = default (where tiles % 256 == 0, Cout % 128 == 0; with it F(4x4,3x3) is taken from Cin >= 128), < 0 = never
+   * (fp32 MFMA).  The transformed input V reaches the GEMM either as the three planes, written by the input transform
+   * (1 = always), or as fp32 that the GEMM's loader waves split on the way into LDS (2 = always): a third less V traffic
+   * for vector work beside the MFMA waves.  0 picks per layer: fp32 where the GEMM waits for HBM rather than for the matrix
+   * pipe (Cin Cout / (6 Cin + 4 Cout) < 20: the Cout = 128 layers of the large maps), planes elsewhere.  Same results
+   * bit for bit either way. */
   int gemm_bf16x3;
   /* Token GEMMs and 1x1 convs (attention projections, feed-forward, skip convs without output statistics) on the same
    * bf16x3 kernel in its epilogue form (bias / residual / gate, strided rows; the fp32 activations are split by the

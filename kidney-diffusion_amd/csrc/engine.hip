@@ -1053,7 +1053,9 @@ struct Builder {
     // (later in round 5, with the input transform's loads issued together - 185 -> 121 us at 65536 pixels x 512 channels -
     // Cout = 128 wins as well: 256 -> 128 at 128 x 128 698 us fused against 241 + 258 + 80, at 256 x 256 2639 against 1031 + 934
     // + 299; same-box bench 27.81 / 27.89 -> 27.56 / 27.62 ms: the rule is Cin >= 256 wherever the bf16x3 GEMM takes the shape)
-    if (cfg.wino43_min_cin == 0 && cfg.gemm_bf16x3 >= 0 && gemm_bf16x3_ok(36, Mt, cout, x.C)) thr = 256;
+    // (end of round 5: Cin = 128 too, with V of those HBM-bound layers kept in fp32 - wino4_block -: 128 -> 128 at 256 x 256
+    // 1509 us fused against 332 + 608 + 333, at 128 x 128 375 against 88 + 166 + 88)
+    if (cfg.wino43_min_cin == 0 && cfg.gemm_bf16x3 >= 0 && gemm_bf16x3_ok(36, Mt, cout, x.C)) thr = 128;
     return x.C >= thr;
   }
   // skip_c0 >= 0: channels [skip_c0, ..) of x hold an unscaled skip tensor the layer must see times skip_scale: the input
@@ -1071,10 +1073,16 @@ struct Builder {
     emit_gn_stats(x, gamma, beta, ss_col, nullptr);
     // the 36 GEMMs as fp32-class products on the bf16 matrix pipe (kernels_gemm_bf16x3.hip) where the shape fits its tile
     const bool x3 = cfg.gemm_bf16x3 >= 0 && !to_text && !to_static && gemm_bf16x3_ok(36, Mt, Cout, Cin);
-    // V written as planes by the input transform (default), or (2) as fp32, split by the GEMM's loader waves on the way into
-    // LDS: the transform then writes a third less and is that much faster (-0.47 ms over the 40 layers), but the loaders'
-    // vector work beside the MFMA waves costs the GEMMs 15-25 % (+0.93 ms)
-    const bool x3_planes = x3 && cfg.gemm_bf16x3 != 2;
+    // V written as planes by the input transform, or as fp32, split by the GEMM's loader waves on the way into LDS: the
+    // transform then writes a third less and is that much faster, but the loaders' vector work beside the MFMA waves costs a
+    // GEMM that is bound by the matrix pipe 10-15 %.  Per layer (same box, batch 16, transform + GEMM in us, planes / fp32):
+    //   128 -> 128 at 256 x 256 480 + 568 / 332 + 608    256 -> 128 at 256 x 256 1028 + 935 / 669 + 1052
+    //   128 -> 128 at 128 x 128 118 + 168 / 88 + 166     256 -> 128 at 128 x 128 241 + 256 / 162 + 277
+    //   256 -> 256 at 64 x 64 65 + 106 / 50 + 127        512 -> 512 at 32 x 32 28 + 99 / 25 + 112      1024 -> 1024 at 16 x 16 20 + 99 / 16 + 110
+    // fp32 wins where the GEMM itself waits for HBM - few MACs per byte of V and D: Cin Cout / (6 Cin + 4 Cout) < 20 (12.8 and
+    // 16 for the rows that win, 25.6 upwards for those that lose).  cfg.gemm_bf16x3: 0 = by that rule, 1 = planes, 2 = fp32
+    const bool v_f32 = cfg.gemm_bf16x3 == 2 || (cfg.gemm_bf16x3 == 0 && (int64_t)Cin * Cout < 20 * (6 * (int64_t)Cin + 4 * Cout));
+    const bool x3_planes = x3 && !v_f32;
     T V = x3_planes ? alloc_bytes((size_t)36 * Mt * Cin * 6) : alloc(1, 1, (int)(36 * Mt), Cin);
     T D = alloc(1, 1, (int)(36 * Mt), Cout);
     T y = alloc(Bx, H, W, Cout);

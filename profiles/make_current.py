@@ -13,7 +13,10 @@ import sys
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
-DOMINANT = "wino_fused_gn128_kernel"
+# candidates for the dominant kernel (bench.py picks the same way, by measured time): the fused F(2x2,3x3) kernel, and the
+# position-GEMM form of the bf16x3 kernel - one kernel source, two loader variants (V as planes / as fp32)
+CANDIDATES = {"wino_fused_gn128_kernel": ("wino_fused_gn128_kernel",),
+              "gemm_bf16x3_kernel<*, 0>": ("gemm_bf16x3_kernel<false, 0>", "gemm_bf16x3_kernel<true, 0>")}
 
 
 def main():
@@ -30,20 +33,26 @@ def main():
     traffic = json.loads(out)
     shutil.copy(HERE / "hbm_traffic.json", HERE / f"{tag}_hbm_traffic.json")
     rows = list(csv.DictReader(open(src / "kernel_stats.csv")))
-    dom = next(r for r in rows if DOMINANT in r["Name"])
     steps = 7  # collect.sh: --steps 5 --warmup 2
-    launches_per_step = int(dom["Calls"]) / steps
-    dom_bytes = next(v for k, v in traffic["by_kernel_GB_per_step"].items() if DOMINANT in k) * 1e9
+    member = lambda name, pats: any(p_ in name for p_ in pats)
+    tot = {k: sum(float(r["TotalDurationNs"]) for r in rows if member(r["Name"], pats)) for k, pats in CANDIDATES.items()}
+    name = max(tot, key=tot.get)
+    pats = CANDIDATES[name]
+    doms = [r for r in rows if member(r["Name"], pats)]
+    calls = sum(int(r["Calls"]) for r in doms)
+    launches_per_step = calls / steps
+    dom_bytes = sum(v for k, v in traffic["by_kernel_GB_per_step"].items() if member(k, pats)) * 1e9
     sq = json.loads((src / "sq_summary.json").read_text())
-    dom_sq = next(k for k in sq["kernels"] if DOMINANT in k["kernel"])
+    dom_sq = [k for k in sq["kernels"] if member(k["kernel"], pats)]
+    w = sum(k["avg_us"] * k["dispatches"] for k in dom_sq)
     cur = {
         "tag": tag,
-        "dominant_kernel": dom["Name"].split("(")[0],
-        "dominant_avg_us": float(dom["AverageNs"]) / 1e3,
+        "dominant_kernel": "kd::" + name,
+        "dominant_avg_us": tot[name] / calls / 1e3,
         "dominant_launches_per_step": launches_per_step,
-        "dominant_share_of_kernel_time": float(dom["Percentage"]) / 100.0,
+        "dominant_share_of_kernel_time": sum(float(r["Percentage"]) for r in doms) / 100.0,
         "dominant_bytes_per_launch": dom_bytes / launches_per_step,
-        "dominant_mfma_util": dom_sq["mfma_util"],
+        "dominant_mfma_util": sum(k["mfma_util"] * k["avg_us"] * k["dispatches"] for k in dom_sq) / w if w else None,
         "bytes_per_step": traffic["bytes_per_step"],
         "source": f"profiles/{tag}_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 2 "
                   f"--no-cpu-baseline --no-kernel-classes --no-line-grid --no-cond-table`: the step without the one-off table of the time conditioning, which removes 21 small launches / 0.37 ms per step), profiles/{tag}_pmc_fetch.csv.gz + {tag}_pmc_write.csv.gz (separate "
