@@ -683,6 +683,9 @@ def main():
     ap.add_argument("--fp32-mfma-gemms", action="store_true",
                     help="sr: the F(4x4,3x3) position GEMMs on the fp32 MFMA pipe (conv_buf_kernel) instead of the bf16x3 "
                          "kernel - the A/B of profiles/README.md")
+    ap.add_argument("--v-form", type=int, default=0, choices=(0, 1, 2),
+                    help="sr: Unet.gemm_bf16x3 (0 = the plan's rule per layer, 1 = V of every F(4x4,3x3) layer as bf16 planes, "
+                         "2 = as fp32 split by the GEMM's loader waves)")
     ap.add_argument("--wino43-min-cin", type=int, default=0,
                     help="sr: Unet.wino43_min_cin (0 = the plan's default rule; 512 = the rule of the fp32 MFMA GEMMs)")
     ap.add_argument("--x3-linear", type=int, default=0,
@@ -747,6 +750,8 @@ def main():
     unet = build_unet(0)
     if args.fp32_mfma_gemms:
         unet.gemm_bf16x3 = -1
+    elif args.v_form:
+        unet.gemm_bf16x3 = args.v_form
     unet.wino43_min_cin = args.wino43_min_cin
     unet.x3_linear = args.x3_linear
     handle = unet.engine(BATCH, SIZE, device, with_text=False)
