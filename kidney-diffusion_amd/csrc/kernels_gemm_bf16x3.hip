@@ -126,9 +126,10 @@ constexpr int X3_MAX_SPLIT = 8;
 // SGPRs with kind 1 alone, 133 when one kernel served both - and 791 instead of 645 us on the 256 -> 128 conv of the 256^2 map)
 template <bool A_F32, int EK>
 __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __restrict__ A3, const uint16_t* __restrict__ B3,
-                                                          float* __restrict__ C, int G, int M, int N, int K, int S,
+                                                          float* __restrict__ C, int G, int M, int N, int K, int S_st,
                                                           float* __restrict__ slab, X3Epi e) {
   constexpr bool EPI = EK != 0;
+  const int S = S_st & 0xff, stagger = S_st >> 8;
   const int lda = EPI ? e.lda : K, ldc = EPI ? e.ldy : N;
   // kind 1 turns its accumulator blocks through 2 KB of LDS per computing wave behind the ring (16-byte epilogue accesses):
   // 147456 + 16384 = 160 KB, the whole LDS of a CU
@@ -143,6 +144,13 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
   int q = blockIdx.x;
   if ((P & 7) == 0) q = (blockIdx.x & 7) * (P >> 3) + (blockIdx.x >> 3);
   const int tiles = mtiles * ntiles * G, rounds = tiles / P, R = tiles - rounds * P;
+  // every other workgroup starts `stagger` x 4 us late (launches of many rounds whose tiles are short in k): the chip's
+  // workgroups otherwise compute together and store together, the matrix pipes idle while HBM takes the tiles and HBM's
+  // write side idle while they compute
+  // (measured, same box, step of the headline plan: 26.21-26.23 ms without, 26.10 / 26.05-26.07 / 26.04-26.08 / 26.11-26.15
+  // with 2 / 3 / 4 / 6 units; four phases (q & 3) 26.07-26.08)
+  if (stagger && (q & 1))
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
   const bool tail = q < S * R;                        // this workgroup has a part of a left-over tile
   const int part = tail ? q % S : 0;
   const int tail_k0 = part * nk / S, tail_k1 = (part + 1) * nk / S;
@@ -853,6 +861,7 @@ int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, i
   // The plain form (Winograd position GEMMs, G > 1) stores its tiles through kind 1's 16-byte path too - nothing added, rows
   // of N floats: 16 store instructions per lane and tile instead of 64, what the K = 256 launches (16 stages per tile) gain
   // most from.  (`epi` stays null for the summing launch: sum_slabs_kernel<false>.)
+  // (not with fp32 A - the Cout = 128 layers of the large maps: 26.60 -> 26.71-26.73 ms per step with it)
   const bool plain_wide = !epi && !a_f32 && al16(C) && kd_switch("KD_X3_WIDE_STORE", 1) != 0;
   if (plain_wide) {
     e.ldy = N;
@@ -863,7 +872,12 @@ int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, i
   const dim3 grid((unsigned)P), block(768);
   const uint16_t *a = (const uint16_t*)A3, *b = (const uint16_t*)B3;
   const int kind = plain_wide && e.wide ? 1 : !epi ? 0 : (e.act != ACT_NONE || e.pixshuf_wo || !e.wide) ? 2 : 1;
-#define KD_X3(AF, EKIND) hipLaunchKernelGGL((gemm_bf16x3_kernel<AF, EKIND>), grid, block, 0, s, a, b, C, G, M, N, K, S, slab, e)
+  // every other workgroup starts 3 x 4 us late where a launch runs at least eight rounds of tiles that are short in k (see the
+  // kernel): the position GEMMs and 1x1 convs of the 128 x 128 and 256 x 256 levels
+  const int tiles_all = (M / BM) * (N / BN) * G;
+  const int stag = tiles_all / P >= 8 && K <= 256 ? kd_switch("KD_X3_STAGGER", 3) : 0;
+  const int S_st = S | (stag << 8);
+#define KD_X3(AF, EKIND) hipLaunchKernelGGL((gemm_bf16x3_kernel<AF, EKIND>), grid, block, 0, s, a, b, C, G, M, N, K, S_st, slab, e)
   if (kind == 0) {
     if (a_f32) KD_X3(true, 0); else KD_X3(false, 0);
   } else if (kind == 1) {

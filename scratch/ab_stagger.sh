@@ -1,0 +1,17 @@
+#!/bin/bash
+# same-box A/B of the bf16x3 GEMM's experiment switches (experiment build in lib_x/)
+export KD_ENGINE_LIB=$PWD/kidney-diffusion_amd/lib_x/libkd_engine.so
+run() {
+  env "$@" python bench.py --no-cpu-baseline --no-line-grid --no-other-configs --no-kernel-classes --steps 20 --warmup 5 > gpurun_out/b_ab.json 2> gpurun_out/b_ab.err
+  python -c "import json,sys;d=json.load(open('gpurun_out/b_ab.json'));print(' '.join(sys.argv[1:]), round(d['ms_per_step'],3))" "$@"
+}
+for rep in 1 2; do
+  run KD_NONE=0
+  run KD_X3_STAGGER=2
+  run KD_X3_STAGGER=3
+  run KD_X3_STAGGER=4
+  run KD_X3_STAGGER=6
+  run KD_X3_STAGGER=257
+  run KD_X3_STAGGER=258
+  run KD_X3_STAGGER=3 KD_X3_STAGGER_MAXK=512
+done
