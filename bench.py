@@ -47,6 +47,9 @@ WINO4_X3 = ("gemm_bf16x3_kernel: the 36 position GEMMs of Winograd F(4x4,3x3) - 
 LIN_X3 = ("gemm_bf16x3_kernel, epilogue form: attention projections, feed-forward, 1x1 skip convs, upsample and 2x2-s2 "
           "downsample convs with K >= 256 as fp32 products on the bf16 matrix pipe (fp32 activations split by the kernel's loader waves; bias / "
           "residual / GlobalContext gate / SiLU + PixelShuffle epilogue, GroupNorm partials of the output)")
+X3_ALL = ("gemm_bf16x3_kernel, all launches of the step (the two entries above without their sum_slabs_kernel launches): fp32 "
+          "products on the bf16 matrix pipe - three bf16 pieces per fp32 operand, six exact products per k-step, fp32 accumulation; "
+          "persistent 256 x 128 tiles, 8 computing + 4 loader waves, 4-stage LDS-DMA ring")
 CONV_CLASS = "conv_buf_kernel / conv_igemm_kernel / init_conv_kernel: 1x1, 2x2-s2, init and final convs, token GEMMs"
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix = vector peak (v_mfma_f32_32x32x2_f32, exact fp32)
 # dense bf16 matrix peak (MI355X_MICROARCH.md "~2.5 PF dense": v_mfma_f32_32x32x16_bf16 at 32 cycles per SIMD, 1024 CU-SIMDs,
@@ -137,6 +140,7 @@ def kernel_classes(lib, handle, iters=3):
         m = re.match(r"(wino_in|wino_out|wino gemm|wino4_in3|wino4_in|wino4_out|wino4 gemm bf16x3|wino4 gemm) M(\d+) Cin(\d+) Cout(\d+)", label)
         if re.match(r"conv k[12] x3 sum", label):   # the k-parts of the tiles added and the epilogue applied: time of the same GEMMs
             cls[LIN_X3][1] += us
+            sums_us[LIN_X3] = sums_us.get(LIN_X3, 0.0) + us
         elif re.match(r"conv k[12] x3", label):     # `mfma` = bf16 MACs (6 per fp32 MAC)
             add(LIN_X3, us, 2.0 * macs, 2.0 * mfma)
         elif label.startswith("conv k3"):
@@ -189,6 +193,18 @@ def kernel_classes(lib, handle, iters=3):
         elif nbytes:
             e.update(bound="hbm", achieved=nbytes / us / 1e3, unit="GB/s", peak=8000.0, frac=nbytes / us / 1e3 / 8000.0)
         out.append(e)
+    # gemm_bf16x3_kernel as ONE kernel (all its template instances: position GEMMs with V as planes / as fp32, token-GEMM and
+    # 1x1-conv epilogue forms), without the sum_slabs_kernel launches: what rocprofv3's per-kernel table shows
+    x3 = [(k, cls[k]) for k in (WINO4_X3, LIN_X3) if k in cls]
+    if x3:
+        n = sum(c[0] for _, c in x3)
+        us = sum(c[1] - sums_us.get(k, 0.0) for k, c in x3)
+        flop, issued = sum(c[2] for _, c in x3), sum(c[3] for _, c in x3)
+        out.append({"kernel": X3_ALL, "combined": True, "launches": n, "ms": us / 1e3, "avg_us": us / n, "share": us / total_us,
+                    "sum_launches_ms": sum(sums_us.values()) / 1e3,
+                    "bound": "mfma", "achieved": issued / us / 1e6, "unit": "TFLOP/s (bf16 MFMA)", "peak": BF16_PEAK_TFLOPS,
+                    "frac": issued / us / 1e6 / BF16_PEAK_TFLOPS, "achieved_fp32_equiv": issued / 6.0 / us / 1e6,
+                    "achieved_direct_equiv": flop / us / 1e6, "issued_tflop_per_step": issued / 1e12})
     # the class VERDICT r4 item 1 tracks: every 1x1 / 2x2-s2 / init / final conv and token GEMM, whichever kernel runs it
     both = [e for e in out if e["kernel"] in (CONV_CLASS, LIN_X3)]
     if len(both) == 2:
@@ -840,7 +856,7 @@ def main():
         kernels = kernel_classes(lib, handle) if world == 1 and not args.no_kernel_classes else None
         # the dominant kernel: whichever of the ResnetBlock 3x3-conv kernels takes most of the step in this plan (since the end
         # of round 5 the bf16x3 position GEMMs of F(4x4,3x3); the fused F(2x2,3x3) kernel where the plan keeps layers on it)
-        dom = max((k for k in (kernels or []) if k["kernel"] in (DOMINANT, WINO4_X3)), key=lambda k: k["ms"], default=None)
+        dom = max((k for k in (kernels or []) if k["kernel"] in (DOMINANT, X3_ALL)), key=lambda k: k["ms"], default=None)
         # committed profile artefacts of the same command (profiles/): rocprofv3's average launch duration of the
         # dominant kernel and the PMC traffic.  They are NOT measured in this run and are labelled as such.
         prof = {}
@@ -850,20 +866,20 @@ def main():
         roof = {"bound": "mfma", "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s"}
         if dom:
             n = dom["launches"]
-            x3 = dom["kernel"] == WINO4_X3
+            x3 = dom["kernel"] == X3_ALL
             same = ("gemm_bf16x3" in prof.get("dominant_kernel", "")) == x3   # the profile set is of this plan's dominant kernel
             if x3:
                 work = (f"achieved = FLOPs the kernel ISSUES on the bf16 MFMA pipe per launch ({dom['issued_tflop_per_step'] / n * 1e3:.1f} "
-                        f"GFLOP average over its {n} launches per step = 2 x 6 bf16 products x 36 Winograd positions x tiles x Cout x "
-                        "Cin: six bf16 MACs per fp32 MAC, 36/144 of the direct 3x3 convolution's fp32 MACs) / average launch "
-                        "duration measured live with HIP events around each launch (kd_unet_profile, on the launch stream; the "
-                        "sum_slabs_kernel launches that add the k-parts of left-over tiles are counted in share_of_step and the "
-                        "class_* fields, not in avg_launch_us / achieved / frac, which are the GEMM kernel's own); peak = the dense bf16 MFMA "
-                        "rate at 2.4 GHz - under this load the chip sustains 1.9-2.1 GHz, a bare six-product loop issues "
-                        "1.24-1.37 PFLOP/s (profiles/README.md) - and the sixteen launches with Cout = 128 wait for HBM, not "
-                        "for the pipe (V + D = 2.4 GB per launch at 256 x 256); achieved_fp32_equiv = the same work as fp32 "
-                        "TFLOP/s (a sixth), achieved_direct_equiv prices the time against the direct-convolution FLOPs of SURVEY "
-                        "§8d - neither is a utilisation")
+                        f"GFLOP average over its {n} launches per step = 2 x 6 bf16 products x rows x Cout x K: six bf16 MACs per "
+                        "fp32 MAC; rows x K = 36 Winograd positions x tiles x Cin for the 56 position GEMMs of the F(4x4,3x3) layers, "
+                        "36/144 of the direct 3x3 convolution's MACs, and pixels x Cin for the token GEMMs / 1x1 convs) / average "
+                        "launch duration measured live with HIP events around each launch (kd_unet_profile, on the launch stream; "
+                        "the sum_slabs_kernel launches that add the k-parts of left-over tiles are another kernel and not in it: "
+                        "sum_launches_ms); peak = the dense bf16 MFMA rate at 2.4 GHz - under this load the chip sustains "
+                        "1.9-2.3 GHz, a bare six-product loop issues 1.24-1.37 PFLOP/s (profiles/README.md) - and the launches with "
+                        "Cout = 128 on the 128 x 128 and 256 x 256 maps wait for HBM, not for the pipe (V + D = 2.4 GB per launch at "
+                        "256 x 256: traffic); achieved_fp32_equiv = the same work as fp32 TFLOP/s (a sixth), achieved_direct_equiv "
+                        "prices the time against the direct-convolution FLOPs of SURVEY §8d - neither is a utilisation")
                 roof.update(peak=BF16_PEAK_TFLOPS, peak_dtype="bf16 (dense MFMA)", achieved_fp32_equiv=dom["achieved_fp32_equiv"])
             else:
                 work = (f"achieved = FLOPs the kernel ISSUES on the fp32 MFMA pipe per launch ({dom['issued_tflop_per_step'] / n * 1e3:.1f} "
@@ -874,10 +890,10 @@ def main():
                         "and can exceed the peak - it is not a utilisation")
             roof.update(
                 kernel=dom["kernel"],
-                achieved=dom.get("kernel_only_achieved", dom["achieved"]), frac=dom.get("kernel_only_frac", dom["frac"]),
+                achieved=dom["achieved"], frac=dom["frac"],
                 achieved_direct_equiv=dom["achieved_direct_equiv"],
-                launches_per_step=n, avg_launch_us=dom.get("kernel_only_avg_us", dom["avg_us"]), share_of_step=dom["share"],
-                class_avg_us_with_sum_launches=dom["avg_us"], class_frac_with_sum_launches=dom["frac"],
+                launches_per_step=n, avg_launch_us=dom["avg_us"], share_of_step=dom["share"],
+                sum_launches_ms=dom.get("sum_launches_ms"),
                 work=work,
                 rocprof_avg_launch_us=prof.get("dominant_avg_us") if same else None,
                 traffic=prof.get("dominant_bytes_per_launch") if same else None,

@@ -14,9 +14,9 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 # candidates for the dominant kernel (bench.py picks the same way, by measured time): the fused F(2x2,3x3) kernel, and the
-# position-GEMM form of the bf16x3 kernel - one kernel source, two loader variants (V as planes / as fp32)
+# bf16x3 GEMM kernel - one kernel source, template instances by loader (A as planes / as fp32) and epilogue kind
 CANDIDATES = {"wino_fused_gn128_kernel": ("wino_fused_gn128_kernel",),
-              "gemm_bf16x3_kernel<*, 0>": ("gemm_bf16x3_kernel<false, 0>", "gemm_bf16x3_kernel<true, 0>")}
+              "gemm_bf16x3_kernel": ("gemm_bf16x3_kernel<",)}
 
 
 def main():
