@@ -112,7 +112,6 @@ int launch_split3(const float* x, void* planes, int G, int R, int K, hipStream_t
 // waves store the last one.
 template <int V>
 struct X3Set { static constexpr int value = V; };
-constexpr int X3_AD = 3;             // register sets (stages in flight) of the fp32-A loader waves
 struct X3Yes { static constexpr bool value = true; };
 struct X3No { static constexpr bool value = false; };
 constexpr int X3_MAX_WG = 512;       // slabs of the workspace
@@ -162,85 +161,52 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
   auto seg_tile = [&](int sg) __attribute__((always_inline)) { return sg < rounds ? sg * P + q : rounds * P + q / S; };
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
   if (A_F32 && wave >= 8) {
-    // Two kinds of loader waves, so that each kind's vmcnt counts one kind of access only (returns are in order: with the B
-    // DMAs and the A loads in one queue, waiting for a B piece two stages old also waited for every older A load - the A
-    // prefetch could never run more than two stages ahead, 32 KB in flight per CU, and the launches that are short in k ran at
-    // 3.4-4 TB/s where the all-DMA form of the same GEMM moves 5.1-5.3):
-    //   waves 8, 9   the A rows: wave l takes rows 32 l .. 32 l + 31 of every 64-row block (lane -> row = lane >> 2, quarter =
-    //                lane & 3 of its 64 bytes of a stage: 16 bytes, four values, per load; eight loads per stage) into
-    //                registers X3_AD stages ahead, splits them and writes the three planes to LDS one stage ahead
-    //   waves 10, 11 the B planes by LDS-DMA four stages ahead, six pieces each (as the all-DMA form below)
+    // loader l: rows 16 l .. 16 l + 15 of every 64-row block of the A tile (lane -> row = lane >> 2, quarter = lane & 3 of
+    // its 64 bytes of a stage: 16 bytes, four values, per load; four loads per stage), and pieces 3 l .. 3 l + 2 of the 12
+    // of the B planes (LDS-DMA, as in the other form).  Unit u is issued behind barrier u - 4 - its A values into registers
+    // (set u % 4), its B pieces into ring buffer u % 4 - and must be in LDS before barrier u - 1: the A values are split and
+    // written in front of it.  Three units in flight: 48 KB of A per CU.
+    // The vmcnt waits are placed by hand and the A loads are inline assembly, because hipcc's own bookkeeping cannot count
+    // across the `ic < T` branches: it made every use of a loaded value wait for ALL outstanding accesses - the round-4 / 5
+    // form of this loader (builtin loads, "two units ahead") never had more than one stage in flight, whatever its source
+    // said, and the launches that are short in k ran at 3.4-4 TB/s where the all-DMA form of the same GEMM moves 5.1-5.3.
     const int l = wave - 8;
-    int ic = 0, iseg = 0, ik = 0, ik1 = 0;
-    if (l >= 2) {
-      const uint32_t planeB = (uint32_t)((int64_t)G * N * K * 2);
-      const i32x4 rsB = make_rsrc(B3, 3u * planeB);
-      const uint32_t voffB = (uint32_t)((lane >> 1) * ROWB + (((lane & 1) ^ ((lane >> 4) & 1)) * 16));
-      const uint32_t chunkB = (uint32_t)(N * ROWB);
-      uint32_t baseB = 0;
-      auto locate = [&]() __attribute__((always_inline)) {
-        const int it = seg_tile(iseg);
-        const int nt = it % ntiles, g = it / (ntiles * mtiles);
-        baseB = (uint32_t)((int64_t)g * N * K * 2) + (uint32_t)(nt * BN * ROWB);
-        ik = iseg < rounds ? 0 : tail_k0;
-        ik1 = iseg < rounds ? nk : tail_k1;
-      };
-      locate();
-      auto issue_next = [&]() __attribute__((always_inline)) {
-        const int st = ic & (NST - 1);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          const int id = (l - 2) * 6 + j, pl = id >> 2, pr = id & 3;
-          const uint32_t dst = lds0 + (uint32_t)(st * STAGE_B + B_OFF + (pl * BN + pr * 32) * ROWB);
-          dma16(rsB, dst, voffB, (uint32_t)pl * planeB + baseB + (uint32_t)ik * chunkB + (uint32_t)(pr * 32 * ROWB));
-        }
-        ++ic;
-        if (++ik == ik1 && ++iseg < nseg) locate();
-      };
-      for (int j = 0; j < NST && ic < T; ++j) issue_next();
-      if (T > 3) wait_vm<18>(); else if (T > 2) wait_vm<12>(); else if (T > 1) wait_vm<6>(); else wait_vm<0>();
-      __builtin_amdgcn_s_barrier();
-      for (int c = 0; c < T; ++c) {   // the barriers of the computing waves' stages, one for one: unit c + 1 landed
-        if (c + 3 < T) wait_vm<12>(); else if (c + 2 < T) wait_vm<6>(); else wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
-        if (ic < T) issue_next();
-      }
-      return;
-    }
+    const uint32_t planeB = (uint32_t)((int64_t)G * N * K * 2);
+    const i32x4 rsB = make_rsrc(B3, 3u * planeB);
     // (gather form: the resource spans the input map, 4 M pixels)
     const i32x4 rsA = make_rsrc(A3, (uint32_t)((int64_t)G * M * lda * 4 * ((EPI && e.a_tap_c > 0) ? 4 : 1)));
-    const int arow = l * 32 + (lane >> 2), aq = lane & 3;
-    // the lane's eight rows of a tile (arow + 64 j + 16 h, jj = 2 j + h): byte offsets of their first value.  Plain rows:
-    // fixed, the tile's base goes into the scalar offset.  GATHER (X3Epi::a_tap_c = C > 0; kinds 1 / 2): the rows are the
-    // OUTPUT pixels of a 2 x 2 / stride-2 conv (the Downsample's pixel-unshuffle + 1x1 conv) over a
-    // [B][Hi][Wi][lda] map and k = tap C + c walks the four input pixels (tap = 2 dy + dx) of a row: the lane keeps the offset
-    // of pixel (2 oy, 2 ox) per row - set per tile - and the tap's displacement (dy Wi + dx) lda is wave-uniform, so it joins
-    // the scalar offset.
+    const uint32_t voffB = (uint32_t)((lane >> 1) * ROWB + (((lane & 1) ^ ((lane >> 4) & 1)) * 16));
+    const uint32_t chunkB = (uint32_t)(N * ROWB);
+    const int arow = l * 16 + (lane >> 2), aq = lane & 3;
+    // the lane's four rows of a tile (arow + 64 j): byte offsets of their first value.  Plain rows: fixed, the tile's base
+    // goes into the scalar offset.  GATHER (X3Epi::a_tap_c = C > 0; kinds 1 / 2): the rows are the OUTPUT pixels of a 2 x 2 /
+    // stride-2 conv (the Downsample's pixel-unshuffle + 1x1 conv) over a [B][Hi][Wi][lda] map and k = tap C + c
+    // walks the four input pixels (tap = 2 dy + dx) of a row: the lane keeps the offset of pixel (2 oy, 2 ox) per row - set
+    // per tile - and the tap's displacement (dy Wi + dx) lda is wave-uniform, so it joins the scalar offset.
     const bool gather = EPI && e.a_tap_c > 0;
     const int cpt = gather ? e.a_tap_c / BK : nk;   // stage units per tap
-    constexpr int NR = 8;
-    auto row_of = [&](int jj) __attribute__((always_inline)) { return arow + 64 * (jj >> 1) + 16 * (jj & 1); };
+    constexpr int NR = 4, AD = 4, PER = NR + 3;     // accesses of a unit: NR loads, then 3 DMAs
     uint32_t voffAj[NR];
 #pragma unroll
-    for (int jj = 0; jj < NR; ++jj) voffAj[jj] = (uint32_t)((row_of(jj) * lda + aq * 4) * 4);
-    // LDS position of the lane's 8 bytes of a plane row: 16-byte slot (aq >> 1) ^ ((row >> 3) & 1), half aq & 1 (bit 3 of the
-    // row is arow's in all eight)
+    for (int j = 0; j < NR; ++j) voffAj[j] = (uint32_t)(((arow + 64 * j) * lda + aq * 4) * 4);
+    // LDS position of the lane's 8 bytes of a plane row: 16-byte slot (aq >> 1) ^ ((row >> 3) & 1), half aq & 1
     const int ldsA = arow * ROWB + ((((aq >> 1) ^ ((arow >> 3) & 1)) * 16) + (aq & 1) * 8);
-    int kc = 0, tap = 0;
-    uint32_t baseA = 0;
+    int ic = 0, iseg = 0, ik = 0, ik1 = 0, kc = 0, tap = 0;
+    uint32_t baseA = 0, baseB = 0;
     auto locate = [&]() __attribute__((always_inline)) {
       const int it = seg_tile(iseg);
-      const int mt = (it / ntiles) % mtiles, g = it / (ntiles * mtiles);
+      const int nt = it % ntiles, mt = (it / ntiles) % mtiles, g = it / (ntiles * mtiles);
       baseA = (uint32_t)(((int64_t)g * M + mt * BM) * lda * 4);
+      baseB = (uint32_t)((int64_t)g * N * K * 2) + (uint32_t)(nt * BN * ROWB);
       ik = iseg < rounds ? 0 : tail_k0;
       ik1 = iseg < rounds ? nk : tail_k1;
       if (gather) {
         const int Wo = e.a_wi >> 1, how = (e.a_hi >> 1) * Wo;
 #pragma unroll
-        for (int jj = 0; jj < NR; ++jj) {
-          const int m = mt * BM + row_of(jj);
+        for (int j = 0; j < NR; ++j) {
+          const int m = mt * BM + arow + 64 * j;
           const int b = m / how, rem = m - b * how, oy = rem / Wo, ox = rem - oy * Wo;
-          voffAj[jj] = (uint32_t)((((b * e.a_hi + 2 * oy) * e.a_wi + 2 * ox) * lda + aq * 4) * 4);
+          voffAj[j] = (uint32_t)((((b * e.a_hi + 2 * oy) * e.a_wi + 2 * ox) * lda + aq * 4) * 4);
         }
         baseA = 0;
         tap = ik / cpt;
@@ -250,18 +216,21 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     locate();
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    constexpr int AD = X3_AD;
-    u32x4 ra[AD][NR];   // the A values of the AD units in flight
+    u32x4 ra[AD][NR];   // the A values of the units in flight
     auto issue_next = [&](auto SET) __attribute__((always_inline)) {
       constexpr int set = decltype(SET)::value;
+      const int st = ic & (NST - 1);
       // plain: the tile's base + stage ik of the row; gather: the tap's pixel displacement + stage kc of the tap's channels
       const uint32_t soA = gather ? (uint32_t)((((tap >> 1) * e.a_wi + (tap & 1)) * lda + kc * BK) * 4) : baseA + (uint32_t)(ik * (BK * 4));
-      // (inline assembly: hipcc's own vmcnt bookkeeping cannot count across the `ic < T` branches and made every use of a
-      // loaded value wait for ALL outstanding loads - the round-4 / 5 form of this loader never had more than one stage in
-      // flight, whatever its source said; the waits are placed by hand below, `wait_unit`)
 #pragma unroll
-      for (int jj = 0; jj < NR; ++jj)
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[set][jj]) : "v"(voffAj[jj]), "s"(rsA), "s"(soA) : "memory");
+      for (int j = 0; j < NR; ++j)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[set][j]) : "v"(voffAj[j]), "s"(rsA), "s"(soA) : "memory");
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int id = l * 3 + j, pl = id >> 2, pr = id & 3;
+        const uint32_t dst = lds0 + (uint32_t)(st * STAGE_B + B_OFF + (pl * BN + pr * 32) * ROWB);
+        dma16(rsB, dst, voffB, (uint32_t)pl * planeB + baseB + (uint32_t)ik * chunkB + (uint32_t)(pr * 32 * ROWB));
+      }
       ++ic;
       if (++kc == cpt) {
         kc = 0;
@@ -269,66 +238,54 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
       }
       if (++ik == ik1 && ++iseg < nseg) locate();
     };
-    // the loads of unit u have landed: they return in order and NR (AD - 1) later ones may be in flight behind them - fewer
-    // at the end of the workgroup's units.  The registers pass through the statement so that nothing that reads them moves
-    // in front of it
-    auto pin = [](u32x4(&r)[NR], auto N) __attribute__((always_inline)) {
-      asm volatile("s_waitcnt vmcnt(%8)"
-                   : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
-                   : "n"(decltype(N)::value)
-                   : "memory");
+    // Unit u's A values have landed: accesses return in order; behind them its own 3 DMAs and the PER accesses of each of the
+    // two later units may be in flight.  Short of two later units - the workgroup's last - wait for everything (a plain
+    // statement).  ONE pinning statement on every path, the registers passing through it so that nothing that reads them
+    // moves in front of it: with one statement per case hipcc joined the cases through COPIES of the registers, made in
+    // front of the waits - of values still in flight.
+    auto wait_a = [&](int u, u32x4(&r)[NR]) __attribute__((always_inline)) {
+      if (ic < u + 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(3 + 2 * PER) : "memory");
     };
-    auto wait_unit = [&](int u, u32x4(&r)[NR]) __attribute__((always_inline)) {
-      const int behind = ic - 1 - u;   // units issued after u
-      if (behind >= 3) pin(r, X3Set<3 * NR>());
-      else if (behind == 2) pin(r, X3Set<2 * NR>());
-      else if (behind == 1) pin(r, X3Set<NR>());
-      else pin(r, X3Set<0>());
+    auto wait_b = [&](int u) __attribute__((always_inline)) {   // ... and its B pieces
+      if (ic < u + 3) wait_vm<0>(); else wait_vm<2 * PER>();
     };
     auto write_unit = [&](int u, auto SET) __attribute__((always_inline)) {   // split + store the A planes of unit u
       constexpr int set = decltype(SET)::value;
-      wait_unit(u, ra[set]);
+      wait_a(u, ra[set]);
       char* dst = lds + (u & (NST - 1)) * STAGE_B + ldsA;
 #pragma unroll
-      for (int jj = 0; jj < NR; ++jj) {
+      for (int j = 0; j < NR; ++j) {
         uint32_t h0, m0, l0, h1, m1, l1;
-        const f32x2 v01 = {__uint_as_float(ra[set][jj][0]), __uint_as_float(ra[set][jj][1])};
-        const f32x2 v23 = {__uint_as_float(ra[set][jj][2]), __uint_as_float(ra[set][jj][3])};
+        const f32x2 v01 = {__uint_as_float(ra[set][j][0]), __uint_as_float(ra[set][j][1])};
+        const f32x2 v23 = {__uint_as_float(ra[set][j][2]), __uint_as_float(ra[set][j][3])};
         x3_split(v01, h0, m0, l0);
         x3_split(v23, h1, m1, l1);
-        const int ro = (64 * (jj >> 1) + 16 * (jj & 1)) * ROWB;
-        *(u32x2*)(dst + ro) = u32x2{h0, h1};
-        *(u32x2*)(dst + BM * ROWB + ro) = u32x2{m0, m1};
-        *(u32x2*)(dst + 2 * BM * ROWB + ro) = u32x2{l0, l1};
+        *(u32x2*)(dst + j * 64 * ROWB) = u32x2{h0, h1};
+        *(u32x2*)(dst + BM * ROWB + j * 64 * ROWB) = u32x2{m0, m1};
+        *(u32x2*)(dst + 2 * BM * ROWB + j * 64 * ROWB) = u32x2{l0, l1};
       }
+      wait_b(u);
     };
-    // unit u lives in register set u % AD: loaded AD stages before it is written to LDS, which is one stage before the
-    // computing waves read it (the queue holds nothing but these loads, in unit order)
-    auto prologue = [&](auto SET) __attribute__((always_inline)) {
-      if (ic < T) issue_next(SET);
-    };
-    prologue(X3Set<0>());
-    if constexpr (AD > 1) prologue(X3Set<1>());
-    if constexpr (AD > 2) prologue(X3Set<2>());
-    if constexpr (AD > 3) prologue(X3Set<3>());
-    write_unit(0, X3Set<0>());
     if (ic < T) issue_next(X3Set<0>());
+    if (ic < T) issue_next(X3Set<1>());
+    if (ic < T) issue_next(X3Set<2>());
+    if (ic < T) issue_next(X3Set<3>());
+    write_unit(0, X3Set<0>());
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // iteration c: unit c + 1 into LDS, the loads of unit c + 1 + AD into its registers, barrier c
-    auto iter = [&](int c, auto SET) __attribute__((always_inline)) {   // SET: register set of unit c + 1
-      if (c + 1 < T) {
-        write_unit(c + 1, SET);
-        if (ic < T) issue_next(SET);
-      }
+    // iteration c: unit c + 1 into LDS, barrier c, then unit c + 4 (into the registers and the ring buffer of unit c)
+    auto iter = [&](int c, auto SET_W, auto SET_I) __attribute__((always_inline)) {   // sets of units c + 1 and c + 4
+      if (c + 1 < T) write_unit(c + 1, SET_W);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      if (ic < T) issue_next(SET_I);
     };
-    for (int c = 0; c < T; c += AD) {
-      iter(c, X3Set<1 % AD>());
-      if constexpr (AD > 1) if (c + 1 < T) iter(c + 1, X3Set<2 % AD>());
-      if constexpr (AD > 2) if (c + 2 < T) iter(c + 2, X3Set<3 % AD>());
-      if constexpr (AD > 3) if (c + 3 < T) iter(c + 3, X3Set<0>());
+    for (int c = 0; c < T; c += 4) {
+      iter(c, X3Set<1>(), X3Set<0>());
+      if (c + 1 < T) iter(c + 1, X3Set<2>(), X3Set<1>());
+      if (c + 2 < T) iter(c + 2, X3Set<3>(), X3Set<2>());
+      if (c + 3 < T) iter(c + 3, X3Set<0>(), X3Set<3>());
     }
     return;
   }
