@@ -110,7 +110,7 @@ typedef struct kd_unet_config {
    * (fp32 MFMA).  The transformed input V reaches the GEMM either as the three planes, written by the input transform
    * (1 = always), or as fp32 that the GEMM's loader waves split on the way into LDS (2 = always): a third less V traffic
    * for vector work beside the MFMA waves.  0 picks per layer: fp32 where the GEMM waits for HBM rather than for the matrix
-   * pipe (Cin Cout / (6 Cin + 4 Cout) < 20: the Cout = 128 layers of the large maps), planes elsewhere.  Same results
+   * pipe (Cin Cout / (6 Cin + 4 Cout) < 40: the 64 x 64 level and above of the SR UNet), planes elsewhere.  Same results
    * bit for bit either way. */
   int gemm_bf16x3;
   /* Token GEMMs and 1x1 convs (attention projections, feed-forward, skip convs without output statistics) on the same

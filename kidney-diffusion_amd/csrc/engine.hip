@@ -1075,13 +1075,15 @@ struct Builder {
     const bool x3 = cfg.gemm_bf16x3 >= 0 && !to_text && !to_static && gemm_bf16x3_ok(36, Mt, Cout, Cin);
     // V written as planes by the input transform, or as fp32, split by the GEMM's loader waves on the way into LDS: the
     // transform then writes a third less and is that much faster, but the loaders' vector work beside the MFMA waves costs a
-    // GEMM that is bound by the matrix pipe 10-15 %.  Per layer (same box, batch 16, transform + GEMM in us, planes / fp32):
-    //   128 -> 128 at 256 x 256 480 + 568 / 332 + 608    256 -> 128 at 256 x 256 1028 + 935 / 669 + 1052
-    //   128 -> 128 at 128 x 128 118 + 168 / 88 + 166     256 -> 128 at 128 x 128 241 + 256 / 162 + 277
-    //   256 -> 256 at 64 x 64 65 + 106 / 50 + 127        512 -> 512 at 32 x 32 28 + 99 / 25 + 112      1024 -> 1024 at 16 x 16 20 + 99 / 16 + 110
-    // fp32 wins where the GEMM itself waits for HBM - few MACs per byte of V and D: Cin Cout / (6 Cin + 4 Cout) < 20 (12.8 and
-    // 16 for the rows that win, 25.6 upwards for those that lose).  cfg.gemm_bf16x3: 0 = by that rule, 1 = planes, 2 = fp32
-    const bool v_f32 = cfg.gemm_bf16x3 == 2 || (cfg.gemm_bf16x3 == 0 && (int64_t)Cin * Cout < 20 * (6 * (int64_t)Cin + 4 * Cout));
+    // GEMM that is bound by the matrix pipe 10-15 %.  Per layer (same box, batch 16, transform + GEMM in us, planes / fp32;
+    // with the loader waves' loads three stages in flight, kernels_gemm_bf16x3.hip):
+    //   128 -> 128 at 256 x 256 480 + 568 / 336 + 526    256 -> 128 at 256 x 256 1028 + 935 / 671 + 858
+    //   128 -> 128 at 128 x 128 118 + 168 / 90 + 146     256 -> 128 at 128 x 128 241 + 256 / 164 + 238
+    //   256 -> 256 at 64 x 64 65.5 + 112 / 50.5 + 121    512 -> 256 at 64 x 64 123 + 190 / 90 + 215
+    //   512 -> 512 at 32 x 32 28.5 + 103 / 25.5 + 115    1024 -> 1024 at 16 x 16 19.6 + 102 / 16.8 + 113
+    // fp32 wins where the GEMM itself waits for HBM - few MACs per byte of V and D: Cin Cout / (6 Cin + 4 Cout) < 40 (12.8 ...
+    // 32 for the rows that win, 51 upwards for those that lose).  cfg.gemm_bf16x3: 0 = by that rule, 1 = planes, 2 = fp32
+    const bool v_f32 = cfg.gemm_bf16x3 == 2 || (cfg.gemm_bf16x3 == 0 && (int64_t)Cin * Cout < 40 * (6 * (int64_t)Cin + 4 * Cout));
     const bool x3_planes = x3 && !v_f32;
     T V = x3_planes ? alloc_bytes((size_t)36 * Mt * Cin * 6) : alloc(1, 1, (int)(36 * Mt), Cin);
     T D = alloc(1, 1, (int)(36 * Mt), Cout);
