@@ -1,8 +1,11 @@
 #!/bin/bash
-# per-op profiles of the headline UNet: baseline library (lib_x, built from the previous sources) vs the in-tree library
-out=gpurun_out/$1; mkdir -p $out
-for r in 1 2; do
-  KD_ENGINE_LIB=$PWD/kidney-diffusion_amd/lib_x/libkd_engine.so python scratch/dump_ops.py 16 > $out/ops_base$r.csv 2>/dev/null
-  python scratch/dump_ops.py 16 > $out/ops_new$r.csv 2>/dev/null
+# same-box A/B of two builds of the engine: kidney-diffusion_amd/lib_old/libkd_engine.so (an earlier commit, see
+# profiles/README.md) against the product library
+run() {
+  env "$@" python bench.py --no-cpu-baseline --no-line-grid --no-other-configs --no-kernel-classes --steps 20 --warmup 5 > gpurun_out/b_ab.json 2> gpurun_out/b_ab.err
+  python -c "import json,sys;d=json.load(open('gpurun_out/b_ab.json'));print(' '.join(sys.argv[1:]), round(d['ms_per_step'],3))" "$@"
+}
+for rep in 1 2 3; do
+  run KD_ENGINE_LIB=$PWD/kidney-diffusion_amd/lib_old/libkd_engine.so
+  run KD_NEW=1
 done
-python scratch/ops_summary.py $out/ops_base1.csv $out/ops_new1.csv $out/ops_base2.csv $out/ops_new2.csv | grep -E "==|fused Winograd|wino fused"
