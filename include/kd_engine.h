@@ -37,7 +37,7 @@ const char* kd_last_error(void);
  * caller built against an older header can refuse the library instead of passing short structs.  History:
  *   1  rounds 1-3
  *   2  round 4/5: kd_conv3x3_winograd4_nhwc gained `gemm_bf16x3` (before `stream`); kd_unet_config_t gained
- *      `gemm_bf16x3` and `x3_linear`, kd_sample_args_t `cond_table_max_mb`; kd_unet_cond_table_refused_bytes, kd_linear_bf16x3 (+ _seg_rows), kd_downsample_bf16x3, kd_layernorm_ex and kd_layernorm_linear_bf16x3 added;
+ *      `gemm_bf16x3`, `x3_linear` and `wino4_max_images`, kd_sample_args_t `cond_table_max_mb`; kd_unet_cond_table_refused_bytes, kd_linear_bf16x3 (+ _seg_rows), kd_downsample_bf16x3, kd_layernorm_ex and kd_layernorm_linear_bf16x3 added;
  *      kd_unet_cond_table_build_ms takes a non-const handle (it reads the build's events on demand) */
 #define KD_ENGINE_ABI_VERSION 2
 int kd_version(void);
@@ -118,6 +118,11 @@ typedef struct kd_unet_config {
    * kernel's loader waves): 0 = default (K >= 512 input channels, rows % 256 == 0, Cout % 128 == 0, at least 64 tiles of
    * 256 x 128; needs gemm_bf16x3 >= 0 and conv_algo == 0), n > 0 = K >= n, < 0 = never (conv_buf_kernel, fp32 MFMA). */
   int x3_linear;
+  /* F(4x4,3x3) layers run in sets of at most this many images, one set of launches after the other with V and D of one set
+   * (0 = default: the whole batch, or - where V / D / the map of the whole batch pass the 4 GB a buffer resource spans,
+   * unet3's outer levels at batch 8 - the largest divisor of the batch that fits).  A test knob: results equal the
+   * whole-batch plan's to fp32 rounding (the k-cut of left-over tiles follows the tile count). */
+  int wino4_max_images;
 } kd_unet_config_t;
 
 /* One named parameter tensor of the UNet's state_dict (key WITHOUT the `unets.N.` prefix,

@@ -1029,7 +1029,28 @@ struct Builder {
   // the direct conv and 1.78x fewer than F(2x2,3x3), for V / D transform buffers of 2.25x the map.  cfg.conv_algo 0:
   // layers with Cin >= cfg.wino43_min_cin (default 512) whose GEMMs fill the chip - measured against the fused
   // F(2x2,3x3) kernel at batch 16 (profiles/README.md); 4: wherever the shape fits (tests); 1 / 2 / 3 / >= 32: never.
-  bool wino4_ok(const T& x, int cout) const {
+  // images per launch set of a F(4x4,3x3) layer: the whole batch where the rule below takes it, otherwise (default plan with
+  // the bf16x3 GEMMs) the largest divisor of the batch whose V / D / maps stay inside what a buffer resource spans (4 GB) -
+  // unet3's 512 x 512 and 1024 x 1024 levels at batch 8, which otherwise fall back to the fused F(2x2,3x3) kernel; 0 = not a
+  // F(4x4,3x3) layer
+  int wino4_images(const T& x, int cout) const {
+    const int cap = cfg.wino4_max_images > 0 ? cfg.wino4_max_images : x.B;
+    if (cap >= x.B && wino4_whole_ok(x, cout)) return x.B;
+    if (cap >= x.B && (cfg.conv_algo != 0 || cfg.wino43_min_cin != 0 || cfg.gemm_bf16x3 < 0 || to_text || to_static)) return 0;
+    if (cap < x.B && !wino4_whole_ok(x, cout)) return 0;   // (the test knob cuts layers the plan takes, nothing else)
+    for (int ns = 2; ns <= x.B; ++ns) {
+      if (x.B % ns) continue;
+      T xs = x;
+      xs.B = x.B / ns;
+      if (xs.B > cap || (int64_t)xs.B * x.H * x.W * x.LD() * 4 >= ((int64_t)1 << 32)) continue;
+      const int64_t Mt = (int64_t)xs.B * (x.H / 4) * (x.W / 4);
+      if (cap >= x.B && ((x.H & 3) || (x.W & 3) || !gemm_bf16x3_ok(36, Mt, cout, x.C))) continue;
+      if (wino4_whole_ok(xs, cout)) return xs.B;
+    }
+    return 0;
+  }
+  bool wino4_ok(const T& x, int cout) const { return wino4_images(x, cout) > 0; }
+  bool wino4_whole_ok(const T& x, int cout) const {
     if (cfg.conv_algo != 0 && cfg.conv_algo != 4) return false;
     if (cfg.wino43_min_cin < 0 && cfg.conv_algo == 0) return false;
     if ((x.H & 3) || (x.W & 3) || x.C % 32 || cout % 64 || cout < 64) return false;
@@ -1062,7 +1083,9 @@ struct Builder {
   // transform folds the factor into its affine (the statistics come from partials that carry the scale: add_skip)
   T wino4_block(const T& x, const std::string& gn_prefix, int ss_col, const std::string& conv_prefix, int Cout,
                 const T* res, int skip_c0 = -1, float skip_scale = 1.0f) {
-    const int Cin = x.C, G = cfg.resnet_groups, Bx = x.B, H = x.H, W = x.W, HW = x.HW();
+    const int Cin = x.C, G = cfg.resnet_groups, H = x.H, W = x.W, HW = x.HW();
+    // Bx images per set of launches (wino4_images): V and D are one set's, the sets run one after the other
+    const int Bs_ = wino4_images(x, Cout), Bx = Bs_ > 0 ? Bs_ : x.B, nset = x.B / Bx;
     const int64_t Mt = (int64_t)Bx * (H / 4) * (W / 4);
     const float* gamma = P(gn_prefix + ".weight", Cin);
     const float* beta = P(gn_prefix + ".bias", Cin);
@@ -1087,12 +1110,17 @@ struct Builder {
     const bool x3_planes = x3 && !v_f32;
     T V = x3_planes ? alloc_bytes((size_t)36 * Mt * Cin * 6) : alloc(1, 1, (int)(36 * Mt), Cin);
     T D = alloc(1, 1, (int)(36 * Mt), Cout);
-    T y = alloc(Bx, H, W, Cout);
+    T y = alloc(x.B, H, W, Cout);
     const std::string shape = " M" + std::to_string((int64_t)Bx * HW) + " Cin" + std::to_string(Cin) + " Cout" +
                               std::to_string(Cout);
     kd_unet* uu = u;
+    const bool sg = seg_on && Cout % 64 == 0;   // GroupNorm partials of y for whichever layer normalises it next
+    const size_t sgo_all = sg ? add_seg(y, 0, Cout / 16, (H / 4) * (W / 4)) : 0;
+    for (int st = 0; st < nset; ++st) {
+    const int b0 = st * Bx;   // first image of the set
     {
-      size_t xo = x.at(), vo = V.off, so = gn_stats_t.off, sso = t_ss.off;
+      size_t xo = x.at() + (size_t)b0 * HW * x.LD() * sizeof(float), vo = V.off;
+      size_t so = gn_stats_t.off + (size_t)b0 * G * 2 * sizeof(float), sso = t_ss.off + (size_t)b0 * tmlp_total * sizeof(float);
       const int ld = tmlp_total, ldx = x.LD();
       emit([=](hipStream_t s) {
         const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
@@ -1125,16 +1153,17 @@ struct Builder {
       if (!to_text && !to_static) u->op_label.back() = "wino4 gemm" + shape;
     }
     {
-      const bool sg = seg_on && Cout % 64 == 0;   // GroupNorm partials of y for whichever layer normalises it next
-      const size_t sgo = sg ? add_seg(y, 0, Cout / 16, (H / 4) * (W / 4)) : 0;
-      size_t d_o = D.off, yo = y.off, ro = res ? res->at() : 0;
+      const size_t sgo = sgo_all + (size_t)b0 * (Cout / 16) * ((H / 4) * (W / 4)) * 2 * sizeof(double);
+      size_t d_o = D.off, yo = y.off + (size_t)b0 * HW * Cout * sizeof(float);
       const bool hr = res != nullptr;
       const int ldres = res ? res->LD() : 0;
+      size_t ro = res ? res->at() + (size_t)b0 * HW * ldres * sizeof(float) : 0;
       emit([=](hipStream_t s) {
         return launch_wino4_out(uu->P(d_o), bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Cout,
                                 sg ? (double*)uu->P(sgo) : nullptr, Bx, H, W, Cout, s);
       }, "wino4_out" + shape);
     }
+    }   // sets
     free(V);
     free(D);
     return y;

@@ -56,6 +56,7 @@ class kd_unet_config_t(C.Structure):
         ("wino43_min_cin", C.c_int),
         ("gemm_bf16x3", C.c_int),
         ("x3_linear", C.c_int),
+        ("wino4_max_images", C.c_int),
     ]
 
 

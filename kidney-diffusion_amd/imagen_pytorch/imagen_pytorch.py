@@ -552,7 +552,8 @@ class Unet(nn.Module):
         w43 = int(getattr(self, "wino43_min_cin", 0))       # engine extension: F(4x4,3x3) threshold (0 = default, < 0 = never)
         x3 = int(getattr(self, "gemm_bf16x3", 0))           # engine extension: bf16x3 position GEMMs (0 = default on, < 0 = fp32 MFMA)
         x3lin = int(getattr(self, "x3_linear", 0))          # engine extension: token GEMMs / 1x1 convs on bf16x3 (0 = default: K >= 512, < 0 = never)
-        key = (batch, image_size, device.index, bool(with_text), conv_algo, self.attn_qk_norm, slice_mb, w43, x3, x3lin) + \
+        w4img = int(getattr(self, "wino4_max_images", 0))   # engine extension: F(4x4,3x3) layers in sets of at most n images (0 = default)
+        key = (batch, image_size, device.index, bool(with_text), conv_algo, self.attn_qk_norm, slice_mb, w43, x3, x3lin, w4img) + \
             ((replica,) if replica else ())   # (the structural forks drop every plan when they change)
         if self._engines:
             fp = self._weights_fingerprint()
@@ -591,6 +592,7 @@ class Unet(nn.Module):
         cfg.wino43_min_cin = w43
         cfg.gemm_bf16x3 = x3
         cfg.x3_linear = x3lin
+        cfg.wino4_max_images = w4img
         cfg.downsample_conv4 = int(self.downsample_form == "conv4x4")
         cfg.mid_attn_plain = int(self.mid_attn_form == "residual_attention")
 

@@ -351,7 +351,7 @@ def test_library_loads_and_exports_every_symbol_the_header_declares():
         assert hasattr(lib, sym), f"libkd_engine.so does not export {sym}"
     assert set(E.SIGNATURES) == declared, "ctypes table and header disagree"
     assert lib.kd_version() == 2   # KD_ENGINE_ABI_VERSION of include/kd_engine.h
-    assert C.sizeof(E.kd_unet_config_t) == 4 * (2 + 4 * E.KD_MAX_LEVELS + 26)  # ints only, header order
+    assert C.sizeof(E.kd_unet_config_t) == 4 * (2 + 4 * E.KD_MAX_LEVELS + 27)  # ints only, header order
     assert lib.kd_quantile_workspace_bytes(4) == 4 * 16 + 4 * 4 * 256 * 4
 
 

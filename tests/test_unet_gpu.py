@@ -121,7 +121,21 @@ def test_unet_forward_with_winograd_f4_levels_matches_oracle(device):
             n4 = buf.value.decode().count("wino4 gemm")
             assert (n4 >= 8) == (algo == 4), f"{name} conv_algo={algo}: {n4} F(4x4,3x3) layers in the plan"
             print(f"{name} conv_algo={algo}: rel-L2 vs oracle {err:.2e} ({n4} F(4x4,3x3) layers)")
+            if algo == 4:
+                n4_whole = n4
         assert H.rel_l2(outs[4], outs[1]) < FWD_REL_L2
+        # the same layers in sets of 8 images (what the default plan does where V / D of the whole batch pass 4 GB - unet3's
+        # outer levels at batch 8): two sets of launches per layer over one set's V and D, every per-image pointer (map,
+        # statistics, FiLM rows, residual, output partials) moved on by a set - the whole-batch result to fp32 rounding
+        pu = H.product_unet_like(ou).to(device)
+        pu.conv_algo = 4
+        pu.wino4_max_images = 8
+        got = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
+        buf = C.create_string_buffer(1 << 20)
+        E.check(E.load().kd_unet_profile(pu.engine(B, S, device, with_text=False), 1, buf, len(buf), E.current_stream()))
+        n4 = buf.value.decode().count("wino4 gemm")
+        assert n4 == 2 * n4_whole, (n4, n4_whole)
+        assert H.rel_l2(got, outs[4]) < 2e-6 and H.rel_l2(got, ref) < FWD_REL_L2, (H.rel_l2(got, outs[4]), H.rel_l2(got, ref))
 
 
 def test_conditioning_table_gives_bit_identical_samples(device):
