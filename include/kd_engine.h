@@ -118,10 +118,11 @@ typedef struct kd_unet_config {
    * kernel's loader waves): 0 = default (K >= 512 input channels, rows % 256 == 0, Cout % 128 == 0, at least 64 tiles of
    * 256 x 128; needs gemm_bf16x3 >= 0 and conv_algo == 0), n > 0 = K >= n, < 0 = never (conv_buf_kernel, fp32 MFMA). */
   int x3_linear;
-  /* F(4x4,3x3) layers run in sets of at most this many images, one set of launches after the other with V and D of one set
-   * (0 = default: the whole batch, or - where V / D / the map of the whole batch pass the 4 GB a buffer resource spans,
-   * unet3's outer levels at batch 8 - the largest divisor of the batch that fits).  A test knob: results equal the
-   * whole-batch plan's to fp32 rounding (the k-cut of left-over tiles follows the tile count). */
+  /* F(4x4,3x3) layers - and the 1x1 convs on the bf16x3 kernel - run in sets of at most this many images, one set of
+   * launches after the other (V and D of one set) (0 = default: the whole batch, or - where V / D / the maps of the whole
+   * batch pass the 4 GB a buffer resource spans, unet3's outer levels at batch 8 - the largest divisor of the batch that
+   * fits).  A test knob: results equal the whole-batch plan's to fp32 rounding (the k-cut of left-over tiles follows the
+   * tile count). */
   int wino4_max_images;
 } kd_unet_config_t;
 

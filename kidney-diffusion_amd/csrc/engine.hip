@@ -537,6 +537,22 @@ struct Builder {
     e.pixshuf_wo = o.out_mode == OUT_PIXSHUF ? x.W : 0;
     return gemm_bf16x3_epi_ok(M, Cout, x.C, e);
   }
+  // images per launch of a 1x1 conv on the bf16x3 kernel: the whole batch, or - where the maps of the whole batch pass the
+  // 2 GB its 32-bit offsets span (unet3's outer levels at batch 8) - the largest divisor of the batch that fits; 0 = not on it
+  // (cfg.wino4_max_images, the test knob, cuts these launches too)
+  int x3_linear_images(const T& x, int Cout, int K, int stride, int pad, const ConvOpt& o) const {
+    const bool whole = x3_linear_ok(x, Cout, K, stride, pad, o);
+    const int cap = cfg.wino4_max_images > 0 && whole ? cfg.wino4_max_images : x.B;
+    if (whole && cap >= x.B) return x.B;
+    if (x.B < 2 || x.x3p || cfg.x3_linear != 0) return whole ? x.B : 0;
+    for (int ns = 2; ns <= x.B; ++ns) {
+      if (x.B % ns) continue;
+      T xs = x;
+      xs.B = x.B / ns;
+      if (xs.B <= cap && x3_linear_ok(xs, Cout, K, stride, pad, o)) return xs.B;
+    }
+    return whole ? x.B : 0;
+  }
   T conv(const T& x, const float* w, const float* bias, int Cout, int K, int stride, int pad, const ConvOpt& o) {
     if (x.x3p && !x3_linear_ok(x, Cout, K, stride, pad, o))
       throw std::runtime_error("plan: a tensor in plane form reached a layer that is not a bf16x3 GEMM");
@@ -588,7 +604,7 @@ struct Builder {
     // GroupNorm partials of the output, left by the epilogue (channels [yoff, yoff + Cout) of y, or the Cout / 4
     // shuffled channels): several launches filling slices of one tensor (init conv) share the chunk count
     size_t sego = 0;
-    int seg_nseg = 0, seg_c0 = 0;
+    int seg_nseg = 0, seg_c0 = 0, seg_nchunk = 0;
     if (o.want_seg && seg_on && !ext && !to_text && !to_static && !to_cond) {
       const int cw = o.out_mode == OUT_PIXSHUF ? Cout / 4 : Cout;
       seg_c0 = o.seg_c0 >= 0 ? o.seg_c0 : o.yoff;   // in channels of the tensor y (a slice counts from its own first)
@@ -600,9 +616,10 @@ struct Builder {
       probe.seg_c0 = y.coff + seg_c0;
       probe.partial = ks > 1 ? (float*)16 : nullptr;   // split-K: statistics from the reduction kernel, one chunk per pixel
       // (the bf16x3 form of a 1x1 conv whose tiles are cut in k leaves its partials from the summing launch, a chunk per 8 rows)
-      const bool lin3 = x3_linear_ok(x, Cout, K, stride, pad, o);
+      const int lin3_b = x3_linear_images(x, Cout, K, stride, pad, o);
+      const bool lin3 = lin3_b > 0;
       int nchunk = conv_seg_chunks(probe) > 0 && lin3 && o.out_mode == OUT_NHWC
-                       ? Ho * Wo / gemm_bf16x3_seg_rows(x.B * Ho * Wo, Cout, x.C)
+                       ? Ho * Wo / gemm_bf16x3_seg_rows(lin3_b * Ho * Wo, Cout, x.C)
                        : conv_seg_chunks(probe);
       // (the bf16x3 PixelShuffle epilogue takes maps 16 pixels wide - conv_buf_kernel's wants 32 - with the same chunks: four
       // sub-positions per 32 input pixels)
@@ -615,6 +632,7 @@ struct Builder {
           for (auto& sp : it->second.parts)
             if (sp.c0 == seg_c0 && sp.nseg == span / 16 && sp.nchunk == nchunk) have = &sp;
         seg_nseg = span / 16;
+        seg_nchunk = nchunk;
         sego = have ? have->off : add_seg(y, seg_c0, seg_nseg, nchunk);
       }
     }
@@ -622,8 +640,8 @@ struct Builder {
     // epilogue form: bias / residual / gate, strided rows; weights split into planes once per plan, the fp32 activations by
     // the kernel's loader waves; GroupNorm partials of the output where no tile is cut in k).  Layers with an activation
     // stay on conv_buf_kernel; cfg.conv_algo != 0 (the direct-convolution plans of the tests) too
-    if (x3_linear_ok(x, Cout, K, stride, pad, o)) {
-      const int64_t M = (int64_t)x.B * Ho * Wo;
+    if (const int Bset = x3_linear_images(x, Cout, K, stride, pad, o)) {
+      const int64_t M = (int64_t)Bset * Ho * Wo;   // rows of one launch: Bset images (the whole batch but for maps past 2 GB)
       const int Cin = x.C;
       const float* W3 = cached("x3lin:" + std::to_string((uintptr_t)w) + ":" + std::to_string(Cout) + "x" + std::to_string(Cin),
                                ((size_t)Cout * Cin * 3 + 1) / 2,
@@ -640,13 +658,20 @@ struct Builder {
       base.pixshuf_wo = o.out_mode == OUT_PIXSHUF ? Wo : 0;
       const int yoff = p.yoff;
       const int seg_coff = o_yoff - seg_c0;
+      const int64_t seg_per_image = (int64_t)seg_nseg * seg_nchunk * 2;   // doubles: [image][segment][chunk][2]
+      const int64_t y_per_image = (int64_t)(o.out_mode == OUT_PIXSHUF ? 4 : 1) * Ho * Wo * p.ldy;   // floats
+      for (int b0 = 0; b0 < x.B; b0 += Bset) {
+      // (every per-image pointer moved on by the set's first image)
+      const size_t xo_s = xo + (size_t)b0 * x.H * x.W * p.ldx * sizeof(float), yo_s = yo + (size_t)b0 * y_per_image * sizeof(float);
+      const size_t ro_s = ro + (size_t)b0 * Ho * Wo * p.ldres * sizeof(float), gso_s = gso + (size_t)b0 * Ho * Wo * p.ldgs * sizeof(float);
+      const size_t go_s = go + (size_t)b0 * Cout * sizeof(float), sego_s = sego + (size_t)b0 * seg_per_image * sizeof(double);
       auto epi_of = [=]() {
         X3Epi e = base;
-        e.res = has_res ? uu->P(ro) + res_coff : nullptr;
-        e.gate_src = has_gs ? uu->P(gso) : nullptr;
-        e.gate = has_gs ? uu->P(go) : nullptr;
+        e.res = has_res ? uu->P(ro_s) + res_coff : nullptr;
+        e.gate_src = has_gs ? uu->P(gso_s) : nullptr;
+        e.gate = has_gs ? uu->P(go_s) : nullptr;
         if (seg_nseg) {   // the output feeds a GroupNorm: its partials from the epilogue (of the summing launch where tiles are cut in k)
-          e.seg = (double*)uu->P(sego);
+          e.seg = (double*)uu->P(sego_s);
           e.seg_nseg = seg_nseg;
           e.seg_coff = seg_coff;
         }
@@ -657,7 +682,7 @@ struct Builder {
       const bool a_f32 = !x.x3p;   // (planes: written by the LayerNorm in front, the loader waves only move them)
       emit([=](hipStream_t s) {
         const X3Epi e = epi_of();
-        return launch_gemm_bf16x3(uu->P(xo), W3, uu->P(yo) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, a_f32, false, &e);
+        return launch_gemm_bf16x3(uu->P(xo_s), W3, uu->P(yo_s) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, a_f32, false, &e);
       }, "conv k1 x3" + shape, m);
       u->macs += m;
       u->op_mfma.back() = 6 * M * Cout * Cin;   // bf16 MACs
@@ -665,8 +690,9 @@ struct Builder {
       if (gemm_bf16x3_needs_sum(1, (int)M, Cout, Cin))   // every tile cut in k (fewer tiles than CUs): the parts are added, and the epilogue applied, here
         emit([=](hipStream_t s) {
           const X3Epi e = epi_of();
-          return launch_gemm_bf16x3_sum(uu->P(yo) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, &e);
+          return launch_gemm_bf16x3_sum(uu->P(yo_s) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, &e);
         }, "conv k1 x3 sum" + shape);
+      }   // sets of images
       if (ks > 1) free(part);
       return y;
     }

@@ -168,6 +168,22 @@ def test_c3_sr_unet_at_the_benchmark_batch_matches_oracle(device, c3):
         del pu
     # the two forms of V are the same numbers: the loader waves split what the transform would have split
     assert torch.equal(outs[0, 0], outs[0, 1])
+    # the default plan with its F(4x4,3x3) layers and its 1x1 convs on the bf16x3 kernel in sets of 8 images (what the plan does
+    # by itself where the maps of the whole batch pass 4 GB: unet3's outer levels at batch 8): the whole-batch result to fp32
+    # rounding, twice the launches for those layers
+    pu = H.product_unet_like(ou).to(device)
+    pu.wino4_max_images = 8
+    got8 = pu(dv(x), dv(t), lowres_cond_img=dv(lr), lowres_noise_times=dv(tl), cond_images=dv(cond))
+    buf = C.create_string_buffer(1 << 20)
+    E.check(E.load().kd_unet_profile(pu.engine(B, S, device, with_text=False), 1, buf, len(buf), E.current_stream()))
+    labels8 = buf.value.decode()
+    assert labels8.count("wino4 gemm bf16x3") == 2 * 56, labels8.count("wino4 gemm bf16x3")
+    n_conv8 = labels8.count("conv k1 x3 M")
+    assert n_conv8 > nlin[0, 0] - 8, (n_conv8, nlin[0, 0])   # (the convs doubled; the token GEMMs - flat rows - as they were)
+    e8 = H.rel_l2(got8, outs[0, 0])
+    print(f"C3 plan at batch 16 in sets of 8 images: {n_conv8} 1x1-conv / token-GEMM launches on bf16x3, rel-L2 against the whole-batch plan {e8:.2e}")
+    assert e8 < 2e-6 and H.rel_l2(got8, ref) < FWD_REL_L2
+    del pu
     print(f"C3 plan at batch 16: {nlin[0, 0]} token GEMMs / 1x1 convs on bf16x3; rel-L2 {errs[0, 0]:.3e} with them, "
           f"{errs['fp32 token GEMMs']:.3e} with conv_buf_kernel (fp32 MFMA)")
     assert errs[0, 0] < 1.5 * errs["fp32 token GEMMs"] + 1e-7, errs   # fp32-class products: nothing is lost
