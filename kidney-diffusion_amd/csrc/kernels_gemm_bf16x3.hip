@@ -428,6 +428,22 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           float f1 = 0.f, f2 = 0.f;
+          // the block's four rows of the added map(s), all issued here, in front of the block's LDS turns and stores: loaded
+          // where they are used (round 5's first form) every one of the sixteen loads of a tile had `s_waitcnt vmcnt(0)` behind
+          // it - which also waits for the STORES in front of it to be acknowledged: sixteen dependent round trips per tile,
+          // 17 us of epilogue behind 20 us of MFMAs on the 256 -> 128 skip conv of the 256 x 256 map
+          // (one register set: the plan never adds both maps to one launch - x3_linear_ok -; a caller of the C ABI that does
+          // gets the residual loaded where it is used)
+          const bool pre_g = e.gate_src != nullptr, pre_r = !pre_g && e.res != nullptr;
+          u32x4 aq[2][2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int row = rowb0 + i * 32 + 16 * h + 8 * t;   // (the lane's: + rr)
+              if (pre_g) aq[h][t] = __builtin_amdgcn_raw_buffer_load_b128(rsG, vGw, (row * e.ldgs + col) * 4, 0);
+              else if (pre_r) aq[h][t] = __builtin_amdgcn_raw_buffer_load_b128(rsR, vRw, (row * e.ldres + col) * 4, 0);
+            }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -439,11 +455,11 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
             for (int t = 0; t < 2; ++t) {
               const int row = rowb0 + i * 32 + 16 * h + 8 * t;   // (the lane's: + rr)
               f4 v = *(const f4*)(sc + (rr + 8 * t) * 32 + c4) + b4;
-              if (e.gate_src) {
-                const u32x4 gq = __builtin_amdgcn_raw_buffer_load_b128(rsG, vGw, (row * e.ldgs + col) * 4, 0);
-                v += f4{__uint_as_float(gq[0]), __uint_as_float(gq[1]), __uint_as_float(gq[2]), __uint_as_float(gq[3])} * g4;
-              }
-              if (e.res) {
+              const f4 a4 = {__uint_as_float(aq[h][t][0]), __uint_as_float(aq[h][t][1]), __uint_as_float(aq[h][t][2]),
+                             __uint_as_float(aq[h][t][3])};
+              if (pre_g) v += a4 * g4;
+              if (pre_r) v += a4;
+              if (pre_g && e.res) {
                 const u32x4 rq = __builtin_amdgcn_raw_buffer_load_b128(rsR, vRw, (row * e.ldres + col) * 4, 0);
                 v += f4{__uint_as_float(rq[0]), __uint_as_float(rq[1]), __uint_as_float(rq[2]), __uint_as_float(rq[3])};
               }
