@@ -30,7 +30,9 @@ struct WideEpilogue {
 };
 
 __device__ __forceinline__ float ep_act(float v, int act) {
-  if (act == ACT_SILU) return v / (1.0f + __expf(-v));
+  // (the hardware exp2 / reciprocal, ~1 ulp each, as the Winograd input transforms evaluate it: an IEEE division is ten
+  // instructions, and the upsample convs' epilogue applies this to 64 values per lane and tile)
+  if (act == ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
   if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
   if (act == ACT_SIGMOID) return 1.0f / (1.0f + __expf(-v));
   return v;

@@ -6,12 +6,9 @@ run() {
   python -c "import json,sys;d=json.load(open('gpurun_out/b_ab.json'));print(' '.join(sys.argv[1:]), round(d['ms_per_step'],3))" "$@"
 }
 for rep in 1 2; do
-  run KD_NONE=0
+  run KD_X3_STAGGER=0
+  run KD_X3_STAGGER=1
   run KD_X3_STAGGER=2
   run KD_X3_STAGGER=3
   run KD_X3_STAGGER=4
-  run KD_X3_STAGGER=6
-  run KD_X3_STAGGER=257
-  run KD_X3_STAGGER=258
-  run KD_X3_STAGGER=3 KD_X3_STAGGER_MAXK=512
 done
