@@ -42,9 +42,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 256, BN = 128, BK = X3_BK;
 constexpr int ROWB = BK * 2;                          // 32 bytes per LDS row
-constexpr int NST = 4;
-constexpr int STAGE_B = 3 * (BM + BN) * ROWB;         // 36 864 bytes
-constexpr int B_OFF = 3 * BM * ROWB;
+// (ring depth, stage size and the B planes' offset in a stage follow the tile: constants of the kernel, see there)
 
 // m0 is not live across this statement (nothing else in the kernel uses it); the kernel orders its DMAs itself
 __device__ __forceinline__ void dma16(const i32x4& rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
@@ -126,16 +124,25 @@ constexpr int X3_MAX_SPLIT = 8;
 // 1x1 skip convs: rows 16-byte aligned), 2 = the general form: 4-byte accesses, activation, PixelShuffle output (upsample convs) - kinds of their own so that the common one carries neither
 // the extra branches nor the scalar registers of the rare one (the loop's scalar state spills to vector lanes: 73 spilled
 // SGPRs with kind 1 alone, 133 when one kernel served both - and 791 instead of 645 us on the 256 -> 128 conv of the 256^2 map)
-template <bool A_F32, int EK>
-__global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __restrict__ A3, const uint16_t* __restrict__ B3,
-                                                          float* __restrict__ C, int G, int M, int N, int K, int S_st,
-                                                          float* __restrict__ slab, X3Epi e) {
+// BMT: rows of a tile.  256: the kernel described above, one workgroup of 8 computing + 4 loader waves per CU, a ring of four
+// stages.  128 (fp32 A only; launches of whole rounds, no tile cut in k): 4 + 2 waves, a ring of three stages (72 KB) - TWO
+// workgroups per CU, so that one's tile store (and epilogue) runs under the other's MFMAs: what the launches that are short
+// in k lose between their tiles (a 256 x 128 tile at K = 128 is 10 us of MFMAs and 4 us of stores with the matrix pipe idle).
+template <bool A_F32, int EK, int BMT>
+__global__ __launch_bounds__(BMT * 3, 3) void gemm_bf16x3_kernel(const uint16_t* __restrict__ A3, const uint16_t* __restrict__ B3,
+                                                                 float* __restrict__ C, int G, int M, int N, int K, int S_st,
+                                                                 float* __restrict__ slab, X3Epi e) {
+  static_assert(BMT == 256 || (BMT == 128 && A_F32), "the 128-row tile exists for the fp32-A loaders only");
+  // (these shadow the file's constants of the 256-row tile, which the host side and sum_slabs_kernel keep using)
+  constexpr int BM = BMT, NST = BMT == 256 ? 4 : 3, STAGE_B = 3 * (BM + BN) * ROWB, B_OFF = 3 * BM * ROWB;
+  constexpr int NCW = BM / 32, NLW = BM / 64;   // computing / loader waves
+  auto slot = [](int c) __attribute__((always_inline)) { return NST == 4 ? (c & 3) : c % 3; };
   constexpr bool EPI = EK != 0;
   const int S = S_st & 0xff, stagger = S_st >> 8;
   const int lda = EPI ? e.lda : K, ldc = EPI ? e.ldy : N;
   // kind 1 turns its accumulator blocks through 2 KB of LDS per computing wave behind the ring (16-byte epilogue accesses):
   // 147456 + 16384 = 160 KB, the whole LDS of a CU
-  constexpr int EPI_LDS = EK == 1 ? 8 * 2048 : 0;
+  constexpr int EPI_LDS = EK == 1 ? NCW * 2048 : 0;
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE_B + EPI_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
   const int T = rounds * nk + (tail ? tail_k1 - tail_k0 : 0);   // stage units of this workgroup
   auto seg_tile = [&](int sg) __attribute__((always_inline)) { return sg < rounds ? sg * P + q : rounds * P + q / S; };
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-  if (A_F32 && wave >= 8) {
+  if (A_F32 && wave >= NCW) {
     // loader l: rows 16 l .. 16 l + 15 of every 64-row block of the A tile (lane -> row = lane >> 2, quarter = lane & 3 of
     // its 64 bytes of a stage: 16 bytes, four values, per load; four loads per stage), and pieces 3 l .. 3 l + 2 of the 12
     // of the B planes (LDS-DMA, as in the other form).  Unit u is issued behind barrier u - 4 - its A values into registers
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     // across the `ic < T` branches: it made every use of a loaded value wait for ALL outstanding accesses - the round-4 / 5
     // form of this loader (builtin loads, "two units ahead") never had more than one stage in flight, whatever its source
     // said, and the launches that are short in k ran at 3.4-4 TB/s where the all-DMA form of the same GEMM moves 5.1-5.3.
-    const int l = wave - 8;
+    const int l = wave - NCW;
     const uint32_t planeB = (uint32_t)((int64_t)G * N * K * 2);
     const i32x4 rsB = make_rsrc(B3, 3u * planeB);
     // (gather form: the resource spans the input map, 4 M pixels)
@@ -185,10 +192,11 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     // per tile - and the tap's displacement (dy Wi + dx) lda is wave-uniform, so it joins the scalar offset.
     const bool gather = EPI && e.a_tap_c > 0;
     const int cpt = gather ? e.a_tap_c / BK : nk;   // stage units per tap
-    constexpr int NR = 4, AD = 4, PER = NR + 3;     // accesses of a unit: NR loads, then 3 DMAs
+    // (BMT = 128: two loader waves - rows 16 l + 32 j, six B pieces each -, units three stages ahead, three register sets)
+    constexpr int NR = 4, AD = NST, NB = 12 / NLW, PER = NR + NB, RJ = 16 * NLW;   // accesses of a unit: NR loads, then NB DMAs
     uint32_t voffAj[NR];
 #pragma unroll
-    for (int j = 0; j < NR; ++j) voffAj[j] = (uint32_t)(((arow + 64 * j) * lda + aq * 4) * 4);
+    for (int j = 0; j < NR; ++j) voffAj[j] = (uint32_t)(((arow + RJ * j) * lda + aq * 4) * 4);
     // LDS position of the lane's 8 bytes of a plane row: 16-byte slot (aq >> 1) ^ ((row >> 3) & 1), half aq & 1
     const int ldsA = arow * ROWB + ((((aq >> 1) ^ ((arow >> 3) & 1)) * 16) + (aq & 1) * 8);
     int ic = 0, iseg = 0, ik = 0, ik1 = 0, kc = 0, tap = 0;
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
         const int Wo = e.a_wi >> 1, how = (e.a_hi >> 1) * Wo;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-          const int m = mt * BM + arow + 64 * j;
+          const int m = mt * BM + arow + RJ * j;
           const int b = m / how, rem = m - b * how, oy = rem / Wo, ox = rem - oy * Wo;
           voffAj[j] = (uint32_t)((((b * e.a_hi + 2 * oy) * e.a_wi + 2 * ox) * lda + aq * 4) * 4);
         }
@@ -219,15 +227,15 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     u32x4 ra[AD][NR];   // the A values of the units in flight
     auto issue_next = [&](auto SET) __attribute__((always_inline)) {
       constexpr int set = decltype(SET)::value;
-      const int st = ic & (NST - 1);
+      const int st = slot(ic);
       // plain: the tile's base + stage ik of the row; gather: the tap's pixel displacement + stage kc of the tap's channels
       const uint32_t soA = gather ? (uint32_t)((((tap >> 1) * e.a_wi + (tap & 1)) * lda + kc * BK) * 4) : baseA + (uint32_t)(ik * (BK * 4));
 #pragma unroll
       for (int j = 0; j < NR; ++j)
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[set][j]) : "v"(voffAj[j]), "s"(rsA), "s"(soA) : "memory");
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int id = l * 3 + j, pl = id >> 2, pr = id & 3;
+      for (int j = 0; j < NB; ++j) {
+        const int id = l * NB + j, pl = id >> 2, pr = id & 3;
         const uint32_t dst = lds0 + (uint32_t)(st * STAGE_B + B_OFF + (pl * BN + pr * 32) * ROWB);
         dma16(rsB, dst, voffB, (uint32_t)pl * planeB + baseB + (uint32_t)ik * chunkB + (uint32_t)(pr * 32 * ROWB));
       }
@@ -244,16 +252,16 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     // moves in front of it: with one statement per case hipcc joined the cases through COPIES of the registers, made in
     // front of the waits - of values still in flight.
     auto wait_a = [&](int u, u32x4(&r)[NR]) __attribute__((always_inline)) {
-      if (ic < u + 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(3 + 2 * PER) : "memory");
+      if (ic < u + (NST - 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(NB + (NST - 2) * PER) : "memory");
     };
     auto wait_b = [&](int u) __attribute__((always_inline)) {   // ... and its B pieces
-      if (ic < u + 3) wait_vm<0>(); else wait_vm<2 * PER>();
+      if (ic < u + (NST - 1)) wait_vm<0>(); else wait_vm<(NST - 2) * PER>();
     };
     auto write_unit = [&](int u, auto SET) __attribute__((always_inline)) {   // split + store the A planes of unit u
       constexpr int set = decltype(SET)::value;
       wait_a(u, ra[set]);
-      char* dst = lds + (u & (NST - 1)) * STAGE_B + ldsA;
+      char* dst = lds + slot(u) * STAGE_B + ldsA;
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         uint32_t h0, m0, l0, h1, m1, l1;
@@ -261,39 +269,41 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
         const f32x2 v23 = {__uint_as_float(ra[set][j][2]), __uint_as_float(ra[set][j][3])};
         x3_split(v01, h0, m0, l0);
         x3_split(v23, h1, m1, l1);
-        *(u32x2*)(dst + j * 64 * ROWB) = u32x2{h0, h1};
-        *(u32x2*)(dst + BM * ROWB + j * 64 * ROWB) = u32x2{m0, m1};
-        *(u32x2*)(dst + 2 * BM * ROWB + j * 64 * ROWB) = u32x2{l0, l1};
+        *(u32x2*)(dst + j * RJ * ROWB) = u32x2{h0, h1};
+        *(u32x2*)(dst + BM * ROWB + j * RJ * ROWB) = u32x2{m0, m1};
+        *(u32x2*)(dst + 2 * BM * ROWB + j * RJ * ROWB) = u32x2{l0, l1};
       }
       wait_b(u);
     };
     if (ic < T) issue_next(X3Set<0>());
     if (ic < T) issue_next(X3Set<1>());
     if (ic < T) issue_next(X3Set<2>());
-    if (ic < T) issue_next(X3Set<3>());
+    if constexpr (AD > 3)
+      if (ic < T) issue_next(X3Set<3 % AD>());
     write_unit(0, X3Set<0>());
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // iteration c: unit c + 1 into LDS, barrier c, then unit c + 4 (into the registers and the ring buffer of unit c)
-    auto iter = [&](int c, auto SET_W, auto SET_I) __attribute__((always_inline)) {   // sets of units c + 1 and c + 4
+    // iteration c: unit c + 1 into LDS, barrier c, then unit c + NST (into the registers and the ring buffer of unit c)
+    auto iter = [&](int c, auto SET_W, auto SET_I) __attribute__((always_inline)) {   // sets of units c + 1 and c + NST
       if (c + 1 < T) write_unit(c + 1, SET_W);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (ic < T) issue_next(SET_I);
     };
-    for (int c = 0; c < T; c += 4) {
+    for (int c = 0; c < T; c += AD) {
       iter(c, X3Set<1>(), X3Set<0>());
-      if (c + 1 < T) iter(c + 1, X3Set<2>(), X3Set<1>());
-      if (c + 2 < T) iter(c + 2, X3Set<3>(), X3Set<2>());
-      if (c + 3 < T) iter(c + 3, X3Set<0>(), X3Set<3>());
+      if (c + 1 < T) iter(c + 1, X3Set<2 % AD>(), X3Set<1>());
+      if (c + 2 < T) iter(c + 2, X3Set<3 % AD>(), X3Set<2>());
+      if constexpr (AD > 3)
+        if (c + 3 < T) iter(c + 3, X3Set<0>(), X3Set<3 % AD>());
     }
     return;
   }
-  if (wave >= 8) {
+  if (wave >= NCW) {   // (BMT = 256 only: the 128-row tile has fp32 A)
     // loader l moves pieces 9 l .. 9 l + 8 of the 36 of every stage (0..23: A plane id / 8, rows 32 (id % 8); 24..35: B
     // plane (id - 24) / 4, rows 32 ((id - 24) % 4)).  A piece = 32 rows x 32 bytes = 1 KB of consecutive memory: lane ->
     // LDS (row = lane >> 1, slot = lane & 1), read from source slot (lane & 1) ^ ((row >> 3) & 1) of the same row
-    const int l = wave - 8;
+    const int l = wave - NCW;
     const uint32_t planeA = (uint32_t)((int64_t)G * M * K * 2), planeB = (uint32_t)((int64_t)G * N * K * 2);
     const i32x4 rsA = make_rsrc(A3, 3u * planeA), rsB = make_rsrc(B3, 3u * planeB);
     const uint32_t voff = (uint32_t)((lane >> 1) * ROWB + (((lane & 1) ^ ((lane >> 4) & 1)) * 16));
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     };
     locate();
     auto issue_next = [&]() __attribute__((always_inline)) {
-      const int st = ic & (NST - 1);
+      const int st = slot(ic);
 #pragma unroll
       for (int j = 0; j < 9; ++j) {
         const int id = l * 9 + j;
@@ -351,12 +361,12 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     bf16x8 a[3][2], b[3][2];
   };
   auto read_a = [&](Frags& f, int c, int p) __attribute__((always_inline)) {
-    const int so = (c & (NST - 1)) * STAGE_B;
+    const int so = slot(c) * STAGE_B;
 #pragma unroll
     for (int i = 0; i < 2; ++i) f.a[p][i] = *(const bf16x8*)(fa + so + p * BM * ROWB + i * 32 * ROWB);
   };
   auto read_b = [&](Frags& f, int c, int p) __attribute__((always_inline)) {
-    const int so = (c & (NST - 1)) * STAGE_B;
+    const int so = slot(c) * STAGE_B;
 #pragma unroll
     for (int i = 0; i < 2; ++i) f.b[p][i] = *(const bf16x8*)(fb + so + p * BN * ROWB + i * 32 * ROWB);
   };
@@ -654,7 +664,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
     __builtin_amdgcn_sched_barrier(0);
     read_a(f, c + 1, 2);
     {
-      const int so = ((c + 1) & (NST - 1)) * STAGE_B;
+      const int so = slot(c + 1) * STAGE_B;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         ahn[i] = *(const bf16x8*)(fa + so + i * 32 * ROWB);
@@ -903,21 +913,31 @@ int launch_gemm_bf16x3(const void* A3, const void* B3, float* C, int G, int M, i
   }
   e.wide = (epi || plain_wide) && al16(C) && e.ldy % 4 == 0 && al16(e.bias) && (!e.res || (al16(e.res) && e.ldres % 4 == 0)) &&
            (!e.gate_src || (al16(e.gate_src) && al16(e.gate) && e.ldgs % 4 == 0));
-  const dim3 grid((unsigned)P), block(768);
   const uint16_t *a = (const uint16_t*)A3, *b = (const uint16_t*)B3;
   const int kind = plain_wide && e.wide ? 1 : !epi ? 0 : (e.act != ACT_NONE || e.pixshuf_wo || !e.wide) ? 2 : 1;
+  // The 128-row tile, two workgroups per CU (fp32 A; see the kernel): launches of whole rounds either way - no left-over
+  // tiles, nothing cut in k, so the summing launch and the chunks of the output statistics are what the callers expect -
+  // that are short in k, where the store of a tile is a large part of it
+  const int cus = x3_cus();
+  const int64_t tiles128 = (int64_t)(M / 128) * (N / BN) * G;
+  const bool bm128 = a_f32 && R == 0 && S == 1 && K <= kd_switch("KD_X3_BM128_MAXK", 512) && tiles128 % (2 * cus) == 0 &&
+                     tiles128 / (2 * cus) >= 4 && 2 * cus <= X3_MAX_WG && kd_switch("KD_X3_BM128", 1) != 0;
   // every other workgroup starts 3 x 4 us late where a launch runs at least eight rounds of tiles that are short in k (see the
   // kernel): the position GEMMs and 1x1 convs of the 128 x 128 and 256 x 256 levels
   const int tiles_all = (M / BM) * (N / BN) * G;
-  const int stag = tiles_all / P >= 8 && K <= 256 ? kd_switch("KD_X3_STAGGER", 3) : 0;
+  const int stag = !bm128 && tiles_all / P >= 8 && K <= 256 ? kd_switch("KD_X3_STAGGER", 3) : 0;
   const int S_st = S | (stag << 8);
-#define KD_X3(AF, EKIND) hipLaunchKernelGGL((gemm_bf16x3_kernel<AF, EKIND>), grid, block, 0, s, a, b, C, G, M, N, K, S_st, slab, e)
-  if (kind == 0) {
-    if (a_f32) KD_X3(true, 0); else KD_X3(false, 0);
+  const dim3 grid((unsigned)(bm128 ? 2 * cus : P)), block(bm128 ? 384 : 768);
+#define KD_X3(AF, EKIND, BMT_) \
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<AF, EKIND, BMT_>), grid, block, 0, s, a, b, C, G, M, N, K, S_st, slab, e)
+  if (bm128) {
+    if (kind == 0) KD_X3(true, 0, 128); else if (kind == 1) KD_X3(true, 1, 128); else KD_X3(true, 2, 128);
+  } else if (kind == 0) {
+    if (a_f32) KD_X3(true, 0, 256); else KD_X3(false, 0, 256);
   } else if (kind == 1) {
-    if (a_f32) KD_X3(true, 1); else KD_X3(false, 1);
+    if (a_f32) KD_X3(true, 1, 256); else KD_X3(false, 1, 256);
   } else {
-    if (a_f32) KD_X3(true, 2); else KD_X3(false, 2);
+    if (a_f32) KD_X3(true, 2, 256); else KD_X3(false, 2, 256);
   }
 #undef KD_X3
   KD_HIP_CHECK(hipGetLastError());
