@@ -134,6 +134,8 @@ def kernel_classes(lib, handle, iters=3):
 
     total_us = 0.0
     sums_us = {}   # time of sum_slabs_kernel launches booked to a GEMM class
+    x3_parts = {"position GEMMs, V as fp32 (HBM side)": [], "position GEMMs, V as planes (matrix side)": [],
+                "token GEMMs / 1x1 convs": []}   # (us, bf16 FLOP issued, algorithmic bytes) per gemm_bf16x3_kernel launch
     for _, label, macs, us, mfma in rows:
         us, macs, mfma = float(us), int(macs), int(mfma)
         total_us += us
@@ -143,6 +145,11 @@ def kernel_classes(lib, handle, iters=3):
             sums_us[LIN_X3] = sums_us.get(LIN_X3, 0.0) + us
         elif re.match(r"conv k[12] x3", label):     # `mfma` = bf16 MACs (6 per fp32 MAC)
             add(LIN_X3, us, 2.0 * macs, 2.0 * mfma)
+            g3 = re.match(r"conv k[12] x3 M(\d+) Cin(\d+) Cout(\d+)", label)
+            if g3:   # rows x (K in, fp32 - planes where a LayerNorm wrote them: priced as fp32 here - + N out) + the weights' planes
+                rows, kin, nout = (int(v) for v in g3.groups())
+                kin *= 4 if label.startswith("conv k2") else 1
+                x3_parts["token GEMMs / 1x1 convs"].append((us, 2.0 * mfma, 4.0 * rows * (kin + nout) + 6.0 * kin * nout))
         elif label.startswith("conv k3"):
             add("conv_buf_kernel: direct 3x3 convs", us, 2.0 * macs, 2.0 * mfma)
         elif label.startswith("wino fused"):
@@ -151,6 +158,12 @@ def kernel_classes(lib, handle, iters=3):
             add("conv_buf_kernel: Winograd F(2x2,3x3) position GEMMs", us, 2.0 * macs, 2.0 * mfma)
         elif m and m.group(1) == "wino4 gemm bf16x3":   # `mfma` = the bf16 MACs (6 per fp32 MAC of the 36 GEMMs)
             add(WINO4_X3, us, 2.0 * macs, 2.0 * mfma)
+            # V and D of the 36 positions: 2.25 values per pixel and channel; V 4 B as fp32 (the plan's rule: where
+            # Cin Cout / (6 Cin + 4 Cout) < 40), 6 B as planes; D 4 B; the weights' planes once
+            px, cin, cout = int(m.group(2)), int(m.group(3)), int(m.group(4))
+            f32v = cin * cout < 40 * (6 * cin + 4 * cout)
+            x3_parts["position GEMMs, V as fp32 (HBM side)" if f32v else "position GEMMs, V as planes (matrix side)"].append(
+                (us, 2.0 * mfma, 2.25 * px * (cin * (4.0 if f32v else 6.0) + cout * 4.0) + 36 * 6.0 * cin * cout))
         elif label.startswith("wino4 x3 sum"):   # the left-over tiles' k-parts added up: time of the same GEMMs (not a launch of the class's count)
             cls[WINO4_X3][1] += us
             sums_us[WINO4_X3] = sums_us.get(WINO4_X3, 0.0) + us
@@ -200,8 +213,14 @@ def kernel_classes(lib, handle, iters=3):
         n = sum(c[0] for _, c in x3)
         us = sum(c[1] - sums_us.get(k, 0.0) for k, c in x3)
         flop, issued = sum(c[2] for _, c in x3), sum(c[3] for _, c in x3)
+        parts = [{"launches_of": k, "launches": len(v), "ms": sum(t[0] for t in v) / 1e3,
+                  "mfma_frac": sum(t[1] for t in v) / sum(t[0] for t in v) / 1e6 / BF16_PEAK_TFLOPS,
+                  "hbm_frac": sum(t[2] for t in v) / sum(t[0] for t in v) / 1e3 / 8000.0,
+                  "algorithmic_gb": sum(t[2] for t in v) / 1e9} for k, v in x3_parts.items() if v]
         out.append({"kernel": X3_ALL, "combined": True, "launches": n, "ms": us / 1e3, "avg_us": us / n, "share": us / total_us,
                     "sum_launches_ms": sum(sums_us.values()) / 1e3,
+                    "algorithmic_bytes_per_launch": sum(t[2] for v in x3_parts.values() for t in v) / n,
+                    "by_side": parts,
                     "bound": "mfma", "achieved": issued / us / 1e6, "unit": "TFLOP/s (bf16 MFMA)", "peak": BF16_PEAK_TFLOPS,
                     "frac": issued / us / 1e6 / BF16_PEAK_TFLOPS, "achieved_fp32_equiv": issued / 6.0 / us / 1e6,
                     "achieved_direct_equiv": flop / us / 1e6, "issued_tflop_per_step": issued / 1e12})
@@ -878,7 +897,8 @@ def main():
                         "sum_launches_ms); peak = the dense bf16 MFMA rate at 2.4 GHz - under this load the chip sustains "
                         "1.9-2.3 GHz, a bare six-product loop issues 1.24-1.37 PFLOP/s (profiles/README.md) - and the launches with "
                         "Cout = 128 on the 128 x 128 and 256 x 256 maps wait for HBM, not for the pipe (V + D = 2.4 GB per launch at "
-                        "256 x 256: traffic); achieved_fp32_equiv = the same work as fp32 TFLOP/s (a sixth), achieved_direct_equiv "
+                        "256 x 256: traffic, against algorithmic_bytes_per_launch = V + D + weights / A + Y + weights; by_side prices each group of "
+                        "launches against both roofs: mfma_frac of 2516.6 TFLOP/s and hbm_frac of 8 TB/s over the same time); achieved_fp32_equiv = the same work as fp32 TFLOP/s (a sixth), achieved_direct_equiv "
                         "prices the time against the direct-convolution FLOPs of SURVEY §8d - neither is a utilisation")
                 roof.update(peak=BF16_PEAK_TFLOPS, peak_dtype="bf16 (dense MFMA)", achieved_fp32_equiv=dom["achieved_fp32_equiv"])
             else:
@@ -894,6 +914,7 @@ def main():
                 achieved_direct_equiv=dom["achieved_direct_equiv"],
                 launches_per_step=n, avg_launch_us=dom["avg_us"], share_of_step=dom["share"],
                 sum_launches_ms=dom.get("sum_launches_ms"),
+                algorithmic_bytes_per_launch=dom.get("algorithmic_bytes_per_launch"), by_side=dom.get("by_side"),
                 work=work,
                 rocprof_avg_launch_us=prof.get("dominant_avg_us") if same else None,
                 traffic=prof.get("dominant_bytes_per_launch") if same else None,
