@@ -920,8 +920,15 @@ def main():
                 traffic=prof.get("dominant_bytes_per_launch") if same else None,
                 traffic_source=("profile-derived, not measured in this run: " + prof["source"]) if prof.get("source") and same else None)
         else:  # multi-GPU runs / --no-kernel-classes: no per-launch profile, whole-step pipe utilisation instead
-            roof.update(kernel="whole denoising step (per-launch profile skipped)", achieved=step_issued,
-                        frac=step_pipe_frac, achieved_direct_equiv=step_direct, traffic=None)
+            # (nearly all matrix work of the plan is bf16 MFMA now: the step's bf16 rate against the bf16 peak, per GPU; the
+            # fp32-pipe share and the combined busy fraction are in roofline.step)
+            if step_issued_bf16 / BF16_PEAK_TFLOPS >= step_issued / FP32_PEAK_TFLOPS:
+                roof.update(kernel="whole denoising step, per GPU (per-launch profile skipped)", peak=BF16_PEAK_TFLOPS,
+                            peak_dtype="bf16 (dense MFMA)", achieved=step_issued_bf16, frac=step_issued_bf16 / BF16_PEAK_TFLOPS,
+                            achieved_direct_equiv=step_direct, traffic=None)
+            else:   # (a plan on the fp32 pipe: --fp32-mfma-gemms)
+                roof.update(kernel="whole denoising step, per GPU (per-launch profile skipped)", achieved=step_issued,
+                            frac=step_issued / FP32_PEAK_TFLOPS, achieved_direct_equiv=step_direct, traffic=None)
         roof["step"] = {
             "issued_tflops": step_issued, "issued_bf16_tflops": step_issued_bf16, "frac_issued": step_pipe_frac,
             "direct_equiv_tflops": step_direct, "device_ms": dev_ms_per_step,
