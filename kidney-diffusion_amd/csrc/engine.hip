@@ -661,37 +661,37 @@ struct Builder {
       const int64_t seg_per_image = (int64_t)seg_nseg * seg_nchunk * 2;   // doubles: [image][segment][chunk][2]
       const int64_t y_per_image = (int64_t)(o.out_mode == OUT_PIXSHUF ? 4 : 1) * Ho * Wo * p.ldy;   // floats
       for (int b0 = 0; b0 < x.B; b0 += Bset) {
-      // (every per-image pointer moved on by the set's first image)
-      const size_t xo_s = xo + (size_t)b0 * x.H * x.W * p.ldx * sizeof(float), yo_s = yo + (size_t)b0 * y_per_image * sizeof(float);
-      const size_t ro_s = ro + (size_t)b0 * Ho * Wo * p.ldres * sizeof(float), gso_s = gso + (size_t)b0 * Ho * Wo * p.ldgs * sizeof(float);
-      const size_t go_s = go + (size_t)b0 * Cout * sizeof(float), sego_s = sego + (size_t)b0 * seg_per_image * sizeof(double);
-      auto epi_of = [=]() {
-        X3Epi e = base;
-        e.res = has_res ? uu->P(ro_s) + res_coff : nullptr;
-        e.gate_src = has_gs ? uu->P(gso_s) : nullptr;
-        e.gate = has_gs ? uu->P(go_s) : nullptr;
-        if (seg_nseg) {   // the output feeds a GroupNorm: its partials from the epilogue (of the summing launch where tiles are cut in k)
-          e.seg = (double*)uu->P(sego_s);
-          e.seg_nseg = seg_nseg;
-          e.seg_coff = seg_coff;
-        }
-        return e;
-      };
-      const std::string shape = " M" + std::to_string(M) + " Cin" + std::to_string(Cin) + " Cout" + std::to_string(Cout);
-      const int64_t m = o.macs_override >= 0 ? o.macs_override : M * Cout * Cin;
-      const bool a_f32 = !x.x3p;   // (planes: written by the LayerNorm in front, the loader waves only move them)
-      emit([=](hipStream_t s) {
-        const X3Epi e = epi_of();
-        return launch_gemm_bf16x3(uu->P(xo_s), W3, uu->P(yo_s) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, a_f32, false, &e);
-      }, "conv k1 x3" + shape, m);
-      u->macs += m;
-      u->op_mfma.back() = 6 * M * Cout * Cin;   // bf16 MACs
-      u->mfma_bf16_macs += u->op_mfma.back();
-      if (gemm_bf16x3_needs_sum(1, (int)M, Cout, Cin))   // every tile cut in k (fewer tiles than CUs): the parts are added, and the epilogue applied, here
+        // (every per-image pointer moved on by the set's first image)
+        const size_t xo_s = xo + (size_t)b0 * x.H * x.W * p.ldx * sizeof(float), yo_s = yo + (size_t)b0 * y_per_image * sizeof(float);
+        const size_t ro_s = ro + (size_t)b0 * Ho * Wo * p.ldres * sizeof(float), gso_s = gso + (size_t)b0 * Ho * Wo * p.ldgs * sizeof(float);
+        const size_t go_s = go + (size_t)b0 * Cout * sizeof(float), sego_s = sego + (size_t)b0 * seg_per_image * sizeof(double);
+        auto epi_of = [=]() {
+          X3Epi e = base;
+          e.res = has_res ? uu->P(ro_s) + res_coff : nullptr;
+          e.gate_src = has_gs ? uu->P(gso_s) : nullptr;
+          e.gate = has_gs ? uu->P(go_s) : nullptr;
+          if (seg_nseg) {   // the output feeds a GroupNorm: its partials from the epilogue (of the summing launch where tiles are cut in k)
+            e.seg = (double*)uu->P(sego_s);
+            e.seg_nseg = seg_nseg;
+            e.seg_coff = seg_coff;
+          }
+          return e;
+        };
+        const std::string shape = " M" + std::to_string(M) + " Cin" + std::to_string(Cin) + " Cout" + std::to_string(Cout);
+        const int64_t m = o.macs_override >= 0 ? o.macs_override : M * Cout * Cin;
+        const bool a_f32 = !x.x3p;   // (planes: written by the LayerNorm in front, the loader waves only move them)
         emit([=](hipStream_t s) {
           const X3Epi e = epi_of();
-          return launch_gemm_bf16x3_sum(uu->P(yo_s) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, &e);
-        }, "conv k1 x3 sum" + shape);
+          return launch_gemm_bf16x3(uu->P(xo_s), W3, uu->P(yo_s) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, a_f32, false, &e);
+        }, "conv k1 x3" + shape, m);
+        u->macs += m;
+        u->op_mfma.back() = 6 * M * Cout * Cin;   // bf16 MACs
+        u->mfma_bf16_macs += u->op_mfma.back();
+        if (gemm_bf16x3_needs_sum(1, (int)M, Cout, Cin))   // every tile cut in k (fewer tiles than CUs): the parts are added, and the epilogue applied, here
+          emit([=](hipStream_t s) {
+            const X3Epi e = epi_of();
+            return launch_gemm_bf16x3_sum(uu->P(yo_s) + yoff, 1, (int)M, Cout, Cin, uu->x3_ws, s, &e);
+          }, "conv k1 x3 sum" + shape);
       }   // sets of images
       if (ks > 1) free(part);
       return y;
@@ -1143,52 +1143,52 @@ struct Builder {
     const bool sg = seg_on && Cout % 64 == 0;   // GroupNorm partials of y for whichever layer normalises it next
     const size_t sgo_all = sg ? add_seg(y, 0, Cout / 16, (H / 4) * (W / 4)) : 0;
     for (int st = 0; st < nset; ++st) {
-    const int b0 = st * Bx;   // first image of the set
-    {
-      size_t xo = x.at() + (size_t)b0 * HW * x.LD() * sizeof(float), vo = V.off;
-      size_t so = gn_stats_t.off + (size_t)b0 * G * 2 * sizeof(float), sso = t_ss.off + (size_t)b0 * tmlp_total * sizeof(float);
-      const int ld = tmlp_total, ldx = x.LD();
-      emit([=](hipStream_t s) {
-        const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
-        if (x3_planes)
-          return launch_wino4_in3(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s, skip_c0, skip_scale);
-        return launch_wino4_in(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s, skip_c0, skip_scale);
-      }, (x3_planes ? "wino4_in3" : "wino4_in") + shape);
-    }
-    if (x3) {
-      const float* U3 = cached("wino4x3:" + conv_prefix, ((size_t)36 * Cout * Cin * 3 + 1) / 2,
-                               [&](float* dst) { KD_THROW_IF(launch_split3(U, dst, 36, Cout, Cin, 0)); });
-      const size_t vo = V.off, d_o = D.off;
-      const int64_t macs = (int64_t)Bx * HW * Cout * Cin * 9;   // the algorithmic MACs of the 3x3 conv it replaces
-      if (!u->x3_ws) KD_HIP_THROW(hipMalloc(&u->x3_ws, gemm_bf16x3_workspace_bytes()));
-      emit([=](hipStream_t s) { return launch_gemm_bf16x3(uu->P(vo), U3, uu->P(d_o), 36, (int)Mt, Cout, Cin, uu->x3_ws, s, !x3_planes, false); },
-           "wino4 gemm bf16x3" + shape, macs);
-      u->macs += macs;
-      u->op_mfma.back() = 6 * 36 * Mt * Cout * Cin;   // bf16 MACs
-      u->mfma_bf16_macs += u->op_mfma.back();
-      if (gemm_bf16x3_needs_sum(36, (int)Mt, Cout, Cin))   // the left-over tiles' k-parts (its own launch: the whole chip adds them)
-        emit([=](hipStream_t s) { return launch_gemm_bf16x3_sum(uu->P(d_o), 36, (int)Mt, Cout, Cin, uu->x3_ws, s); },
-             "wino4 x3 sum" + shape);
-    } else {
-      ConvOpt o;
-      o.wz_rows = (int)Mt;
-      o.wz_count = 36;
-      o.dst = &D;
-      o.macs_override = (int64_t)Bx * HW * Cout * Cin * 9;   // the algorithmic MACs of the 3x3 conv it replaces
-      conv(V, U, nullptr, Cout, 1, 1, 0, o);
-      if (!to_text && !to_static) u->op_label.back() = "wino4 gemm" + shape;
-    }
-    {
-      const size_t sgo = sgo_all + (size_t)b0 * (Cout / 16) * ((H / 4) * (W / 4)) * 2 * sizeof(double);
-      size_t d_o = D.off, yo = y.off + (size_t)b0 * HW * Cout * sizeof(float);
-      const bool hr = res != nullptr;
-      const int ldres = res ? res->LD() : 0;
-      size_t ro = res ? res->at() + (size_t)b0 * HW * ldres * sizeof(float) : 0;
-      emit([=](hipStream_t s) {
-        return launch_wino4_out(uu->P(d_o), bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Cout,
-                                sg ? (double*)uu->P(sgo) : nullptr, Bx, H, W, Cout, s);
-      }, "wino4_out" + shape);
-    }
+      const int b0 = st * Bx;   // first image of the set
+      {
+        size_t xo = x.at() + (size_t)b0 * HW * x.LD() * sizeof(float), vo = V.off;
+        size_t so = gn_stats_t.off + (size_t)b0 * G * 2 * sizeof(float), sso = t_ss.off + (size_t)b0 * tmlp_total * sizeof(float);
+        const int ld = tmlp_total, ldx = x.LD();
+        emit([=](hipStream_t s) {
+          const float* ssp = ss_col >= 0 ? uu->P(sso) + ss_col : nullptr;
+          if (x3_planes)
+            return launch_wino4_in3(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s, skip_c0, skip_scale);
+          return launch_wino4_in(uu->P(xo), ldx, uu->P(so), gamma, beta, ssp, ld, uu->P(vo), Bx, H, W, Cin, G, s, skip_c0, skip_scale);
+        }, (x3_planes ? "wino4_in3" : "wino4_in") + shape);
+      }
+      if (x3) {
+        const float* U3 = cached("wino4x3:" + conv_prefix, ((size_t)36 * Cout * Cin * 3 + 1) / 2,
+                                 [&](float* dst) { KD_THROW_IF(launch_split3(U, dst, 36, Cout, Cin, 0)); });
+        const size_t vo = V.off, d_o = D.off;
+        const int64_t macs = (int64_t)Bx * HW * Cout * Cin * 9;   // the algorithmic MACs of the 3x3 conv it replaces
+        if (!u->x3_ws) KD_HIP_THROW(hipMalloc(&u->x3_ws, gemm_bf16x3_workspace_bytes()));
+        emit([=](hipStream_t s) { return launch_gemm_bf16x3(uu->P(vo), U3, uu->P(d_o), 36, (int)Mt, Cout, Cin, uu->x3_ws, s, !x3_planes, false); },
+             "wino4 gemm bf16x3" + shape, macs);
+        u->macs += macs;
+        u->op_mfma.back() = 6 * 36 * Mt * Cout * Cin;   // bf16 MACs
+        u->mfma_bf16_macs += u->op_mfma.back();
+        if (gemm_bf16x3_needs_sum(36, (int)Mt, Cout, Cin))   // the left-over tiles' k-parts (its own launch: the whole chip adds them)
+          emit([=](hipStream_t s) { return launch_gemm_bf16x3_sum(uu->P(d_o), 36, (int)Mt, Cout, Cin, uu->x3_ws, s); },
+               "wino4 x3 sum" + shape);
+      } else {
+        ConvOpt o;
+        o.wz_rows = (int)Mt;
+        o.wz_count = 36;
+        o.dst = &D;
+        o.macs_override = (int64_t)Bx * HW * Cout * Cin * 9;   // the algorithmic MACs of the 3x3 conv it replaces
+        conv(V, U, nullptr, Cout, 1, 1, 0, o);
+        if (!to_text && !to_static) u->op_label.back() = "wino4 gemm" + shape;
+      }
+      {
+        const size_t sgo = sgo_all + (size_t)b0 * (Cout / 16) * ((H / 4) * (W / 4)) * 2 * sizeof(double);
+        size_t d_o = D.off, yo = y.off + (size_t)b0 * HW * Cout * sizeof(float);
+        const bool hr = res != nullptr;
+        const int ldres = res ? res->LD() : 0;
+        size_t ro = res ? res->at() + (size_t)b0 * HW * ldres * sizeof(float) : 0;
+        emit([=](hipStream_t s) {
+          return launch_wino4_out(uu->P(d_o), bias, hr ? uu->P(ro) : nullptr, ldres, uu->P(yo), Cout,
+                                  sg ? (double*)uu->P(sgo) : nullptr, Bx, H, W, Cout, s);
+        }, "wino4_out" + shape);
+      }
     }   // sets
     free(V);
     free(D);
