@@ -224,7 +224,7 @@ __global__ __launch_bounds__(768) void gemm_bf16x3_kernel(const uint16_t* __rest
       const uint32_t soA = gather ? (uint32_t)((((tap >> 1) * e.a_wi + (tap & 1)) * lda + kc * BK) * 4) : baseA + (uint32_t)(ik * (BK * 4));
 #pragma unroll
       for (int j = 0; j < NR; ++j)
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[set][j]) : "v"(voffAj[j]), "s"(rsA), "s"(soA) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(ra[set][j]) : "v"(voffAj[j]), "s"(rsA), "s"(soA) : "memory");
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int id = l * 3 + j, pl = id >> 2, pr = id & 3;
