@@ -460,6 +460,43 @@ def test_philox_host_reference_is_standard_normal_and_keyed():
     assert np.array_equal(a[:1001], philox_normal(1001, 1, 2))  # prefix-stable
 
 
+def test_fp32_a_loader_waves_keep_their_hand_placed_waits(tmp_path):
+    """gemm_bf16x3_kernel<true, *>: the loader waves' A loads are inline assembly and their `s_waitcnt vmcnt` are placed by
+    hand (kernels_gemm_bf16x3.hip: hipcc's own bookkeeping made every use wait for all outstanding accesses).  Two things the
+    compiler must not do to that code, checked in the assembly it emits: copy a register whose load is still in flight (it
+    did, in front of the waits, when the waits of the tail cases were separate statements - wrong results), or add waits of
+    its own for the loaded registers."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    csrc = ROOT / "kidney-diffusion_amd" / "csrc"
+    out = tmp_path / "x3.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--cuda-device-only", "-S",
+                        str(csrc / "kernels_gemm_bf16x3.hip"), f"-I{csrc}", f"-I{ROOT / 'include'}", "-o", str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    checked = 0
+    for m in re.finditer(r"^(_ZN2kd18gemm_bf16x3_kernelILb1E\S+):[^\n]*\n(.*?)\n\.Lfunc_end", asm, re.S | re.M):
+        ins = [l.split(";")[0].strip() for l in m.group(2).split("\n")]
+        ins = [l for l in ins if l and not l.startswith(".") and not l.endswith(":")]
+        dma = [i for i, l in enumerate(ins) if l.startswith("buffer_load_dwordx4") and l.endswith(" lds")]
+        # the loader waves' code: from the first register load that shares the DMAs' neighbourhood to the last DMA
+        loads = [i for i, l in enumerate(ins) if re.match(r"buffer_load_dwordx4 v\[\d+:\d+\], v\d+, s\[\d+:\d+\], s\d+ offen$", l)
+                 and dma and dma[0] - 400 < i < dma[-1]]
+        assert dma and len(loads) >= 16, (m.group(1), len(dma), len(loads))
+        region = ins[loads[0]:dma[-1] + 40]
+        assert not [l for l in region if re.match(r"v_mov_b(32|64)(_e32)? v\[?\d+[:\d\]]*, v", l)], m.group(1)
+        waits = [l for l in region if l.startswith("s_waitcnt") and "vmcnt" in l]
+        counts = sorted({int(re.search(r"vmcnt\((\d+)\)", l).group(1)) for l in waits})
+        assert counts == [0, 14, 17], (m.group(1), counts)   # the tail's plain wait, B pieces landed, A values landed
+        checked += 1
+    assert checked == 3   # epilogue kinds 0, 1, 2
+
+
 def test_kernels_with_counted_vmcnt_waits_use_no_scratch(tmp_path):
     """conv_buf_kernel and wino_fused_kernel pace their LDS-DMA pipelines with counted `s_waitcnt vmcnt(N)`.
     A register spill would add scratch loads / stores to the same counter and let a barrier pass before the
